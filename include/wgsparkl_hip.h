@@ -1,0 +1,216 @@
+/*
+ * wgsparkl_hip.h — C ABI of the MI355X-native MLS-MPM step (drop-in for the
+ * one hot path of dimforge/wgsparkl: `MpmPipeline::queue_step`).
+ *
+ * Build twice, like the reference builds its two crates from one source tree
+ * (Cargo.toml:1-8): -DWGS_DIM=3 -> libwgsparkl3d_hip.so, -DWGS_DIM=2 ->
+ * libwgsparkl2d_hip.so. Both export the same symbol names.
+ *
+ * Every entry point cites the reference interface it replaces (paths relative
+ * to /root/reference). Plain pointers and sizes only; no exceptions cross the
+ * boundary; every call returns a wgs_status (0 = ok) and leaves a message for
+ * wgs_last_error(). Handles are not internally synchronised: one host thread
+ * per wgs_data at a time (the reference calls from one Bevy system,
+ * src_testbed/lib.rs:60-69).
+ */
+#ifndef WGSPARKL_HIP_H
+#define WGSPARKL_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifndef WGS_DIM
+#define WGS_DIM 3
+#endif
+
+#if WGS_DIM == 2
+#define WGS_ANG_DIM 1
+#else
+#define WGS_ANG_DIM 3
+#endif
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef int32_t wgs_status;
+enum {
+    WGS_OK = 0,
+    WGS_ERR_INVALID_ARGUMENT = 1,
+    WGS_ERR_NO_DEVICE = 2,       /* no HIP device / HIP runtime failure at creation */
+    WGS_ERR_HIP = 3,             /* a HIP call failed; see wgs_last_error() */
+    WGS_ERR_GRID_OVERFLOW = 4,   /* more active blocks than grid_capacity (the reference drops them silently, src/grid/grid.wgsl:126-128,163) */
+    WGS_ERR_KEY_RANGE = 5,       /* a block left the packed-key range (src/grid/grid.wgsl:88-95; quirk B5) */
+    WGS_ERR_UNSUPPORTED = 6
+};
+
+/* src/solver/params.rs:6-16 SimulationParams (2D: gravity[2]; the f32 padding is not exposed). */
+typedef struct {
+    float gravity[WGS_DIM];
+    float dt;
+} wgs_sim_params;
+
+/* src/models/mod.rs:65-70 ElasticCoefficients */
+typedef struct { float lambda, mu; } wgs_elastic_coefficients;
+/* src/models/drucker_prager.rs:6-15 DruckerPrager */
+typedef struct { float h0, h1, h2, h3, lambda, mu; } wgs_drucker_prager;
+/* src/models/drucker_prager.rs:36-42 DruckerPragerPlasticState */
+typedef struct { float plastic_deformation_gradient_det, plastic_hardening, log_vol_gain; } wgs_plastic_state;
+/* src/solver/particle_update.rs:35-40 ParticlePhase */
+typedef struct { float phase, max_stretch; } wgs_particle_phase;
+
+/* src/solver/particle3d.rs:44-51 / particle2d.rs:42-49 Cdf */
+typedef struct {
+    float normal[WGS_DIM];
+    float rigid_vel[WGS_DIM];
+    float signed_distance;
+    uint32_t affinity;
+} wgs_cdf;
+
+/* src/solver/particle3d.rs:16-26 ParticleDynamics, Rust field order; matrices column-major (nalgebra). */
+typedef struct {
+    float velocity[WGS_DIM];
+    float def_grad[WGS_DIM * WGS_DIM];
+    float affine[WGS_DIM * WGS_DIM];
+    wgs_cdf cdf;
+    float init_volume;
+    float init_radius;
+    float mass;
+} wgs_particle_dynamics;
+
+/* src/solver/particle3d.rs:53-60 Particle. Option<T> is flattened to has_* + value;
+ * has_* == 0 applies the reference defaults of src/models/mod.rs:24,33-36. */
+typedef struct {
+    float position[WGS_DIM];
+    wgs_particle_dynamics dynamics;
+    wgs_elastic_coefficients model;
+    uint32_t has_plasticity;
+    wgs_drucker_prager plasticity;
+    uint32_t has_phase;
+    wgs_particle_phase phase;
+} wgs_particle;
+
+/* One coupled collider: what MpmData::new keeps of rapier's (RigidBody, Collider)
+ * pair (src/pipeline.rs:107-117 -> wgrapier GpuBodySet: shape, pose, velocity,
+ * world mass properties). Only analytic shapes are handled, like collide()
+ * (src/collision/collide.wgsl:36-38 skips polylines and trimeshes). */
+enum { WGS_SHAPE_BALL = 0, WGS_SHAPE_CUBOID = 1, WGS_SHAPE_CAPSULE = 2 };
+typedef struct {
+    float rotation[4];     /* 3D: unit quaternion (i, j, k, w); 2D: (cos, sin, 0, 0) */
+    float translation[3];
+    float scale;
+} wgs_pose;                /* wgebra Sim3 / Sim2 */
+typedef struct {
+    float linear[3];
+    float angular[3];      /* 2D: angular[0] */
+} wgs_velocity;            /* wgrapier Body::Velocity */
+typedef struct {
+    uint32_t shape_type;   /* WGS_SHAPE_* */
+    float shape[4];        /* ball: r | cuboid: half extents | capsule: half height (local y), r */
+    wgs_pose pose;
+    wgs_velocity velocity;
+    float com[3];          /* world-space centre of mass (wgrapier MassProperties.com) */
+} wgs_collider;
+#define WGS_MAX_COLLIDERS 16 /* src/grid/grid.wgsl:230-240: 16 affinity + 16 sign bits */
+
+/* Constitutive model (the reference picks at shader-compile time,
+ * src/solver/particle_update.wgsl:7-8; default = corotated like the reference). */
+enum { WGS_MODEL_COROTATED = 0, WGS_MODEL_NEO_HOOKEAN = 1 };
+
+/* The reference's 10 timestamped passes (src/pipeline.rs:201-271). The fused
+ * G2P + particle update reports its time under WGS_PASS_G2P and 0 under
+ * WGS_PASS_PARTICLES_UPDATE. */
+enum {
+    WGS_PASS_UPDATE_RIGID_PARTICLES = 0, WGS_PASS_GRID_SORT = 1, WGS_PASS_GRID_UPDATE_CDF = 2,
+    WGS_PASS_P2G_CDF = 3, WGS_PASS_G2P_CDF = 4, WGS_PASS_P2G = 5, WGS_PASS_GRID_UPDATE = 6,
+    WGS_PASS_G2P = 7, WGS_PASS_PARTICLES_UPDATE = 8, WGS_PASS_INTEGRATE_BODIES = 9,
+    WGS_NUM_PASSES = 10
+};
+
+/* Grid node keyed by world cell coordinate (active blocks are numbered by an
+ * atomic counter in the reference, src/grid/grid.wgsl:327, so physical ids are
+ * not comparable between runs; virtual ids are). */
+typedef struct {
+    int32_t cell[WGS_DIM];
+    float velocity[WGS_DIM];   /* momentum_velocity_mass.xyz after the grid update */
+    float mass;
+    float cdf_distance;
+    uint32_t cdf_affinities;
+    uint32_t cdf_closest_id;
+} wgs_node_record;
+
+/* src/grid/grid.rs:250-256 GpuActiveBlockHeader */
+typedef struct {
+    int32_t virtual_id[WGS_DIM];
+    uint32_t first_particle;
+    uint32_t num_particles;
+} wgs_block_record;
+
+typedef struct {
+    uint32_t num_particles;
+    uint32_t num_active_blocks;   /* of the last executed substep */
+    uint32_t grid_capacity;       /* rounded up to a power of two like src/grid/grid.rs:283 */
+    uint32_t overflow;            /* sticky: WGS_ERR_GRID_OVERFLOW / WGS_ERR_KEY_RANGE seen on device */
+    uint64_t substeps_done;
+    uint64_t device_bytes;        /* HBM held by this wgs_data */
+} wgs_stats;
+
+typedef struct wgs_pipeline wgs_pipeline;
+typedef struct wgs_data wgs_data;
+
+/* Thread-local message of the last failing call on this thread. */
+const char *wgs_last_error(void);
+/* 2 or 3: the dimension this library was built for (cargo features dim2/dim3, src/lib.rs:4-15). */
+int32_t wgs_dim(void);
+
+/* MpmPipeline::new(&Device) -> Result<Self, ComposerError>  (src/pipeline.rs:176-193).
+ * Binds to HIP device `hip_device`; fails with WGS_ERR_NO_DEVICE when there is none
+ * (there is no CPU fallback). */
+wgs_status wgs_pipeline_create(int32_t hip_device, wgs_pipeline **out);
+void wgs_pipeline_destroy(wgs_pipeline *pipeline);
+
+/* MpmData::new(device, params, &[Particle], &RigidBodySet, &ColliderSet, cell_width, grid_capacity)
+ * (src/pipeline.rs:98-128). `particles`/`colliders` are borrowed for the call only. */
+wgs_status wgs_data_create(wgs_pipeline *pipeline, const wgs_sim_params *params,
+                           const wgs_particle *particles, size_t num_particles,
+                           const wgs_collider *colliders, size_t num_colliders,
+                           float cell_width, uint32_t grid_capacity, wgs_data **out);
+void wgs_data_destroy(wgs_data *data);
+
+/* Runtime replacement for the compile-time import at src/solver/particle_update.wgsl:7-8. */
+wgs_status wgs_set_constitutive_model(wgs_data *data, int32_t model);
+
+/* MpmPipeline::queue_step + `for _ in 0..num_substeps { queue.encode(..) }` + submit
+ * (src/pipeline.rs:195-281, src_testbed/step.rs:122-128,169): enqueues `num_substeps`
+ * substeps on the data's HIP stream and returns without waiting. `timestamps` != 0
+ * brackets each pass with HIP events (src/pipeline.rs:201-271 compute_pass(name, add_timestamps)). */
+wgs_status wgs_step(wgs_pipeline *pipeline, wgs_data *data, uint32_t num_substeps, int32_t timestamps);
+/* device.poll(Maintain::Wait) (src/pipeline.rs:339). Also reports device-side sticky errors. */
+wgs_status wgs_sync(wgs_data *data);
+
+/* queue.write_buffer(sim_params) from the UI (src_testbed/ui.rs:91-104) */
+wgs_status wgs_set_sim_params(wgs_data *data, const wgs_sim_params *params);
+/* queue.write_buffer(bodies.poses()) (src_testbed/step.rs:79-96); com is refreshed by the caller too */
+wgs_status wgs_set_collider_poses(wgs_data *data, const wgs_pose *poses, const float *coms /* n*3 or NULL */, size_t n);
+/* queue.write_buffer(bodies.vels()) (src_testbed/step.rs:98-119) */
+wgs_status wgs_set_body_velocities(wgs_data *data, const wgs_velocity *vels, size_t n);
+
+/* positions is the only particle buffer the reference creates COPY_SRC (src/solver/particle3d.rs:197-201).
+ * out: num_particles * WGS_DIM floats, in the caller's original particle order. Blocking. */
+wgs_status wgs_read_positions(wgs_data *data, float *out);
+/* Full particle state in the caller's original order (tests / checkpoint). Blocking. */
+wgs_status wgs_read_particles(wgs_data *data, wgs_particle *out, wgs_plastic_state *plastic_out /* may be NULL */);
+/* Sparse grid of the last substep: nodes of every active block. *count receives the number written. */
+wgs_status wgs_read_grid(wgs_data *data, wgs_node_record *out, size_t capacity, size_t *count);
+/* Active block headers + the sorted particle ids (GpuParticles.sorted_ids, src/solver/particle3d.rs:178-180)
+ * of the last substep. sorted_ids may be NULL. */
+wgs_status wgs_read_blocks(wgs_data *data, wgs_block_record *out, size_t capacity, size_t *count, uint32_t *sorted_ids);
+/* GpuTimestamps read-back (src_testbed/step.rs:219-251): ms per pass summed over the substeps of the
+ * last wgs_step(.., timestamps=1) call. */
+wgs_status wgs_read_timings(wgs_data *data, float ms[WGS_NUM_PASSES]);
+wgs_status wgs_get_stats(wgs_data *data, wgs_stats *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* WGSPARKL_HIP_H */

@@ -1,0 +1,690 @@
+// capi.hip — host side of the C ABI declared in include/wgsparkl_hip.h.
+//
+// Host-language note: the reference's host code is Rust (src/pipeline.rs); this
+// image has no Rust toolchain, so the host side above the C ABI is C++ here and
+// the Rust shim a maintainer would add is shown in INTEGRATION.md / rust/.
+//
+// One wgs_data owns one HIP stream and every device buffer of a simulation
+// (MpmData owns every wgpu buffer, src/pipeline.rs:84-95). wgs_step only
+// enqueues; nothing on the step path synchronises with the host.
+#include "../../include/wgsparkl_hip.h"
+
+#include <cfloat>
+#include <cstddef>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "kernels_cdf.h"
+#include "kernels_sort.h"
+#include "kernels_transfer.h"
+
+using namespace wgs;
+
+namespace {
+
+constexpr int D = WGS_DIM;
+constexpr int DD = D * D;
+using P = Pl<D>;
+
+thread_local std::string g_last_error;
+
+wgs_status fail(wgs_status code, const std::string &msg) {
+    g_last_error = msg;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                                   \
+    do {                                                                                                \
+        hipError_t _e = (expr);                                                                         \
+        if (_e != hipSuccess)                                                                           \
+            return fail(WGS_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e));                \
+    } while (0)
+
+struct Events {
+    static constexpr int MAX_SUBSTEPS = 64;
+    static constexpr int MARKS = 8;  // boundaries: start, sort, cdf_nodes, cdf_particles, p2g, grid, g2p(end)
+    hipEvent_t ev[MAX_SUBSTEPS][MARKS];
+    int used = 0;
+    bool created = false;
+};
+
+}  // namespace
+
+struct wgs_pipeline {
+    int device = 0;
+    int num_cus = 256;
+    hipDeviceProp_t props;
+};
+
+struct wgs_data {
+    wgs_pipeline *pipeline = nullptr;
+    hipStream_t stream = nullptr;
+    Dev dev{};
+    int side = 0;
+    bool plastic = false;
+    bool cpic = false;
+    bool deterministic = true;
+    uint64_t substeps = 0;
+    uint64_t device_bytes = 0;
+    uint32_t sticky_errors = 0;
+    uint32_t last_nblocks = 0;
+    std::vector<void *> allocs;
+    // by-pid static tables (never reordered)
+    float *static_radius = nullptr;
+    float *static_dp = nullptr;     // n*6
+    float *static_phase = nullptr;  // n*2
+    uint32_t *static_flags = nullptr;  // bit0 has_plasticity, bit1 has_phase
+    SimParamsDev *sp = nullptr;
+    ColliderDev *colliders = nullptr;
+    std::vector<ColliderDev> host_colliders;
+    SimParamsDev host_sp{};
+    Events events;
+    float timings[WGS_NUM_PASSES] = {0};
+    bool timings_pending = false;
+};
+
+namespace {
+
+template <typename T> wgs_status dev_alloc(wgs_data *d, T **out, size_t count, bool zero = true) {
+    void *p = nullptr;
+    size_t bytes = sizeof(T) * (count ? count : 1);
+    HIP_TRY(hipMalloc(&p, bytes));
+    if (zero) HIP_TRY(hipMemsetAsync(p, 0, bytes, d->stream));
+    d->allocs.push_back(p);
+    d->device_bytes += bytes;
+    *out = static_cast<T *>(p);
+    return WGS_OK;
+}
+
+uint32_t next_pow2(uint32_t v) {
+    uint32_t p = 1;
+    while (p < v) p <<= 1;
+    return p;
+}
+
+void fill_collider(ColliderDev &c, const wgs_collider &in) {
+    c.shape_type = in.shape_type;
+    for (int k = 0; k < 4; k++) c.shape[k] = in.shape[k];
+    for (int k = 0; k < 4; k++) c.rot[k] = in.pose.rotation[k];
+    for (int k = 0; k < 3; k++) c.trans[k] = in.pose.translation[k];
+    c.scale = in.pose.scale;
+    for (int k = 0; k < 3; k++) c.linvel[k] = in.velocity.linear[k];
+    for (int k = 0; k < 3; k++) c.angvel[k] = in.velocity.angular[k];
+    for (int k = 0; k < 3; k++) c.com[k] = in.com[k];
+}
+
+int grid_for(const wgs_data *d, int blocks_per_cu) { return d->pipeline->num_cus * blocks_per_cu; }
+
+// ---- read-back kernels ---------------------------------------------------
+struct ParticleOffsets {  // word offsets inside wgs_particle
+    uint32_t stride, pos, vel, F, C, nrm, rvel, dist, aff, vol, rad, mass, lam, mu, has_pl, dp, has_ph, phase;
+};
+
+__global__ void k_export_particles(Dev d, int side, ParticleOffsets o, bool plastic, bool cpic, const float *s_radius,
+                                   const float *s_dp, const float *s_phase, const uint32_t *s_flags, float *out,
+                                   float *plastic_out) {
+    const float *in = d.buf[side];
+    const uint32_t npad = d.npad;
+    for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < d.n; j += gridDim.x * blockDim.x) {
+        const uint32_t pid = __float_as_uint(in[(size_t)P::PID * npad + j]);
+        float *r = out + (size_t)pid * o.stride;
+        for (int k = 0; k < D; k++) {
+            r[o.pos + k] = in[(size_t)(P::POS + k) * npad + j];
+            r[o.vel + k] = in[(size_t)(P::VEL + k) * npad + j];
+            r[o.nrm + k] = cpic ? in[(size_t)(P::NRM + k) * npad + j] : 0.f;
+            r[o.rvel + k] = cpic ? in[(size_t)(P::RVEL + k) * npad + j] : 0.f;
+        }
+        for (int k = 0; k < DD; k++) {
+            r[o.F + k] = in[(size_t)(P::F + k) * npad + j];
+            r[o.C + k] = in[(size_t)(P::C + k) * npad + j];
+        }
+        r[o.dist] = cpic ? in[(size_t)P::DIST * npad + j] : 0.f;
+        r[o.aff] = cpic ? in[(size_t)P::AFF * npad + j] : 0.f;
+        r[o.vol] = in[(size_t)P::VOL * npad + j];
+        r[o.rad] = s_radius[pid];
+        r[o.mass] = in[(size_t)P::MASS * npad + j];
+        r[o.lam] = in[(size_t)P::LAM * npad + j];
+        r[o.mu] = in[(size_t)P::MU * npad + j];
+        const uint32_t fl = s_flags[pid];
+        r[o.has_pl] = __uint_as_float(fl & 1u);
+        r[o.has_ph] = __uint_as_float((fl >> 1) & 1u);
+        for (int k = 0; k < 6; k++) r[o.dp + k] = s_dp[(size_t)pid * 6 + k];
+        if (plastic) {
+            r[o.phase] = in[(size_t)P::PHASE * npad + j];
+            r[o.phase + 1] = in[(size_t)(P::PHASE + 1) * npad + j];
+        } else {
+            r[o.phase] = s_phase[(size_t)pid * 2];
+            r[o.phase + 1] = s_phase[(size_t)pid * 2 + 1];
+        }
+        if (plastic_out) {
+            for (int k = 0; k < 3; k++)
+                plastic_out[(size_t)pid * 3 + k] = plastic ? in[(size_t)(P::DPS + k) * npad + j] : (k < 2 ? 1.f : 0.f);
+        }
+    }
+}
+
+__global__ void k_export_positions(Dev d, int side, float *out) {
+    const float *in = d.buf[side];
+    for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < d.n; j += gridDim.x * blockDim.x) {
+        const uint32_t pid = __float_as_uint(in[(size_t)P::PID * d.npad + j]);
+        for (int k = 0; k < D; k++) out[(size_t)pid * D + k] = in[(size_t)(P::POS + k) * d.npad + j];
+    }
+}
+
+__global__ void k_export_grid(Dev d, uint32_t nblocks, bool cpic, wgs_node_record *out) {
+    constexpr int BW = Dim<D>::BW, BS = Dim<D>::BSHIFT;
+    const uint32_t total = nblocks * NPB;
+    for (uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; t < total; t += gridDim.x * blockDim.x) {
+        const uint32_t b = t >> 6, ln = t & 63u;
+        int bc[3] = {0, 0, 0};
+        unpack_key<D>(d.block_key[b], bc);
+        int l[3] = {(int)(ln & (BW - 1)), (int)((ln >> BS) & (BW - 1)), D == 3 ? (int)(ln >> (2 * BS)) : 0};
+        wgs_node_record r;
+        for (int k = 0; k < D; k++) r.cell[k] = bc[k] * BW + l[k];
+        float4 v = d.nodes[t];
+        r.velocity[0] = v.x;
+        r.velocity[1] = v.y;
+        if (D == 3) { r.velocity[D - 1] = v.z; r.mass = v.w; } else { r.mass = v.z; }
+        NodeCdf c = {0.f, 0u, NONE, 0u};
+        if (cpic) c = d.node_cdf[t];
+        r.cdf_distance = c.distance;
+        r.cdf_affinities = c.affinities;
+        r.cdf_closest_id = c.closest_id;
+        out[t] = r;
+    }
+}
+
+__global__ void k_export_blocks(Dev d, uint32_t nblocks, wgs_block_record *out) {
+    for (uint32_t b = blockIdx.x * blockDim.x + threadIdx.x; b < nblocks; b += gridDim.x * blockDim.x) {
+        int bc[3] = {0, 0, 0};
+        unpack_key<D>(d.block_key[b], bc);
+        wgs_block_record r;
+        for (int k = 0; k < D; k++) r.virtual_id[k] = bc[k];
+        r.first_particle = d.block_start[b];
+        r.num_particles = d.block_count[b];
+        out[b] = r;
+    }
+}
+
+wgs_status fetch_counters(wgs_data *d) {
+    uint32_t host[CTR_COUNT];
+    HIP_TRY(hipMemcpyAsync(host, d->dev.counters, sizeof(host), hipMemcpyDeviceToHost, d->stream));
+    HIP_TRY(hipStreamSynchronize(d->stream));
+    d->last_nblocks = host[CTR_NBLOCKS] < d->dev.cap ? host[CTR_NBLOCKS] : d->dev.cap;
+    d->sticky_errors |= host[CTR_ERRORS];
+    if (host[CTR_NBLOCKS] > d->dev.cap) d->sticky_errors |= ERRBIT_OVERFLOW;
+    return WGS_OK;
+}
+
+wgs_status sticky_status(wgs_data *d) {
+    if (d->sticky_errors & ERRBIT_OVERFLOW)
+        return fail(WGS_ERR_GRID_OVERFLOW, "sparse grid overflow: more active blocks than grid_capacity");
+    if (d->sticky_errors & ERRBIT_KEYRANGE)
+        return fail(WGS_ERR_KEY_RANGE, "a particle left the packed block-key range (grid.wgsl:88-95)");
+    return WGS_OK;
+}
+
+void resolve_timings(wgs_data *d) {
+    if (!d->timings_pending) return;
+    hipStreamSynchronize(d->stream);
+    for (int p = 0; p < WGS_NUM_PASSES; p++) d->timings[p] = 0.f;
+    // marks: 0 start | 1 after sort | 2 after node cdf | 3 after particle cdf | 4 after p2g | 5 after grid update | 6 after fused g2p
+    const int pass_of_mark[6] = {WGS_PASS_GRID_SORT, WGS_PASS_GRID_UPDATE_CDF, WGS_PASS_G2P_CDF,
+                                 WGS_PASS_P2G,       WGS_PASS_GRID_UPDATE,     WGS_PASS_G2P};
+    for (int s = 0; s < d->events.used; s++)
+        for (int m = 0; m < 6; m++) {
+            float ms = 0.f;
+            if (hipEventElapsedTime(&ms, d->events.ev[s][m], d->events.ev[s][m + 1]) == hipSuccess)
+                d->timings[pass_of_mark[m]] += ms;
+        }
+    d->timings_pending = false;
+}
+
+// One substep = pipeline.rs:201-280 (MPM passes), enqueued on the data's stream.
+template <bool TS> wgs_status enqueue_substep(wgs_data *d, int ts_slot) {
+    Dev &dev = d->dev;
+    hipStream_t s = d->stream;
+    const int side = d->side;
+    const uint32_t n = dev.n;
+    const int pgrid = (int)((n + SORT_THREADS - 1) / SORT_THREADS);
+    auto mark = [&](int m) {
+        if (TS) hipEventRecord(d->events.ev[ts_slot][m], s);
+    };
+    mark(0);
+    // ---- "grid sort" (grid.rs:30-207)
+    HIP_TRY(hipMemsetAsync(dev.hkeys, 0xff, sizeof(uint32_t) * ((size_t)dev.hmask + 1), s));   // reset_hmap
+    HIP_TRY(hipMemsetAsync(dev.counters + CTR_NBLOCKS, 0, sizeof(uint32_t), s));
+    if (n > 0) {
+        hipLaunchKernelGGL(k_touch_blocks<D>, dim3(pgrid), dim3(SORT_THREADS), 0, s, dev, side);
+        hipLaunchKernelGGL(k_block_links<D>, dim3(grid_for(d, 4)), dim3(SORT_THREADS), 0, s, dev);
+        hipLaunchKernelGGL(k_count<D>, dim3(pgrid), dim3(SORT_THREADS), 0, s, dev, side);
+        hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(SCAN_THREADS), 0, s, dev);
+        hipLaunchKernelGGL(k_cell_offsets, dim3(grid_for(d, 4)), dim3(SORT_THREADS), 0, s, dev);
+        hipLaunchKernelGGL(k_scatter, dim3(pgrid), dim3(SORT_THREADS), 0, s, dev);
+        if (d->deterministic)
+            hipLaunchKernelGGL(k_canonical_order<D>, dim3(grid_for(d, 4)), dim3(SORT_THREADS), 0, s, dev, side);
+    }
+    mark(1);
+    // ---- "grid_update_cdf" + "g2p_cdf" (collide.wgsl, grid_update_cdf.wgsl, g2p_cdf.wgsl)
+    if (d->cpic && n > 0) {
+        hipLaunchKernelGGL(k_node_cdf<D>, dim3(grid_for(d, 4)), dim3(256), 0, s, dev);
+        mark(2);
+        hipLaunchKernelGGL(k_particle_cdf<D>, dim3(grid_for(d, 4)), dim3(G2P_THREADS), 0, s, dev, side);
+        mark(3);
+    } else {
+        mark(2);
+        mark(3);
+    }
+    if (n > 0) {
+        // ---- "p2g"
+        if (d->cpic)
+            hipLaunchKernelGGL((k_p2g<D, true>), dim3(grid_for(d, 2)), dim3(P2GCfg<D>::THREADS), 0, s, dev, side);
+        else
+            hipLaunchKernelGGL((k_p2g<D, false>), dim3(grid_for(d, 2)), dim3(P2GCfg<D>::THREADS), 0, s, dev, side);
+        mark(4);
+        // ---- "grid_update"
+        hipLaunchKernelGGL(k_grid_update<D>, dim3(grid_for(d, 4)), dim3(256), 0, s, dev);
+        mark(5);
+        // ---- "g2p" + "particles_update", fused
+        const int g = grid_for(d, 4);
+#define WGS_LAUNCH_G2P(MODEL, PL, CP) \
+    hipLaunchKernelGGL((k_g2p_update<D, MODEL, PL, CP>), dim3(g), dim3(G2P_THREADS), 0, s, dev, side)
+        const int sel = (dev.model == WGS_MODEL_NEO_HOOKEAN ? 4 : 0) | (d->plastic ? 2 : 0) | (d->cpic ? 1 : 0);
+        switch (sel) {
+            case 0: WGS_LAUNCH_G2P(0, false, false); break;
+            case 1: WGS_LAUNCH_G2P(0, false, true); break;
+            case 2: WGS_LAUNCH_G2P(0, true, false); break;
+            case 3: WGS_LAUNCH_G2P(0, true, true); break;
+            case 4: WGS_LAUNCH_G2P(1, false, false); break;
+            case 5: WGS_LAUNCH_G2P(1, false, true); break;
+            case 6: WGS_LAUNCH_G2P(1, true, false); break;
+            default: WGS_LAUNCH_G2P(1, true, true); break;
+        }
+#undef WGS_LAUNCH_G2P
+        mark(6);
+    } else {
+        mark(4);
+        mark(5);
+        mark(6);
+    }
+    HIP_TRY(hipGetLastError());
+    d->side ^= 1;
+    d->substeps++;
+    return WGS_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *wgs_last_error(void) { return g_last_error.c_str(); }
+int32_t wgs_dim(void) { return D; }
+
+wgs_status wgs_pipeline_create(int32_t hip_device, wgs_pipeline **out) {
+    if (!out) return fail(WGS_ERR_INVALID_ARGUMENT, "out is NULL");
+    *out = nullptr;
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count <= 0)
+        return fail(WGS_ERR_NO_DEVICE, std::string("no HIP device: ") + (e != hipSuccess ? hipGetErrorString(e) : "device count is 0"));
+    if (hip_device < 0 || hip_device >= count) return fail(WGS_ERR_INVALID_ARGUMENT, "hip_device out of range");
+    wgs_pipeline *p = new wgs_pipeline();
+    p->device = hip_device;
+    HIP_TRY(hipSetDevice(hip_device));
+    HIP_TRY(hipGetDeviceProperties(&p->props, hip_device));
+    p->num_cus = p->props.multiProcessorCount > 0 ? p->props.multiProcessorCount : 256;
+    *out = p;
+    return WGS_OK;
+}
+
+void wgs_pipeline_destroy(wgs_pipeline *pipeline) { delete pipeline; }
+
+wgs_status wgs_data_create(wgs_pipeline *pipeline, const wgs_sim_params *params, const wgs_particle *particles,
+                           size_t num_particles, const wgs_collider *colliders, size_t num_colliders, float cell_width,
+                           uint32_t grid_capacity, wgs_data **out) {
+    if (!pipeline || !params || !out) return fail(WGS_ERR_INVALID_ARGUMENT, "NULL argument");
+    if (num_particles && !particles) return fail(WGS_ERR_INVALID_ARGUMENT, "particles is NULL");
+    if (num_colliders && !colliders) return fail(WGS_ERR_INVALID_ARGUMENT, "colliders is NULL");
+    if (num_colliders > WGS_MAX_COLLIDERS)
+        return fail(WGS_ERR_UNSUPPORTED, "at most 16 coupled colliders (grid.wgsl:230-240)");
+    if (!(cell_width > 0.f)) return fail(WGS_ERR_INVALID_ARGUMENT, "cell_width must be > 0");
+    if (grid_capacity == 0 || grid_capacity > (1u << 25)) return fail(WGS_ERR_INVALID_ARGUMENT, "grid_capacity out of range");
+    if (num_particles >= 0xfffffff0ull) return fail(WGS_ERR_INVALID_ARGUMENT, "too many particles");
+    *out = nullptr;
+    HIP_TRY(hipSetDevice(pipeline->device));
+    wgs_data *d = new wgs_data();
+    d->pipeline = pipeline;
+    wgs_status st = WGS_OK;
+    auto bail = [&](wgs_status code) {
+        wgs_data_destroy(d);
+        return code;
+    };
+    if (hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking) != hipSuccess)
+        return bail(fail(WGS_ERR_HIP, "hipStreamCreate failed"));
+    Dev &dev = d->dev;
+    const uint32_t n = (uint32_t)num_particles;
+    dev.n = n;
+    dev.npad = ((n + 63u) / 64u) * 64u;
+    if (dev.npad == 0) dev.npad = 64;
+    dev.cap = next_pow2(grid_capacity);  // grid.rs:283
+    const uint32_t hcap = dev.cap * 2u;  // half-full table (reference: exactly cap slots, quirk B4)
+    dev.hmask = hcap - 1u;
+    dev.h = cell_width;
+    dev.inv_h = 1.0f / cell_width;
+    dev.model = WGS_MODEL_COROTATED;
+    dev.n_colliders = (uint32_t)num_colliders;
+    d->cpic = num_colliders > 0;
+
+#define TRY_ALLOC(...)                      \
+    do {                                    \
+        st = dev_alloc(d, __VA_ARGS__);     \
+        if (st != WGS_OK) return bail(st);  \
+    } while (0)
+    const size_t plane_floats = (size_t)P::COUNT * dev.npad;
+    TRY_ALLOC(&dev.buf[0], plane_floats);
+    TRY_ALLOC(&dev.buf[1], plane_floats);
+    TRY_ALLOC(&dev.perm, (size_t)dev.npad);
+    TRY_ALLOC(&dev.cellid, (size_t)dev.npad);
+    TRY_ALLOC(&dev.hkeys, (size_t)hcap);
+    TRY_ALLOC(&dev.hvals, (size_t)hcap);
+    TRY_ALLOC(&dev.block_key, (size_t)dev.cap);
+    TRY_ALLOC(&dev.block_count, (size_t)dev.cap);
+    TRY_ALLOC(&dev.block_start, (size_t)dev.cap);
+    TRY_ALLOC(&dev.nbr_plus, (size_t)dev.cap * 8);
+    TRY_ALLOC(&dev.nbr_minus, (size_t)dev.cap * 8);
+    TRY_ALLOC(&dev.cell_count, (size_t)dev.cap * NPB);
+    TRY_ALLOC(&dev.cell_start, (size_t)dev.cap * NPB);
+    TRY_ALLOC(&dev.cell_cursor, (size_t)dev.cap * NPB);
+    TRY_ALLOC(&dev.nodes, (size_t)dev.cap * NPB);
+    TRY_ALLOC(&dev.node_cdf, (size_t)dev.cap * NPB);
+    TRY_ALLOC(&dev.slab, (size_t)dev.cap * Dim<D>::TILE);
+    TRY_ALLOC(&dev.block_cdf_flag, (size_t)dev.cap);
+    TRY_ALLOC(&dev.counters, (size_t)CTR_COUNT);
+    TRY_ALLOC(&d->sp, (size_t)1);
+    TRY_ALLOC(&d->colliders, (size_t)WGS_MAX_COLLIDERS);
+    TRY_ALLOC(&d->static_radius, (size_t)dev.npad);
+    TRY_ALLOC(&d->static_dp, (size_t)dev.npad * 6);
+    TRY_ALLOC(&d->static_phase, (size_t)dev.npad * 2);
+    TRY_ALLOC(&d->static_flags, (size_t)dev.npad);
+#undef TRY_ALLOC
+    dev.sp = d->sp;
+    dev.colliders = d->colliders;
+
+    // AoS -> SoA staging (GpuParticles::from_particles + GpuModels::from_particles,
+    // particle3d.rs:192-210, models/mod.rs:20-49).
+    std::vector<float> soa(plane_floats, 0.f);
+    std::vector<float> s_radius(dev.npad, 0.f), s_dp((size_t)dev.npad * 6, 0.f), s_phase((size_t)dev.npad * 2, 0.f);
+    std::vector<uint32_t> s_flags(dev.npad, 0u);
+    const float deg = 3.14159265358979323846f / 180.0f;
+    const float default_dp[6] = {35.0f * deg, 9.0f * deg, 0.2f, 10.0f * deg, -1.0f, -1.0f};  // DruckerPrager::new(-1, -1)
+    bool plastic = false;
+    auto pl = [&](int p) { return soa.data() + (size_t)p * dev.npad; };
+    for (uint32_t i = 0; i < n; i++) {
+        const wgs_particle &q = particles[i];
+        for (int k = 0; k < D; k++) {
+            pl(P::POS + k)[i] = q.position[k];
+            pl(P::VEL + k)[i] = q.dynamics.velocity[k];
+            pl(P::NRM + k)[i] = q.dynamics.cdf.normal[k];
+            pl(P::RVEL + k)[i] = q.dynamics.cdf.rigid_vel[k];
+        }
+        for (int k = 0; k < DD; k++) {
+            pl(P::F + k)[i] = q.dynamics.def_grad[k];
+            pl(P::C + k)[i] = q.dynamics.affine[k];
+        }
+        pl(P::DIST)[i] = q.dynamics.cdf.signed_distance;
+        memcpy(&pl(P::AFF)[i], &q.dynamics.cdf.affinity, 4);
+        pl(P::MASS)[i] = q.dynamics.mass;
+        pl(P::VOL)[i] = q.dynamics.init_volume;
+        pl(P::LAM)[i] = q.model.lambda;
+        pl(P::MU)[i] = q.model.mu;
+        memcpy(&pl(P::PID)[i], &i, 4);
+        const float *dp = q.has_plasticity ? &q.plasticity.h0 : default_dp;
+        for (int k = 0; k < 6; k++) {
+            pl(P::DP + k)[i] = dp[k];
+            s_dp[(size_t)i * 6 + k] = dp[k];
+        }
+        pl(P::DPS + 0)[i] = 1.0f;  // DruckerPragerPlasticState::default(), drucker_prager.rs:44-53
+        pl(P::DPS + 1)[i] = 1.0f;
+        pl(P::DPS + 2)[i] = 0.0f;
+        const float phase = q.has_phase ? q.phase.phase : 0.0f;            // models/mod.rs:33-36
+        const float max_stretch = q.has_phase ? q.phase.max_stretch : -1.0f;
+        pl(P::PHASE)[i] = phase;
+        pl(P::PHASE + 1)[i] = max_stretch;
+        s_phase[(size_t)i * 2] = phase;
+        s_phase[(size_t)i * 2 + 1] = max_stretch;
+        s_radius[i] = q.dynamics.init_radius;
+        s_flags[i] = (q.has_plasticity ? 1u : 0u) | (q.has_phase ? 2u : 0u);
+        // Does the plasticity / fracture branch ever run for this particle?
+        // (particle_update.wgsl:98-122; max_stretch >= FLT_MAX can never be exceeded by a finite F)
+        if ((phase == 0.0f && dp[4] != 0.0f) || (phase > 0.0f && max_stretch > 0.0f && max_stretch < FLT_MAX)) plastic = true;
+    }
+    d->plastic = plastic;
+#define H2D(dst, src, bytes)                                                               \
+    if (hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, d->stream) != hipSuccess)   \
+        return bail(fail(WGS_ERR_HIP, "hipMemcpy H2D failed"));
+    H2D(dev.buf[0], soa.data(), plane_floats * sizeof(float));
+    H2D(d->static_radius, s_radius.data(), s_radius.size() * sizeof(float));
+    H2D(d->static_dp, s_dp.data(), s_dp.size() * sizeof(float));
+    H2D(d->static_phase, s_phase.data(), s_phase.size() * sizeof(float));
+    H2D(d->static_flags, s_flags.data(), s_flags.size() * sizeof(uint32_t));
+    d->host_sp = SimParamsDev{};
+    for (int k = 0; k < D; k++) d->host_sp.gravity[k] = params->gravity[k];
+    d->host_sp.dt = params->dt;
+    H2D(d->sp, &d->host_sp, sizeof(SimParamsDev));
+    d->host_colliders.resize(WGS_MAX_COLLIDERS);
+    memset(d->host_colliders.data(), 0, sizeof(ColliderDev) * WGS_MAX_COLLIDERS);
+    for (size_t i = 0; i < num_colliders; i++) fill_collider(d->host_colliders[i], colliders[i]);
+    H2D(d->colliders, d->host_colliders.data(), sizeof(ColliderDev) * WGS_MAX_COLLIDERS);
+#undef H2D
+    if (hipStreamSynchronize(d->stream) != hipSuccess) return bail(fail(WGS_ERR_HIP, "initial upload failed"));
+    *out = d;
+    return WGS_OK;
+}
+
+void wgs_data_destroy(wgs_data *d) {
+    if (!d) return;
+    if (d->stream) hipStreamSynchronize(d->stream);
+    if (d->events.created)
+        for (int s = 0; s < Events::MAX_SUBSTEPS; s++)
+            for (int m = 0; m < Events::MARKS; m++) hipEventDestroy(d->events.ev[s][m]);
+    for (void *p : d->allocs) hipFree(p);
+    if (d->stream) hipStreamDestroy(d->stream);
+    delete d;
+}
+
+wgs_status wgs_set_constitutive_model(wgs_data *d, int32_t model) {
+    if (!d) return fail(WGS_ERR_INVALID_ARGUMENT, "data is NULL");
+    if (model != WGS_MODEL_COROTATED && model != WGS_MODEL_NEO_HOOKEAN) return fail(WGS_ERR_INVALID_ARGUMENT, "unknown model");
+    d->dev.model = model;
+    return WGS_OK;
+}
+
+wgs_status wgs_step(wgs_pipeline *pipeline, wgs_data *d, uint32_t num_substeps, int32_t timestamps) {
+    if (!pipeline || !d) return fail(WGS_ERR_INVALID_ARGUMENT, "NULL argument");
+    HIP_TRY(hipSetDevice(pipeline->device));
+    if (timestamps) {
+        if (!d->events.created) {
+            for (int s = 0; s < Events::MAX_SUBSTEPS; s++)
+                for (int m = 0; m < Events::MARKS; m++) HIP_TRY(hipEventCreate(&d->events.ev[s][m]));
+            d->events.created = true;
+        }
+        d->events.used = 0;
+    }
+    for (uint32_t i = 0; i < num_substeps; i++) {
+        wgs_status st;
+        if (timestamps && d->events.used < Events::MAX_SUBSTEPS) {
+            st = enqueue_substep<true>(d, d->events.used);
+            d->events.used++;
+        } else {
+            st = enqueue_substep<false>(d, 0);
+        }
+        if (st != WGS_OK) return st;
+    }
+    if (timestamps) d->timings_pending = true;
+    return WGS_OK;
+}
+
+wgs_status wgs_sync(wgs_data *d) {
+    if (!d) return fail(WGS_ERR_INVALID_ARGUMENT, "data is NULL");
+    HIP_TRY(hipSetDevice(d->pipeline->device));
+    wgs_status st = fetch_counters(d);
+    if (st != WGS_OK) return st;
+    return sticky_status(d);
+}
+
+wgs_status wgs_set_sim_params(wgs_data *d, const wgs_sim_params *params) {
+    if (!d || !params) return fail(WGS_ERR_INVALID_ARGUMENT, "NULL argument");
+    for (int k = 0; k < D; k++) d->host_sp.gravity[k] = params->gravity[k];
+    d->host_sp.dt = params->dt;
+    // pageable memcpyAsync returns after staging, so host_sp may be reused at once
+    HIP_TRY(hipMemcpyAsync(d->sp, &d->host_sp, sizeof(SimParamsDev), hipMemcpyHostToDevice, d->stream));
+    return WGS_OK;
+}
+
+wgs_status wgs_set_collider_poses(wgs_data *d, const wgs_pose *poses, const float *coms, size_t n) {
+    if (!d || (!poses && n)) return fail(WGS_ERR_INVALID_ARGUMENT, "NULL argument");
+    if (n > d->dev.n_colliders) return fail(WGS_ERR_INVALID_ARGUMENT, "more poses than colliders");
+    for (size_t i = 0; i < n; i++) {
+        ColliderDev &c = d->host_colliders[i];
+        for (int k = 0; k < 4; k++) c.rot[k] = poses[i].rotation[k];
+        for (int k = 0; k < 3; k++) c.trans[k] = poses[i].translation[k];
+        c.scale = poses[i].scale;
+        if (coms) for (int k = 0; k < 3; k++) c.com[k] = coms[i * 3 + k];
+    }
+    HIP_TRY(hipMemcpyAsync(d->colliders, d->host_colliders.data(), sizeof(ColliderDev) * WGS_MAX_COLLIDERS, hipMemcpyHostToDevice, d->stream));
+    return WGS_OK;
+}
+
+wgs_status wgs_set_body_velocities(wgs_data *d, const wgs_velocity *vels, size_t n) {
+    if (!d || (!vels && n)) return fail(WGS_ERR_INVALID_ARGUMENT, "NULL argument");
+    if (n > d->dev.n_colliders) return fail(WGS_ERR_INVALID_ARGUMENT, "more velocities than colliders");
+    for (size_t i = 0; i < n; i++) {
+        ColliderDev &c = d->host_colliders[i];
+        for (int k = 0; k < 3; k++) c.linvel[k] = vels[i].linear[k];
+        for (int k = 0; k < 3; k++) c.angvel[k] = vels[i].angular[k];
+    }
+    HIP_TRY(hipMemcpyAsync(d->colliders, d->host_colliders.data(), sizeof(ColliderDev) * WGS_MAX_COLLIDERS, hipMemcpyHostToDevice, d->stream));
+    return WGS_OK;
+}
+
+wgs_status wgs_read_positions(wgs_data *d, float *out) {
+    if (!d || !out) return fail(WGS_ERR_INVALID_ARGUMENT, "NULL argument");
+    HIP_TRY(hipSetDevice(d->pipeline->device));
+    if (d->dev.n == 0) return WGS_OK;
+    float *tmp = nullptr;
+    const size_t bytes = sizeof(float) * D * (size_t)d->dev.n;
+    HIP_TRY(hipMalloc((void **)&tmp, bytes));
+    hipLaunchKernelGGL(k_export_positions, dim3(grid_for(d, 4)), dim3(256), 0, d->stream, d->dev, d->side, tmp);
+    hipError_t e = hipMemcpyAsync(out, tmp, bytes, hipMemcpyDeviceToHost, d->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(d->stream);
+    hipFree(tmp);
+    if (e != hipSuccess) return fail(WGS_ERR_HIP, hipGetErrorString(e));
+    return WGS_OK;
+}
+
+wgs_status wgs_read_particles(wgs_data *d, wgs_particle *out, wgs_plastic_state *plastic_out) {
+    if (!d || !out) return fail(WGS_ERR_INVALID_ARGUMENT, "NULL argument");
+    HIP_TRY(hipSetDevice(d->pipeline->device));
+    const uint32_t n = d->dev.n;
+    if (n == 0) return WGS_OK;
+    static_assert(sizeof(wgs_particle) % 4 == 0, "wgs_particle must be word-sized");
+    ParticleOffsets o;
+#define OFF(f) (uint32_t)(offsetof(wgs_particle, f) / 4)
+    o.stride = sizeof(wgs_particle) / 4;
+    o.pos = OFF(position); o.vel = OFF(dynamics.velocity); o.F = OFF(dynamics.def_grad); o.C = OFF(dynamics.affine);
+    o.nrm = OFF(dynamics.cdf.normal); o.rvel = OFF(dynamics.cdf.rigid_vel); o.dist = OFF(dynamics.cdf.signed_distance);
+    o.aff = OFF(dynamics.cdf.affinity); o.vol = OFF(dynamics.init_volume); o.rad = OFF(dynamics.init_radius);
+    o.mass = OFF(dynamics.mass); o.lam = OFF(model.lambda); o.mu = OFF(model.mu); o.has_pl = OFF(has_plasticity);
+    o.dp = OFF(plasticity); o.has_ph = OFF(has_phase); o.phase = OFF(phase);
+#undef OFF
+    float *tmp = nullptr, *ptmp = nullptr;
+    const size_t bytes = sizeof(wgs_particle) * (size_t)n;
+    HIP_TRY(hipMalloc((void **)&tmp, bytes));
+    if (plastic_out) {
+        hipError_t e = hipMalloc((void **)&ptmp, sizeof(float) * 3 * (size_t)n);
+        if (e != hipSuccess) { hipFree(tmp); return fail(WGS_ERR_HIP, hipGetErrorString(e)); }
+    }
+    // After a step with zero colliders every particle cdf is default_cdf()
+    // (g2p_cdf.wgsl:246-249 runs unconditionally); before any step the input is echoed.
+    const bool cdf_live = d->cpic || d->substeps == 0;
+    hipLaunchKernelGGL(k_export_particles, dim3(grid_for(d, 4)), dim3(256), 0, d->stream, d->dev, d->side, o, d->plastic,
+                       cdf_live, d->static_radius, d->static_dp, d->static_phase, d->static_flags, tmp, ptmp);
+    hipError_t e = hipMemcpyAsync(out, tmp, bytes, hipMemcpyDeviceToHost, d->stream);
+    if (e == hipSuccess && plastic_out)
+        e = hipMemcpyAsync(plastic_out, ptmp, sizeof(float) * 3 * (size_t)n, hipMemcpyDeviceToHost, d->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(d->stream);
+    hipFree(tmp);
+    if (ptmp) hipFree(ptmp);
+    if (e != hipSuccess) return fail(WGS_ERR_HIP, hipGetErrorString(e));
+    return WGS_OK;
+}
+
+wgs_status wgs_read_grid(wgs_data *d, wgs_node_record *out, size_t capacity, size_t *count) {
+    if (!d || !count) return fail(WGS_ERR_INVALID_ARGUMENT, "NULL argument");
+    HIP_TRY(hipSetDevice(d->pipeline->device));
+    wgs_status st = fetch_counters(d);
+    if (st != WGS_OK) return st;
+    const size_t total = (size_t)d->last_nblocks * NPB;
+    *count = total;
+    if (!out || total == 0) return WGS_OK;
+    if (capacity < total) return fail(WGS_ERR_INVALID_ARGUMENT, "capacity too small; *count holds the required size");
+    wgs_node_record *tmp = nullptr;
+    HIP_TRY(hipMalloc((void **)&tmp, sizeof(wgs_node_record) * total));
+    hipLaunchKernelGGL(k_export_grid, dim3(grid_for(d, 4)), dim3(256), 0, d->stream, d->dev, d->last_nblocks, d->cpic, tmp);
+    hipError_t e = hipMemcpyAsync(out, tmp, sizeof(wgs_node_record) * total, hipMemcpyDeviceToHost, d->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(d->stream);
+    hipFree(tmp);
+    if (e != hipSuccess) return fail(WGS_ERR_HIP, hipGetErrorString(e));
+    return WGS_OK;
+}
+
+wgs_status wgs_read_blocks(wgs_data *d, wgs_block_record *out, size_t capacity, size_t *count, uint32_t *sorted_ids) {
+    if (!d || !count) return fail(WGS_ERR_INVALID_ARGUMENT, "NULL argument");
+    HIP_TRY(hipSetDevice(d->pipeline->device));
+    wgs_status st = fetch_counters(d);
+    if (st != WGS_OK) return st;
+    const size_t total = d->last_nblocks;
+    *count = total;
+    if (out && total) {
+        if (capacity < total) return fail(WGS_ERR_INVALID_ARGUMENT, "capacity too small; *count holds the required size");
+        wgs_block_record *tmp = nullptr;
+        HIP_TRY(hipMalloc((void **)&tmp, sizeof(wgs_block_record) * total));
+        hipLaunchKernelGGL(k_export_blocks, dim3(grid_for(d, 1)), dim3(256), 0, d->stream, d->dev, d->last_nblocks, tmp);
+        hipError_t e = hipMemcpyAsync(out, tmp, sizeof(wgs_block_record) * total, hipMemcpyDeviceToHost, d->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(d->stream);
+        hipFree(tmp);
+        if (e != hipSuccess) return fail(WGS_ERR_HIP, hipGetErrorString(e));
+    }
+    if (sorted_ids && d->dev.n) {
+        // The buffer written by the last substep is in sorted order: its pid plane IS sorted_ids.
+        const float *pidp = d->dev.buf[d->side] + (size_t)P::PID * d->dev.npad;
+        HIP_TRY(hipMemcpyAsync(sorted_ids, pidp, sizeof(uint32_t) * (size_t)d->dev.n, hipMemcpyDeviceToHost, d->stream));
+        HIP_TRY(hipStreamSynchronize(d->stream));
+    }
+    return WGS_OK;
+}
+
+wgs_status wgs_read_timings(wgs_data *d, float ms[WGS_NUM_PASSES]) {
+    if (!d || !ms) return fail(WGS_ERR_INVALID_ARGUMENT, "NULL argument");
+    resolve_timings(d);
+    for (int p = 0; p < WGS_NUM_PASSES; p++) ms[p] = d->timings[p];
+    return WGS_OK;
+}
+
+wgs_status wgs_get_stats(wgs_data *d, wgs_stats *out) {
+    if (!d || !out) return fail(WGS_ERR_INVALID_ARGUMENT, "NULL argument");
+    HIP_TRY(hipSetDevice(d->pipeline->device));
+    wgs_status st = fetch_counters(d);
+    if (st != WGS_OK) return st;
+    out->num_particles = d->dev.n;
+    out->num_active_blocks = d->last_nblocks;
+    out->grid_capacity = d->dev.cap;
+    out->overflow = d->sticky_errors;
+    out->substeps_done = d->substeps;
+    out->device_bytes = d->device_bytes;
+    return WGS_OK;
+}
+
+}  // extern "C"

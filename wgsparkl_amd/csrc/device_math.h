@@ -1,0 +1,419 @@
+// device_math.h — index math, B-spline weights, 2x2/3x3 linear algebra and the
+// constitutive models as gfx950 device functions. Citations are relative to
+// /root/reference/src/.
+#pragma once
+#include "layout.h"
+
+namespace wgs {
+
+// ---------------------------------------------------------------- index math
+// grid/grid.wgsl:82-95 pack_key. Bit-exact.
+template <int D> __host__ __device__ inline uint32_t pack_key(const int *b) {
+    if constexpr (D == 2) {
+        return ((uint32_t)(b[0] + 0x00007fff) & 0x0000ffffu) | (((uint32_t)(b[1] + 0x00007fff) & 0x0000ffffu) << 16);
+    } else {
+        return ((uint32_t)(b[0] + 0x000003ff) & 0x000007ffu) | (((uint32_t)(b[1] + 0x000001ff) & 0x000003ffu) << 11) |
+               (((uint32_t)(b[2] + 0x000003ff) & 0x000007ffu) << 21);
+    }
+}
+
+// Inverse of pack_key for blocks inside the representable range.
+template <int D> __host__ __device__ inline void unpack_key(uint32_t key, int *b) {
+    if constexpr (D == 2) {
+        b[0] = (int)(key & 0xffffu) - 0x7fff;
+        b[1] = (int)(key >> 16) - 0x7fff;
+    } else {
+        b[0] = (int)(key & 0x7ffu) - 0x3ff;
+        b[1] = (int)((key >> 11) & 0x3ffu) - 0x1ff;
+        b[2] = (int)(key >> 21) - 0x3ff;
+    }
+}
+
+template <int D> __host__ __device__ inline bool block_in_key_range(const int *b) {
+    if constexpr (D == 2) {
+        return b[0] >= -0x7fff && b[0] <= 0x8000 && b[1] >= -0x7fff && b[1] <= 0x8000 && !(b[0] == 0x8000 && b[1] == 0x8000);
+    } else {
+        bool in = b[0] >= -0x3ff && b[0] <= 0x400 && b[1] >= -0x1ff && b[1] <= 0x200 && b[2] >= -0x3ff && b[2] <= 0x400;
+        return in && !(b[0] == 0x400 && b[1] == 0x200 && b[2] == 0x400);  // that corner packs to NONE (quirk B5)
+    }
+}
+
+// grid/grid.wgsl:98-105 murmur3 scramble. Bit-exact.
+__host__ __device__ inline uint32_t hash_key(uint32_t key) {
+    key *= 0xcc9e2d51u;
+    key = (key << 15) | (key >> 17);
+    key *= 0x1b873593u;
+    return key;
+}
+
+// solver/particle3d.wgsl:41-49, grid/grid.wgsl:284-292: assoc_cell = round(x / h) - 1 with WGSL
+// round() = ties-to-even and a true fp32 division. v_rndne_f32 + IEEE division (no fast-math).
+__device__ inline int assoc_cell(float x, float h) { return (int)(__builtin_rintf(x / h) - 1.0f); }
+
+// grid/grid.wgsl:167-184 find_block_header_id
+__device__ inline uint32_t hmap_find(const Dev &d, uint32_t key) {
+    uint32_t slot = hash_key(key) & d.hmask;
+    for (uint32_t probe = 0; probe <= d.hmask; ++probe) {
+        uint32_t st = d.hkeys[slot];
+        if (st == key) return d.hvals[slot];
+        if (st == NONE) return NONE;
+        slot = (slot + 1u) & d.hmask;
+    }
+    return NONE;
+}
+
+// grid/grid.wgsl:121-164 insertion_index + :323-334 mark_block_as_active.
+__device__ inline void activate_block(const Dev &d, uint32_t key) {
+    uint32_t slot = hash_key(key) & d.hmask;
+    for (uint32_t probe = 0; probe <= d.hmask; ++probe) {
+        uint32_t cur = __hip_atomic_load(&d.hkeys[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (cur == key) return;
+        if (cur == NONE) {
+            uint32_t old = atomicCAS(&d.hkeys[slot], NONE, key);
+            if (old == NONE) {
+                uint32_t id = atomicAdd(&d.counters[CTR_NBLOCKS], 1u);
+                if (id < d.cap) {
+                    d.hvals[slot] = id;
+                    d.block_key[id] = key;
+                } else {
+                    atomicOr(&d.counters[CTR_ERRORS], ERRBIT_OVERFLOW);
+                }
+                return;
+            }
+            if (old == key) return;
+        }
+        slot = (slot + 1u) & d.hmask;
+    }
+    atomicOr(&d.counters[CTR_ERRORS], ERRBIT_OVERFLOW);
+}
+
+// ------------------------------------------------------- quadratic B-spline
+// grid/kernel.wgsl:60-66 eval_all
+__device__ inline void eval_all(float x, float *w) {
+    w[0] = 0.5f * (1.5f - x) * (1.5f - x);
+    w[1] = 0.75f - (x - 1.0f) * (x - 1.0f);
+    w[2] = 0.5f * (x - 0.5f) * (x - 0.5f);
+}
+
+// ------------------------------------------------------------ small matrices
+// Column-major like WGSL / nalgebra: element (r, c) at [c * D + r].
+template <int D> __device__ inline void mat_mul(const float *a, const float *b, float *out) {
+#pragma unroll
+    for (int c = 0; c < D; c++)
+#pragma unroll
+        for (int r = 0; r < D; r++) {
+            float s = 0.f;
+#pragma unroll
+            for (int k = 0; k < D; k++) s += a[k * D + r] * b[c * D + k];
+            out[c * D + r] = s;
+        }
+}
+
+// out = a * b^T
+template <int D> __device__ inline void mat_mul_bt(const float *a, const float *b, float *out) {
+#pragma unroll
+    for (int c = 0; c < D; c++)
+#pragma unroll
+        for (int r = 0; r < D; r++) {
+            float s = 0.f;
+#pragma unroll
+            for (int k = 0; k < D; k++) s += a[k * D + r] * b[k * D + c];
+            out[c * D + r] = s;
+        }
+}
+
+template <int D> __device__ inline float mat_det(const float *m) {
+    if constexpr (D == 2) {
+        return m[0] * m[3] - m[2] * m[1];
+    } else {
+        return m[0] * (m[4] * m[8] - m[7] * m[5]) - m[3] * (m[1] * m[8] - m[7] * m[2]) + m[6] * (m[1] * m[5] - m[4] * m[2]);
+    }
+}
+
+// One-sided (Hestenes) Jacobi SVD, fp32: F = U diag(S) V^T, written for registers
+// (fully unrolled, no indexing by run-time values). Replaces wgebra::svd2/svd3
+// (third party, not on disk; call sites linear_elasticity.wgsl:15,29,
+// drucker_prager.wgsl:80,139, particle_update.wgsl:103,109).
+// Convention: U, V proper rotations; for det F < 0 the sign sits on the singular
+// value of smallest magnitude (every consumer is invariant to ordering).
+template <int D> struct Svd {
+    float u[D * D], s[D], v[D * D];  // v = V (not transposed), column-major
+};
+
+template <int D> __device__ inline void jacobi_rotate(float *a, float *v, int p, int q) {
+    float alpha = 0.f, beta = 0.f, gamma = 0.f;
+#pragma unroll
+    for (int r = 0; r < D; r++) {
+        alpha += a[p * D + r] * a[p * D + r];
+        beta += a[q * D + r] * a[q * D + r];
+        gamma += a[p * D + r] * a[q * D + r];
+    }
+    // rotation angle zeroing the (p,q) inner product; t = 0 when already orthogonal
+    float zeta = (beta - alpha) / (2.0f * gamma);
+    float t = copysignf(1.0f, zeta) / (fabsf(zeta) + sqrtf(1.0f + zeta * zeta));
+    bool skip = !(fabsf(gamma) > 1.0e-30f) || !(gamma * gamma > 1.0e-15f * alpha * beta) || !(t == t);
+    t = skip ? 0.0f : t;
+    float c = 1.0f / sqrtf(1.0f + t * t);
+    float s = c * t;
+#pragma unroll
+    for (int r = 0; r < D; r++) {
+        float ap = a[p * D + r], aq = a[q * D + r];
+        a[p * D + r] = c * ap - s * aq;
+        a[q * D + r] = s * ap + c * aq;
+        float vp = v[p * D + r], vq = v[q * D + r];
+        v[p * D + r] = c * vp - s * vq;
+        v[q * D + r] = s * vp + c * vq;
+    }
+}
+
+template <int D> __device__ inline void svd(const float *F, Svd<D> &out) {
+    float a[D * D];
+#pragma unroll
+    for (int i = 0; i < D * D; i++) {
+        a[i] = F[i];
+        out.v[i] = 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < D; i++) out.v[i * D + i] = 1.f;
+    if constexpr (D == 2) {
+        jacobi_rotate<2>(a, out.v, 0, 1);  // one rotation is exact in 2D
+        jacobi_rotate<2>(a, out.v, 0, 1);  // second pass mops up fp32 residue
+    } else {
+        // Cyclic sweeps; fp32 converges quadratically, 4-5 sweeps reach round-off for
+        // any conditioning met in practice. Fixed trip count keeps the wave converged.
+        for (int sweep = 0; sweep < 5; sweep++) {
+            jacobi_rotate<3>(a, out.v, 0, 1);
+            jacobi_rotate<3>(a, out.v, 0, 2);
+            jacobi_rotate<3>(a, out.v, 1, 2);
+        }
+    }
+    float smax = 0.f;
+#pragma unroll
+    for (int c = 0; c < D; c++) {
+        float n2 = 0.f;
+#pragma unroll
+        for (int r = 0; r < D; r++) n2 += a[c * D + r] * a[c * D + r];
+        out.s[c] = sqrtf(n2);
+        smax = fmaxf(smax, out.s[c]);
+    }
+    bool ok[D];
+#pragma unroll
+    for (int c = 0; c < D; c++) {
+        ok[c] = out.s[c] > 1.0e-30f && out.s[c] > 1.0e-7f * smax;
+        float inv = ok[c] ? 1.0f / out.s[c] : 0.f;
+#pragma unroll
+        for (int r = 0; r < D; r++) out.u[c * D + r] = a[c * D + r] * inv;
+        if (!ok[c]) out.s[c] = 0.f;
+    }
+    // Rebuild columns of U that belong to vanishing singular values.
+    if constexpr (D == 2) {
+        if (!ok[0] && !ok[1]) {
+            out.u[0] = 1.f; out.u[1] = 0.f; out.u[2] = 0.f; out.u[3] = 1.f;
+        } else if (!ok[0]) {
+            out.u[0] = out.u[3]; out.u[1] = -out.u[2];
+        } else if (!ok[1]) {
+            out.u[2] = -out.u[1]; out.u[3] = out.u[0];
+        }
+    } else {
+        int nbad = (!ok[0]) + (!ok[1]) + (!ok[2]);
+        if (nbad == 3) {
+#pragma unroll
+            for (int i = 0; i < 9; i++) out.u[i] = (i % 4 == 0) ? 1.f : 0.f;
+        } else if (nbad == 2) {
+            float e[3];
+#pragma unroll
+            for (int r = 0; r < 3; r++) e[r] = ok[0] ? out.u[r] : (ok[1] ? out.u[3 + r] : out.u[6 + r]);
+            // axis least aligned with e
+            float t[3] = {0.f, 0.f, 0.f};
+            float a0 = fabsf(e[0]), a1 = fabsf(e[1]), a2 = fabsf(e[2]);
+            if (a0 <= a1 && a0 <= a2) t[0] = 1.f; else if (a1 <= a2) t[1] = 1.f; else t[2] = 1.f;
+            float dt = e[0] * t[0] + e[1] * t[1] + e[2] * t[2];
+            float b1[3] = {t[0] - dt * e[0], t[1] - dt * e[1], t[2] - dt * e[2]};
+            float n1 = 1.0f / sqrtf(b1[0] * b1[0] + b1[1] * b1[1] + b1[2] * b1[2]);
+            b1[0] *= n1; b1[1] *= n1; b1[2] *= n1;
+            float b2[3] = {e[1] * b1[2] - e[2] * b1[1], e[2] * b1[0] - e[0] * b1[2], e[0] * b1[1] - e[1] * b1[0]};
+            // columns (g+1)%3 and (g+2)%3 receive b1, b2 (g = the good column)
+#pragma unroll
+            for (int r = 0; r < 3; r++) {
+                if (ok[0]) { out.u[3 + r] = b1[r]; out.u[6 + r] = b2[r]; }
+                else if (ok[1]) { out.u[6 + r] = b1[r]; out.u[r] = b2[r]; }
+                else { out.u[r] = b1[r]; out.u[3 + r] = b2[r]; }
+            }
+        } else if (nbad == 1) {
+            // missing column = cross product of the next two (cyclic)
+            float x[3], y[3];
+#pragma unroll
+            for (int r = 0; r < 3; r++) {
+                x[r] = !ok[0] ? out.u[3 + r] : (!ok[1] ? out.u[6 + r] : out.u[r]);
+                y[r] = !ok[0] ? out.u[6 + r] : (!ok[1] ? out.u[r] : out.u[3 + r]);
+            }
+            float z[3] = {x[1] * y[2] - x[2] * y[1], x[2] * y[0] - x[0] * y[2], x[0] * y[1] - x[1] * y[0]};
+#pragma unroll
+            for (int r = 0; r < 3; r++) {
+                if (!ok[0]) out.u[r] = z[r]; else if (!ok[1]) out.u[3 + r] = z[r]; else out.u[6 + r] = z[r];
+            }
+        }
+    }
+    // Proper rotations: flip the column of the smallest singular value.
+    int kmin = 0;
+#pragma unroll
+    for (int c = 1; c < D; c++) kmin = out.s[c] < out.s[kmin] ? c : kmin;
+    bool flip_v = mat_det<D>(out.v) < 0.f;
+    bool flip_u = mat_det<D>(out.u) < 0.f;
+#pragma unroll
+    for (int c = 0; c < D; c++) {
+        bool m = c == kmin;
+        float sv = (m && flip_v) ? -1.f : 1.f, su = (m && flip_u) ? -1.f : 1.f;
+#pragma unroll
+        for (int r = 0; r < D; r++) {
+            out.v[c * D + r] *= sv;
+            out.u[c * D + r] *= su;
+        }
+        out.s[c] *= sv * su;
+    }
+}
+
+// U * diag(s) * V^T
+template <int D> __device__ inline void svd_recompose(const Svd<D> &d, const float *s, float *out) {
+    float us[D * D];
+#pragma unroll
+    for (int c = 0; c < D; c++)
+#pragma unroll
+        for (int r = 0; r < D; r++) us[c * D + r] = d.u[c * D + r] * s[c];
+    mat_mul_bt<D>(us, d.v, out);
+}
+
+// --------------------------------------------------------------- models
+// models/neo_hookean_elasticity.wgsl:12-25
+template <int D> __device__ inline void kirchoff_neo_hookean(float lambda, float mu, const float *F, float *tau) {
+    float j = fmaxf(mat_det<D>(F), 1.0e-10f);
+    float diag = lambda * logf(j) - mu;
+    float fft[D * D];
+    mat_mul_bt<D>(F, F, fft);
+#pragma unroll
+    for (int i = 0; i < D * D; i++) tau[i] = mu * fft[i];
+#pragma unroll
+    for (int k = 0; k < D; k++) tau[k * D + k] += diag;
+}
+
+// models/linear_elasticity.wgsl:14-41 (corotated), given the SVD of F.
+template <int D> __device__ inline void kirchoff_corotated(float lambda, float mu, const float *F, const Svd<D> &d, float *tau) {
+    float j = d.s[0];
+#pragma unroll
+    for (int k = 1; k < D; k++) j = j * d.s[k];
+    float sm1[D];
+#pragma unroll
+    for (int k = 0; k < D; k++) sm1[k] = d.s[k] - 1.0f;
+    float diag = lambda * (j - 1.0f) * j;
+    float rec[D * D], prod[D * D];
+    svd_recompose<D>(d, sm1, rec);  // F - R
+    mat_mul_bt<D>(rec, F, prod);
+#pragma unroll
+    for (int i = 0; i < D * D; i++) tau[i] = prod[i] * (2.0f * mu);
+#pragma unroll
+    for (int k = 0; k < D; k++) tau[k * D + k] += diag;
+}
+
+// models/drucker_prager.wgsl:25-29
+__device__ inline float dp_alpha(const float *dp, float q) {
+    float angle = dp[0] + (dp[1] * q - dp[3]) * expf(-dp[2] * q);
+    float s_angle = sinf(angle);
+    return sqrtf(2.0f / 3.0f) * (2.0f * s_angle) / (3.0f - s_angle);
+}
+
+// models/drucker_prager.wgsl:42-101 (2D) / :112-158 (3D). Updates `d.s`, `state`
+// and F in place when the projection is valid; returns whether it changed anything.
+template <int D> __device__ inline bool drucker_prager_project(const float *dp, float *state, float *F, Svd<D> &d) {
+    const float dd = (float)D;
+    float alpha = dp_alpha(dp, state[1]);
+    float strain[D], dev[D], nsv[D];
+    float trace = 0.f;
+#pragma unroll
+    for (int k = 0; k < D; k++) {
+        strain[k] = logf(d.s[k]) + state[2] / dd;
+        trace += strain[k];
+    }
+    bool all_zero = true;
+#pragma unroll
+    for (int k = 0; k < D; k++) {
+        dev[k] = strain[k] - trace / dd;
+        all_zero = all_zero && (dev[k] == 0.f);
+    }
+    float hardening;
+    if (trace > 0.f || all_zero) {
+        float n2 = 0.f;
+#pragma unroll
+        for (int k = 0; k < D; k++) {
+            nsv[k] = 1.f;
+            n2 += strain[k] * strain[k];
+        }
+        hardening = sqrtf(n2);
+    } else {
+        float n2 = 0.f;
+#pragma unroll
+        for (int k = 0; k < D; k++) n2 += dev[k] * dev[k];
+        float dev_norm = sqrtf(n2);
+        float gamma = dev_norm + (dd * dp[4] + 2.0f * dp[5]) / (2.0f * dp[5]) * trace * alpha;
+        if (gamma <= 0.f) return false;
+#pragma unroll
+        for (int k = 0; k < D; k++) nsv[k] = expf(strain[k] - dev[k] * (gamma / dev_norm));
+        hardening = gamma;
+    }
+    float prev_det = d.s[0], new_det = nsv[0];
+#pragma unroll
+    for (int k = 1; k < D; k++) {
+        prev_det = prev_det * d.s[k];
+        new_det = new_det * nsv[k];
+    }
+    state[0] = state[0] * prev_det / new_det;
+    state[2] = state[2] + logf(prev_det) - logf(new_det);
+    state[1] = state[1] + hardening;
+#pragma unroll
+    for (int k = 0; k < D; k++) d.s[k] = nsv[k];
+    svd_recompose<D>(d, d.s, F);
+    return true;
+}
+
+// grid/grid.wgsl:390-404 project_velocity (friction 20)
+template <int D> __device__ inline void project_velocity(const float *vel, const float *n, float *out) {
+    float nv = 0.f;
+#pragma unroll
+    for (int k = 0; k < D; k++) nv += vel[k] * n[k];
+    if (nv < 0.f) {
+        float t[D], l2 = 0.f;
+#pragma unroll
+        for (int k = 0; k < D; k++) {
+            t[k] = vel[k] - n[k] * nv;
+            l2 += t[k] * t[k];
+        }
+        float len = sqrtf(l2);
+        float scale = fmaxf(0.f, len + 20.0f * nv);
+#pragma unroll
+        for (int k = 0; k < D; k++) out[k] = (len > 1.0e-8f ? t[k] / len : 0.f) * scale;
+    } else {
+#pragma unroll
+        for (int k = 0; k < D; k++) out[k] = vel[k];
+    }
+}
+
+// grid/grid.wgsl:250-255
+__device__ inline bool affinities_are_compatible(uint32_t a1, uint32_t a2) {
+    uint32_t common = a1 & a2 & 0x0000ffffu;
+    return ((a1 >> 16) & common) == ((a2 >> 16) & common);
+}
+
+// wgrapier Body::velocity_at_point (call sites p2g.wgsl:208, g2p.wgsl:191,224)
+template <int D> __device__ inline void velocity_at_point(const ColliderDev &c, const float *pt, float *out) {
+    if constexpr (D == 2) {
+        float dx = pt[0] - c.com[0], dy = pt[1] - c.com[1];
+        out[0] = c.linvel[0] - c.angvel[0] * dy;
+        out[1] = c.linvel[1] + c.angvel[0] * dx;
+    } else {
+        float dx = pt[0] - c.com[0], dy = pt[1] - c.com[1], dz = pt[2] - c.com[2];
+        out[0] = c.linvel[0] + (c.angvel[1] * dz - c.angvel[2] * dy);
+        out[1] = c.linvel[1] + (c.angvel[2] * dx - c.angvel[0] * dz);
+        out[2] = c.linvel[2] + (c.angvel[0] * dy - c.angvel[1] * dx);
+    }
+}
+
+}  // namespace wgs

@@ -1,0 +1,340 @@
+// kernels_cdf.h — CPIC colour-distance-field passes for analytic colliders.
+//   k_node_cdf     = solver/grid_update_cdf.wgsl:16-39 + collision/collide.wgsl:23-56
+//   k_particle_cdf = solver/g2p_cdf.wgsl:39-250
+// The shape projections / pose maths are third party in the reference (wgparry
+// Shape::projectPointOnBoundary, wgebra Sim2/Sim3 — not on disk); they are
+// restated from parry's published algorithms, identically to the oracle.
+#pragma once
+#include "device_math.h"
+
+namespace wgs {
+
+template <int D> __device__ inline void quat_rotate(const float *q, const float *v, float *out) {
+    float ux = q[0], uy = q[1], uz = q[2], w = q[3];
+    float tx = 2.0f * (uy * v[2] - uz * v[1]);
+    float ty = 2.0f * (uz * v[0] - ux * v[2]);
+    float tz = 2.0f * (ux * v[1] - uy * v[0]);
+    out[0] = v[0] + w * tx + (uy * tz - uz * ty);
+    out[1] = v[1] + w * ty + (uz * tx - ux * tz);
+    out[2] = v[2] + w * tz + (ux * ty - uy * tx);
+}
+
+template <int D> __device__ inline void pose_to_local(const ColliderDev &c, const float *pw, float *pl) {
+    float dlt[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < D; k++) dlt[k] = pw[k] - c.trans[k];
+    if constexpr (D == 2) {
+        float cs = c.rot[0], sn = c.rot[1];
+        pl[0] = (cs * dlt[0] + sn * dlt[1]) / c.scale;
+        pl[1] = (-sn * dlt[0] + cs * dlt[1]) / c.scale;
+    } else {
+        float qi[4] = {-c.rot[0], -c.rot[1], -c.rot[2], c.rot[3]};
+        float t[3];
+        quat_rotate<3>(qi, dlt, t);
+#pragma unroll
+        for (int k = 0; k < 3; k++) pl[k] = t[k] / c.scale;
+    }
+}
+
+template <int D> __device__ inline void pose_to_world(const ColliderDev &c, const float *pl, float *pw) {
+    float s[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < D; k++) s[k] = pl[k] * c.scale;
+    if constexpr (D == 2) {
+        float cs = c.rot[0], sn = c.rot[1];
+        pw[0] = cs * s[0] - sn * s[1] + c.trans[0];
+        pw[1] = sn * s[0] + cs * s[1] + c.trans[1];
+    } else {
+        float t[3];
+        quat_rotate<3>(c.rot, s, t);
+#pragma unroll
+        for (int k = 0; k < 3; k++) pw[k] = t[k] + c.trans[k];
+    }
+}
+
+// Local-space projection on the shape BOUNDARY; returns is_inside.
+template <int D> __device__ inline bool project_local_on_boundary(const ColliderDev &c, const float *pt, float *proj) {
+    if (c.shape_type == 0u) {  // ball
+        float r = c.shape[0], n2 = 0.f;
+#pragma unroll
+        for (int k = 0; k < D; k++) n2 += pt[k] * pt[k];
+        float n = sqrtf(n2);
+        if (n == 0.f) {
+#pragma unroll
+            for (int k = 0; k < D; k++) proj[k] = 0.f;
+            proj[1] = r;
+        } else {
+#pragma unroll
+            for (int k = 0; k < D; k++) proj[k] = pt[k] * (r / n);
+        }
+        return n2 <= r * r;
+    }
+    if (c.shape_type == 2u) {  // capsule along local y
+        float hh = c.shape[0], r = c.shape[1];
+        float seg[3] = {0.f, fmaxf(-hh, fminf(hh, pt[1])), 0.f};
+        float dl[D], n2 = 0.f;
+#pragma unroll
+        for (int k = 0; k < D; k++) {
+            dl[k] = pt[k] - seg[k];
+            n2 += dl[k] * dl[k];
+        }
+        float n = sqrtf(n2);
+        if (n == 0.f) {
+#pragma unroll
+            for (int k = 0; k < D; k++) proj[k] = seg[k];
+            proj[0] += r;
+        } else {
+#pragma unroll
+            for (int k = 0; k < D; k++) proj[k] = seg[k] + dl[k] * (r / n);
+        }
+        return n2 <= r * r;
+    }
+    // cuboid: parry Aabb::do_project_local_point(solid = false)
+    float mins_pt[D], pt_maxs[D], shift[D];
+    bool inside = true;
+#pragma unroll
+    for (int k = 0; k < D; k++) {
+        float he = c.shape[k];
+        mins_pt[k] = -he - pt[k];
+        pt_maxs[k] = pt[k] - he;
+        shift[k] = fmaxf(mins_pt[k], 0.f) - fmaxf(pt_maxs[k], 0.f);
+        inside = inside && shift[k] == 0.f;
+    }
+    if (!inside) {
+#pragma unroll
+        for (int k = 0; k < D; k++) proj[k] = pt[k] + shift[k];
+        return false;
+    }
+    float best = -3.402823466e+38f;
+    bool is_mins = false;
+    int best_id = 0;
+#pragma unroll
+    for (int k = 0; k < D; k++) {
+        if (mins_pt[k] < pt_maxs[k]) {
+            if (pt_maxs[k] > best) { best_id = k; is_mins = false; best = pt_maxs[k]; }
+        } else if (mins_pt[k] > best) {
+            best_id = k; is_mins = true; best = mins_pt[k];
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < D; k++) proj[k] = pt[k] + (k == best_id ? (is_mins ? best : -best) : 0.f);
+    return true;
+}
+
+template <int D> __global__ __launch_bounds__(256) void k_node_cdf(Dev d) {
+    constexpr int BW = Dim<D>::BW, BS = Dim<D>::BSHIFT;
+    const uint32_t B = min(d.counters[CTR_NBLOCKS], d.cap);
+    const uint32_t total = B * NPB;
+    const float cap = d.h * 1.5f;
+    for (uint32_t t = blockIdx.x * 256 + threadIdx.x; t < total; t += gridDim.x * 256) {
+        const uint32_t b = t >> 6, ln = t & 63u;
+        int bc[3] = {0, 0, 0};
+        unpack_key<D>(d.block_key[b], bc);
+        int l[3] = {(int)(ln & (BW - 1)), (int)((ln >> BS) & (BW - 1)), D == 3 ? (int)(ln >> (2 * BS)) : 0};
+        float pt[D];
+#pragma unroll
+        for (int k = 0; k < D; k++) pt[k] = (float)(bc[k] * BW + l[k]) * d.h;
+        NodeCdf cdf = {1.0e10f, 0u, NONE, 0u};
+        for (uint32_t i = 0; i < d.n_colliders && i < 16u; i++) {
+            const ColliderDev &c = d.colliders[i];
+            float pl[D], projl[D], proj[D];
+            pose_to_local<D>(c, pt, pl);
+            bool inside = project_local_on_boundary<D>(c, pl, projl);
+            pose_to_world<D>(c, projl, proj);
+            float n2 = 0.f;
+            bool within = true;
+#pragma unroll
+            for (int k = 0; k < D; k++) {
+                float dl = proj[k] - pt[k];
+                n2 += dl * dl;
+                within = within && (fabsf(dl) <= cap);
+            }
+            if (inside || within) {
+                float dist = sqrtf(n2);
+                if (dist < cdf.distance) cdf.closest_id = i;
+                cdf.distance = fminf(cdf.distance, dist);
+                cdf.affinities |= (inside ? 0x00010001u : 0x00000001u) << i;
+            }
+        }
+        d.node_cdf[t] = cdf;
+        if (cdf.affinities != 0u) d.block_cdf_flag[b] = 1u;  // benign race: every writer stores 1
+    }
+}
+
+// Solve the symmetric (N x N) system M x = r by LDL^T without pivoting (M is a
+// weighted Gram matrix, positive definite whenever its determinant passes the
+// reference's 1e-8 test). The reference uses wgebra Inv::inv3/inv4 (g2p_cdf.wgsl:236,242).
+template <int N> __device__ inline void solve_spd(float *m, float *r) {
+#pragma unroll
+    for (int c = 0; c < N; c++) {
+        float inv = 1.0f / m[c * N + c];
+#pragma unroll
+        for (int i = c + 1; i < N; i++) {
+            float f = m[c * N + i] * inv;
+#pragma unroll
+            for (int j = c + 1; j < N; j++) m[j * N + i] -= f * m[j * N + c];
+            r[i] -= f * r[c];
+        }
+    }
+#pragma unroll
+    for (int i = N - 1; i >= 0; i--) {
+        float s = r[i];
+#pragma unroll
+        for (int j = i + 1; j < N; j++) s -= m[j * N + i] * r[j];
+        r[i] = s / m[i * N + i];
+    }
+}
+
+template <int N> __device__ inline float det_small(const float *m) {
+    if constexpr (N == 3) {
+        return m[0] * (m[4] * m[8] - m[7] * m[5]) - m[3] * (m[1] * m[8] - m[7] * m[2]) + m[6] * (m[1] * m[5] - m[4] * m[2]);
+    } else {
+        float s0 = m[0] * m[5] - m[4] * m[1], s1 = m[0] * m[9] - m[8] * m[1], s2 = m[0] * m[13] - m[12] * m[1];
+        float s3 = m[4] * m[9] - m[8] * m[5], s4 = m[4] * m[13] - m[12] * m[5], s5 = m[8] * m[13] - m[12] * m[9];
+        float c5 = m[10] * m[15] - m[14] * m[11], c4 = m[6] * m[15] - m[14] * m[7], c3 = m[6] * m[11] - m[10] * m[7];
+        float c2 = m[2] * m[15] - m[14] * m[3], c1 = m[2] * m[11] - m[10] * m[3], c0 = m[2] * m[7] - m[6] * m[3];
+        return s0 * c5 - s1 * c4 + s2 * c3 + s3 * c2 - s4 * c1 + s5 * c0;
+    }
+}
+
+template <int D> __global__ __launch_bounds__(256) void k_particle_cdf(Dev d, int side) {
+    constexpr int BW = Dim<D>::BW, BS = Dim<D>::BSHIFT, TW = Dim<D>::TW, TILE = Dim<D>::TILE, NN = Dim<D>::NNBR;
+    constexpr int N = D + 1;
+    using P = Pl<D>;
+    __shared__ NodeCdf s_cdf[TILE];
+    __shared__ uint32_t s_any;
+    float *buf = d.buf[side];
+    const uint32_t npad = d.npad;
+    const float h = d.h, inv_h = d.inv_h;
+    const int tid = threadIdx.x;
+    const uint32_t B = min(d.counters[CTR_NBLOCKS], d.cap);
+    for (uint32_t b = blockIdx.x; b < B; b += gridDim.x) {
+        const uint32_t cnt = d.block_count[b];
+        if (cnt == 0) continue;
+        const uint32_t start = d.block_start[b];
+        int bc[3] = {0, 0, 0};
+        unpack_key<D>(d.block_key[b], bc);
+        __syncthreads();
+        if (tid == 0) {
+            uint32_t any = 0;
+            for (int o = 0; o < NN; o++) {
+                uint32_t nb = d.nbr_plus[b * 8u + o];
+                if (nb != NONE) any |= d.block_cdf_flag[nb];
+            }
+            s_any = any;
+        }
+        __syncthreads();
+        const bool any = s_any != 0u;  // no node of the tile is near a collider -> default_cdf()
+        if (any) {
+            for (int n = tid; n < TILE; n += 256) {
+                int t[3] = {n % TW, (n / TW) % TW, D == 3 ? n / (TW * TW) : 0};
+                int o = (t[0] >= BW ? 1 : 0) | (t[1] >= BW ? 2 : 0) | (t[2] >= BW ? 4 : 0);
+                int ln = (t[0] & (BW - 1)) + ((t[1] & (BW - 1)) << BS) + (D == 3 ? ((t[2] & (BW - 1)) << (2 * BS)) : 0);
+                uint32_t nb = d.nbr_plus[b * 8u + o];
+                NodeCdf c = {0.f, 0u, NONE, 0u};
+                if (nb != NONE) c = d.node_cdf[(size_t)nb * NPB + ln];
+                s_cdf[n] = c;
+            }
+        }
+        __syncthreads();
+        for (uint32_t j = start + tid; j < start + cnt; j += 256) {
+            const uint32_t src = d.perm[j];
+            float nrm[D], dist = 0.f;
+            uint32_t aff = 0u;
+#pragma unroll
+            for (int k = 0; k < D; k++) nrm[k] = 0.f;
+            if (any) {
+                const uint32_t prev = __float_as_uint(buf[(size_t)P::AFF * npad + src]);
+                float x[D], ref[D], w[D][3];
+                int tbase = 0, stride = 1;
+#pragma unroll
+                for (int k = 0; k < D; k++) {
+                    x[k] = buf[(size_t)(P::POS + k) * npad + src];
+                    int c = assoc_cell(x[k], h);
+                    ref[k] = (float)c * h - x[k];
+                    eval_all(-ref[k] * inv_h, w[k]);
+                    tbase += (c - bc[k] * BW) * stride;
+                    stride *= TW;
+                }
+                // pass 1 (g2p_cdf.wgsl:150-181): union of affinities, sign vote per collider
+                float signs[16];
+#pragma unroll
+                for (int c = 0; c < 16; c++) signs[c] = 0.f;
+                constexpr int SZN = D == 3 ? 3 : 1;
+                for (int sz = 0; sz < SZN; sz++)
+                    for (int sy = 0; sy < 3; sy++)
+                        for (int sx = 0; sx < 3; sx++) {
+                            NodeCdf nc = s_cdf[tbase + sx + TW * sy + (D == 3 ? TW * TW * sz : 0)];
+                            aff |= nc.affinities & 0xffffu;
+                            float wgt = w[0][sx] * w[1][sy];
+                            if constexpr (D == 3) wgt *= w[2][sz];
+                            if (nc.affinities & 0xffffu) {
+#pragma unroll
+                                for (int c = 0; c < 16; c++) {
+                                    float compatible = (nc.affinities >> c) & 1u ? 1.f : 0.f;
+                                    float sign = (nc.affinities >> (16 + c)) & 1u ? -1.f : 1.f;
+                                    signs[c] += compatible * wgt * sign * nc.distance;
+                                }
+                            }
+                        }
+#pragma unroll
+                for (int c = 0; c < 16; c++) {
+                    uint32_t mask = 1u << (c + 16);
+                    if ((prev & (1u << c)) == 0u) aff |= signs[c] < 0.f ? mask : 0u;
+                    else aff |= prev & mask;
+                }
+                // pass 2 (g2p_cdf.wgsl:192-231): weighted least squares for (grad d, d)
+                float qtq[N * N], qtu[N];
+#pragma unroll
+                for (int k = 0; k < N * N; k++) qtq[k] = 0.f;
+#pragma unroll
+                for (int k = 0; k < N; k++) qtu[k] = 0.f;
+                for (int sz = 0; sz < SZN; sz++)
+                    for (int sy = 0; sy < 3; sy++)
+                        for (int sx = 0; sx < 3; sx++) {
+                            NodeCdf nc = s_cdf[tbase + sx + TW * sy + (D == 3 ? TW * TW * sz : 0)];
+                            uint32_t combined = nc.affinities & aff & 0xffffu;
+                            if (combined == 0u) continue;
+                            uint32_t sdiff = ((nc.affinities >> 16) ^ (aff >> 16)) & combined;
+                            float wgt = w[0][sx] * w[1][sy];
+                            float pv[N];
+                            pv[0] = ref[0] + (float)sx * h;
+                            pv[1] = ref[1] + (float)sy * h;
+                            if constexpr (D == 3) {
+                                wgt *= w[2][sz];
+                                pv[2] = ref[2] + (float)sz * h;
+                            }
+                            pv[D] = 1.f;
+                            float dd = sdiff == 0u ? nc.distance : -nc.distance;
+#pragma unroll
+                            for (int c = 0; c < N; c++)
+#pragma unroll
+                                for (int r = 0; r < N; r++) qtq[c * N + r] += (pv[r] * pv[c]) * wgt;
+#pragma unroll
+                            for (int r = 0; r < N; r++) qtu[r] += pv[r] * wgt * dd;
+                        }
+                if (det_small<N>(qtq) > 1.0e-8f) {
+                    solve_spd<N>(qtq, qtu);
+                    float n2 = 0.f;
+#pragma unroll
+                    for (int k = 0; k < D; k++) n2 += qtu[k] * qtu[k];
+                    float len = sqrtf(n2);
+#pragma unroll
+                    for (int k = 0; k < D; k++) nrm[k] = (D == 2 && !(len > 1.0e-6f)) ? 0.f : qtu[k] / len;
+                    dist = qtu[D];
+                } else {
+                    aff = 0u;  // default_cdf()
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < D; k++) {
+                buf[(size_t)(P::NRM + k) * npad + src] = nrm[k];
+                buf[(size_t)(P::RVEL + k) * npad + src] = 0.f;
+            }
+            buf[(size_t)P::DIST * npad + src] = dist;
+            buf[(size_t)P::AFF * npad + src] = __uint_as_float(aff);
+        }
+    }
+}
+
+}  // namespace wgs
