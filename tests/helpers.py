@@ -71,3 +71,25 @@ def compare_grids(gpu_grid, orc_grid):
     assert gc.shape == oc.shape, f"active node sets differ: {gc.shape} vs {oc.shape}"
     assert np.array_equal(gc, oc), "active node cells differ"
     return gv, ov
+
+
+def rms(a):
+    a = np.asarray(a, np.float64)
+    return float(np.sqrt(np.mean(a * a))) if a.size else 0.0
+
+
+def assert_close_to_truth(name, got, ref32, truth, rel_tol, k32=10.0):
+    """fp32 tolerance rule used by every floating-point parity check:
+    the HIP result must be within `rel_tol` (relative RMS) of the fp64 oracle, OR — on
+    inputs where fp32 itself is ill-conditioned (e.g. stress of a rigid free fall, where
+    tau is round-off times E) — within `k32` times the error the fp32 restatement of the
+    reference's own arithmetic makes against the same fp64 truth."""
+    got = np.asarray(got, np.float64)
+    truth = np.asarray(truth, np.float64)
+    e_gpu = rms(got - truth)
+    e_32 = rms(np.asarray(ref32, np.float64) - truth)
+    scale = rms(truth)
+    bound = max(rel_tol * scale, k32 * e_32)
+    assert np.isfinite(e_gpu) and e_gpu <= bound, (
+        f"{name}: rms err {e_gpu:.3e} > bound {bound:.3e} (scale {scale:.3e}, fp32-oracle err {e_32:.3e})")
+    return e_gpu / scale if scale > 0 else e_gpu
