@@ -387,6 +387,7 @@ wgs_status wgs_data_create(wgs_pipeline *pipeline, const wgs_sim_params *params,
     TRY_ALLOC(&dev.buf[1], plane_floats);
     TRY_ALLOC(&dev.perm, (size_t)dev.npad);
     TRY_ALLOC(&dev.cellid, (size_t)dev.npad);
+    TRY_ALLOC(&dev.rank, (size_t)dev.npad);
     TRY_ALLOC(&dev.hkeys, (size_t)hcap);
     TRY_ALLOC(&dev.hvals, (size_t)hcap);
     TRY_ALLOC(&dev.block_key, (size_t)dev.cap);

@@ -25,11 +25,20 @@ template <int D> __device__ inline void load_cell(const float *in, uint32_t npad
 }
 
 // sort.wgsl:26-36 touch_particle_blocks + grid.wgsl:323-334 mark_block_as_active.
+// Workgroup-level de-duplication: the distinct blocks of the 256 particles are collected
+// in a small LDS set (particles arrive block-sorted from the previous substep, so there
+// are 1-3 of them), then 8 lanes per distinct block probe the global hash map. Global
+// atomics happen only for genuinely new blocks.
+constexpr int TOUCH_SET = 32;
 template <int D> __global__ __launch_bounds__(SORT_THREADS) void k_touch_blocks(Dev d, int side) {
     constexpr int BS = Dim<D>::BSHIFT;
     constexpr int NN = Dim<D>::NNBR;
+    __shared__ uint32_t s_keys[TOUCH_SET];
     const float *in = d.buf[side];
-    uint32_t i = blockIdx.x * SORT_THREADS + threadIdx.x;
+    const int tid = threadIdx.x;
+    if (tid < TOUCH_SET) s_keys[tid] = NONE;
+    __syncthreads();
+    uint32_t i = blockIdx.x * SORT_THREADS + tid;
     bool valid = i < d.n;
     int b[3] = {0, 0, 0};
     uint32_t key = NONE;
@@ -49,21 +58,38 @@ template <int D> __global__ __launch_bounds__(SORT_THREADS) void k_touch_blocks(
             key = pack_key<D>(b);
         }
     }
-    const int lane = threadIdx.x & 63;
+    const int lane = tid & 63;
     unsigned long long todo = __ballot(valid);
     while (todo) {  // wave-uniform: one iteration per distinct block in the wave
         int leader = __ffsll((long long)todo) - 1;
         uint32_t k0 = __shfl(key, leader);
-        int lb[3];
-        lb[0] = __shfl(b[0], leader);
-        lb[1] = __shfl(b[1], leader);
-        lb[2] = __shfl(b[2], leader);
         todo &= ~__ballot(valid && key == k0);
-        if (lane < NN) {  // grid.wgsl:300-320: the 2^D blocks {b, b+1} per axis, one per lane
-            int nb[3];
-            nb[0] = lb[0] + (lane & 1);
-            nb[1] = lb[1] + ((lane >> 1) & 1);
-            nb[2] = lb[2] + ((lane >> 2) & 1);
+        if (lane == leader) {
+            // insert into the workgroup's LDS set; on overflow fall back to direct activation
+            uint32_t slot = hash_key(k0) & (TOUCH_SET - 1);
+            bool placed = false;
+            for (int probe = 0; probe < TOUCH_SET; probe++) {
+                uint32_t old = atomicCAS(&s_keys[slot], NONE, k0);
+                if (old == NONE || old == k0) { placed = true; break; }
+                slot = (slot + 1) & (TOUCH_SET - 1);
+            }
+            if (!placed) {
+                for (int o = 0; o < NN; o++) {
+                    int nb[3] = {b[0] + (o & 1), b[1] + ((o >> 1) & 1), b[2] + ((o >> 2) & 1)};
+                    activate_block(d, pack_key<D>(nb));
+                }
+            }
+        }
+    }
+    __syncthreads();
+    // grid.wgsl:300-320: the 2^D blocks {b, b+1} per axis of every distinct block, one per thread
+    {
+        const int slot = tid >> 3, o = tid & 7;
+        const uint32_t k0 = s_keys[slot];
+        if (k0 != NONE && o < NN) {
+            int lb[3] = {0, 0, 0};
+            unpack_key<D>(k0, lb);
+            int nb[3] = {lb[0] + (o & 1), lb[1] + ((o >> 1) & 1), lb[2] + ((o >> 2) & 1)};
             activate_block(d, pack_key<D>(nb));
         }
     }
@@ -96,8 +122,14 @@ template <int D> __global__ __launch_bounds__(SORT_THREADS) void k_block_links(D
 }
 
 // sort.wgsl:89-99 update_block_particle_count, extended to per-cell counts.
+// Scattered device-scope atomics run at the memory side on MI355X (~20 G/s when every lane
+// hits its own line), so counting is done in LDS per (wave, block): lanes get their rank
+// inside the wave's group from an LDS atomic, and one coalesced returning global atomic per
+// (wave, block) reserves the group's range inside each cell. rank_in_cell depends on the
+// arrival order of those atomics; k_canonical_order removes that dependence.
 template <int D> __global__ __launch_bounds__(SORT_THREADS) void k_count(Dev d, int side) {
     constexpr int BS = Dim<D>::BSHIFT, BW = Dim<D>::BW;
+    __shared__ uint32_t s_hist[SORT_THREADS / 64][NPB];
     const float *in = d.buf[side];
     uint32_t i = blockIdx.x * SORT_THREADS + threadIdx.x;
     bool valid = i < d.n;
@@ -115,13 +147,15 @@ template <int D> __global__ __launch_bounds__(SORT_THREADS) void k_count(Dev d, 
         valid = block_in_key_range<D>(b);
         key = valid ? pack_key<D>(b) : NONE;
     }
-    const int lane = threadIdx.x & 63;
-    uint32_t id = NONE;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t *hist = s_hist[wave];
+    uint32_t cid = NONE, rank = 0;
     unsigned long long todo = __ballot(valid);
     while (todo) {
         int leader = __ffsll((long long)todo) - 1;
         uint32_t k0 = __shfl(key, leader);
-        unsigned long long same = __ballot(valid && key == k0);
+        const bool mine = valid && key == k0;
+        unsigned long long same = __ballot(mine);
         todo &= ~same;
         uint32_t found = 0;
         if (lane == leader) {
@@ -129,12 +163,24 @@ template <int D> __global__ __launch_bounds__(SORT_THREADS) void k_count(Dev d, 
             if (found != NONE) atomicAdd(&d.block_count[found], (uint32_t)__popcll(same));
         }
         found = __shfl(found, leader);
-        if (valid && key == k0) id = found;
+        if (found == NONE) continue;  // block missing (grid overflow): particle is dropped, error already flagged
+        // Cross-lane traffic through LDS inside one wave: use (relaxed, wavefront-scope) atomic
+        // accesses so the compiler may not forward this lane's own stores to its loads.
+        __hip_atomic_store(&hist[lane], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+        uint32_t r = 0;
+        if (mine) r = __hip_atomic_fetch_add(&hist[local], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+        uint32_t cnt = __hip_atomic_load(&hist[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+        uint32_t base = 0;
+        if (cnt) base = atomicAdd(&d.cell_count[found * NPB + lane], cnt);  // one coalesced atomic per (wave, block)
+        __hip_atomic_store(&hist[lane], base, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+        if (mine) {
+            cid = found * NPB + local;
+            rank = __hip_atomic_load(&hist[local], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT) + r;
+        }
     }
     if (i < d.n) {
-        uint32_t cid = id == NONE ? NONE : id * NPB + local;
         d.cellid[i] = cid;
-        if (cid != NONE) atomicAdd(&d.cell_count[cid], 1u);
+        d.rank[i] = rank;
     }
 }
 
@@ -199,7 +245,7 @@ __global__ __launch_bounds__(SORT_THREADS) void k_cell_offsets(Dev d) {
         }
         uint32_t start = d.block_start[b] + inc - cnt;
         d.cell_start[idx] = start;
-        d.cell_cursor[idx] = start;
+        d.cell_cursor[idx] = start + cnt;  // cell end
         d.cell_count[idx] = 0;  // ready for the next substep
     }
 }
@@ -210,8 +256,7 @@ __global__ __launch_bounds__(SORT_THREADS) void k_scatter(Dev d) {
     if (i >= d.n) return;
     uint32_t cid = d.cellid[i];
     if (cid == NONE) return;
-    uint32_t r = atomicAdd(&d.cell_cursor[cid], 1u);
-    d.perm[r] = i;
+    d.perm[d.cell_start[cid] + d.rank[i]] = i;
 }
 
 // Canonical order inside each cell: ascending persistent particle id.

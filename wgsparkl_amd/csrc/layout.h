@@ -85,6 +85,7 @@ struct Dev {
     float *buf[2];       // ping-pong particle buffers
     uint32_t *perm;      // sorted slot -> index in the current buffer
     uint32_t *cellid;    // per particle (current-buffer index): dense block id * 64 + cell in block
+    uint32_t *rank;      // per particle: position inside its cell (arrival order; canonicalised later)
     // sparse block grid (grid.wgsl:82-184): open-addressing hash of packed block keys
     uint32_t *hkeys;     // hcap: packed key or NONE
     uint32_t *hvals;     // hcap: dense block id
@@ -97,7 +98,7 @@ struct Dev {
     uint32_t *nbr_minus;   // cap*8: dense ids of b - {0,1}^D or NONE
     uint32_t *cell_count;  // cap*64 (zero outside the sort)
     uint32_t *cell_start;  // cap*64
-    uint32_t *cell_cursor; // cap*64
+    uint32_t *cell_cursor; // cap*64: end of the cell's range in perm
     float4 *nodes;         // cap*64: velocity|momentum xyz, mass (2D: vx, vy, mass, 0)
     NodeCdf *node_cdf;     // cap*64
     float4 *slab;          // cap*TILE: per-block P2G tile (block + its "+1" rim)
