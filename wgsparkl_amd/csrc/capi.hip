@@ -12,6 +12,7 @@
 #include <cfloat>
 #include <cstddef>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -122,54 +123,97 @@ struct ParticleOffsets {  // word offsets inside wgs_particle
     uint32_t stride, pos, vel, F, C, nrm, rvel, dist, aff, vol, rad, mass, lam, mu, has_pl, dp, has_ph, phase;
 };
 
+// Unpacked view of one particle slot (quad layout of layout.h).
+struct Unpacked {
+    float x[D], v[D], F[DD], C[DD], mass, vol, lam, mu;
+    float nrm[D], rvel[D], dist;
+    uint32_t aff;
+    float dp[6], st[3], phase[2];
+};
+
+template <int DIM> __device__ inline void unpack_slot(const float *in, uint32_t npad, uint32_t j, bool plastic, bool cpic, Unpacked &u) {
+    using P = Pl<DIM>;
+    if constexpr (DIM == 3) {
+        const float4 xm = ldq(in, npad, P::XM, j), c0 = ldq(in, npad, P::CV0, j), c1 = ldq(in, npad, P::CV1, j),
+                     c2 = ldq(in, npad, P::CV2, j), f0 = ldq(in, npad, P::F0, j), f1 = ldq(in, npad, P::F1, j),
+                     f2 = ldq(in, npad, P::F2, j);
+        u.x[0] = xm.x; u.x[1] = xm.y; u.x[D - 1] = xm.z; u.mass = xm.w;
+        u.C[0] = c0.x; u.C[1] = c0.y; u.C[2] = c0.z; u.C[3] = c0.w;
+        u.C[DD - 5] = c1.x; u.C[DD - 4] = c1.y; u.C[DD - 3] = c1.z; u.C[DD - 2] = c1.w; u.C[DD - 1] = c2.x;
+        u.v[0] = c2.y; u.v[1] = c2.z; u.v[D - 1] = c2.w;
+        u.F[0] = f0.x; u.F[1] = f0.y; u.F[2] = f0.z; u.F[3] = f0.w;
+        u.F[DD - 5] = f1.x; u.F[DD - 4] = f1.y; u.F[DD - 3] = f1.z; u.F[DD - 2] = f1.w; u.F[DD - 1] = f2.x;
+        u.vol = f2.y; u.lam = f2.z; u.mu = f2.w;
+    } else {
+        const float4 xm = ldq(in, npad, P::XM, j), c0 = ldq(in, npad, P::CV0, j), vl = ldq(in, npad, P::CV2, j),
+                     f0 = ldq(in, npad, P::F0, j);
+        u.x[0] = xm.x; u.x[1] = xm.y; u.mass = xm.z; u.vol = xm.w;
+        u.C[0] = c0.x; u.C[1] = c0.y; u.C[2] = c0.z; u.C[3] = c0.w;
+        u.v[0] = vl.x; u.v[1] = vl.y; u.lam = vl.z; u.mu = vl.w;
+        u.F[0] = f0.x; u.F[1] = f0.y; u.F[2] = f0.z; u.F[3] = f0.w;
+    }
+    for (int k = 0; k < D; k++) { u.nrm[k] = 0.f; u.rvel[k] = 0.f; }
+    u.dist = 0.f;
+    u.aff = 0u;
+    if (cpic) {
+        const float4 a = ldq(in, npad, P::CDF0, j), b = ldq(in, npad, P::CDF1, j);
+        u.nrm[0] = a.x; u.nrm[1] = a.y; u.rvel[0] = b.x; u.rvel[1] = b.y;
+        if constexpr (DIM == 3) { u.nrm[D - 1] = a.z; u.dist = a.w; u.rvel[D - 1] = b.z; u.aff = __float_as_uint(b.w); }
+        else { u.dist = a.z; u.aff = __float_as_uint(a.w); }
+    }
+    if (plastic) {
+        const float4 d0 = ldq(in, npad, P::DP0, j), d1 = ldq(in, npad, P::DP1, j), d2 = ldq(in, npad, P::DP2, j);
+        u.dp[0] = d0.x; u.dp[1] = d0.y; u.dp[2] = d0.z; u.dp[3] = d0.w; u.dp[4] = d1.x; u.dp[5] = d1.y;
+        u.st[0] = d1.z; u.st[1] = d1.w; u.st[2] = d2.x; u.phase[0] = d2.y; u.phase[1] = d2.z;
+    }
+}
+
 __global__ void k_export_particles(Dev d, int side, ParticleOffsets o, bool plastic, bool cpic, const float *s_radius,
                                    const float *s_dp, const float *s_phase, const uint32_t *s_flags, float *out,
                                    float *plastic_out) {
     const float *in = d.buf[side];
     const uint32_t npad = d.npad;
     for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < d.n; j += gridDim.x * blockDim.x) {
-        const uint32_t pid = __float_as_uint(in[(size_t)P::PID * npad + j]);
+        const uint32_t pid = ldpid<D>(in, npad, j);
+        Unpacked u;
+        unpack_slot<D>(in, npad, j, plastic, cpic, u);
         float *r = out + (size_t)pid * o.stride;
         for (int k = 0; k < D; k++) {
-            r[o.pos + k] = in[(size_t)(P::POS + k) * npad + j];
-            r[o.vel + k] = in[(size_t)(P::VEL + k) * npad + j];
-            r[o.nrm + k] = cpic ? in[(size_t)(P::NRM + k) * npad + j] : 0.f;
-            r[o.rvel + k] = cpic ? in[(size_t)(P::RVEL + k) * npad + j] : 0.f;
+            r[o.pos + k] = u.x[k];
+            r[o.vel + k] = u.v[k];
+            r[o.nrm + k] = u.nrm[k];
+            r[o.rvel + k] = u.rvel[k];
         }
         for (int k = 0; k < DD; k++) {
-            r[o.F + k] = in[(size_t)(P::F + k) * npad + j];
-            r[o.C + k] = in[(size_t)(P::C + k) * npad + j];
+            r[o.F + k] = u.F[k];
+            r[o.C + k] = u.C[k];
         }
-        r[o.dist] = cpic ? in[(size_t)P::DIST * npad + j] : 0.f;
-        r[o.aff] = cpic ? in[(size_t)P::AFF * npad + j] : 0.f;
-        r[o.vol] = in[(size_t)P::VOL * npad + j];
+        r[o.dist] = u.dist;
+        r[o.aff] = __uint_as_float(u.aff);
+        r[o.vol] = u.vol;
         r[o.rad] = s_radius[pid];
-        r[o.mass] = in[(size_t)P::MASS * npad + j];
-        r[o.lam] = in[(size_t)P::LAM * npad + j];
-        r[o.mu] = in[(size_t)P::MU * npad + j];
+        r[o.mass] = u.mass;
+        r[o.lam] = u.lam;
+        r[o.mu] = u.mu;
         const uint32_t fl = s_flags[pid];
         r[o.has_pl] = __uint_as_float(fl & 1u);
         r[o.has_ph] = __uint_as_float((fl >> 1) & 1u);
         for (int k = 0; k < 6; k++) r[o.dp + k] = s_dp[(size_t)pid * 6 + k];
-        if (plastic) {
-            r[o.phase] = in[(size_t)P::PHASE * npad + j];
-            r[o.phase + 1] = in[(size_t)(P::PHASE + 1) * npad + j];
-        } else {
-            r[o.phase] = s_phase[(size_t)pid * 2];
-            r[o.phase + 1] = s_phase[(size_t)pid * 2 + 1];
-        }
-        if (plastic_out) {
-            for (int k = 0; k < 3; k++)
-                plastic_out[(size_t)pid * 3 + k] = plastic ? in[(size_t)(P::DPS + k) * npad + j] : (k < 2 ? 1.f : 0.f);
-        }
+        r[o.phase] = plastic ? u.phase[0] : s_phase[(size_t)pid * 2];
+        r[o.phase + 1] = plastic ? u.phase[1] : s_phase[(size_t)pid * 2 + 1];
+        if (plastic_out)
+            for (int k = 0; k < 3; k++) plastic_out[(size_t)pid * 3 + k] = plastic ? u.st[k] : (k < 2 ? 1.f : 0.f);
     }
 }
 
 __global__ void k_export_positions(Dev d, int side, float *out) {
     const float *in = d.buf[side];
     for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < d.n; j += gridDim.x * blockDim.x) {
-        const uint32_t pid = __float_as_uint(in[(size_t)P::PID * d.npad + j]);
-        for (int k = 0; k < D; k++) out[(size_t)pid * D + k] = in[(size_t)(P::POS + k) * d.npad + j];
+        const uint32_t pid = ldpid<D>(in, d.npad, j);
+        const float4 xm = ldq(in, d.npad, P::XM, j);
+        out[(size_t)pid * D + 0] = xm.x;
+        out[(size_t)pid * D + 1] = xm.y;
+        if (D == 3) out[(size_t)pid * D + D - 1] = xm.z;
     }
 }
 
@@ -254,12 +298,16 @@ template <bool TS> wgs_status enqueue_substep(wgs_data *d, int ts_slot) {
     };
     mark(0);
     // ---- "grid sort" (grid.rs:30-207)
-    HIP_TRY(hipMemsetAsync(dev.hkeys, 0xff, sizeof(uint32_t) * ((size_t)dev.hmask + 1), s));   // reset_hmap
-    HIP_TRY(hipMemsetAsync(dev.counters + CTR_NBLOCKS, 0, sizeof(uint32_t), s));
+    const uint32_t epoch = (uint32_t)(d->substeps + 1);
+    if (d->substeps % REHASH_PERIOD == 0) {  // reset_hmap, amortised (device_math.h)
+        HIP_TRY(hipMemsetAsync(dev.hkeys, 0xff, sizeof(uint32_t) * ((size_t)dev.hmask + 1), s));
+        HIP_TRY(hipMemsetAsync(dev.hstamp, 0, sizeof(uint32_t) * ((size_t)dev.hmask + 1), s));
+    }
     if (n > 0) {
-        hipLaunchKernelGGL(k_touch_blocks<D>, dim3(pgrid), dim3(SORT_THREADS), 0, s, dev, side);
-        hipLaunchKernelGGL(k_block_links<D>, dim3(grid_for(d, 4)), dim3(SORT_THREADS), 0, s, dev);
-        hipLaunchKernelGGL(k_count<D>, dim3(pgrid), dim3(SORT_THREADS), 0, s, dev, side);
+        hipLaunchKernelGGL(k_touch_blocks<D>, dim3(pgrid), dim3(SORT_THREADS), 0, s, dev, side, epoch);
+        hipLaunchKernelGGL(k_assign_block_ids, dim3(1), dim3(ASSIGN_THREADS), 0, s, dev, epoch);
+        hipLaunchKernelGGL(k_block_links<D>, dim3(grid_for(d, 4)), dim3(SORT_THREADS), 0, s, dev, epoch);
+        hipLaunchKernelGGL(k_count<D>, dim3(pgrid), dim3(SORT_THREADS), 0, s, dev, side, epoch);
         hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(SCAN_THREADS), 0, s, dev);
         hipLaunchKernelGGL(k_cell_offsets, dim3(grid_for(d, 4)), dim3(SORT_THREADS), 0, s, dev);
         hipLaunchKernelGGL(k_scatter, dim3(pgrid), dim3(SORT_THREADS), 0, s, dev);
@@ -305,6 +353,7 @@ template <bool TS> wgs_status enqueue_substep(wgs_data *d, int ts_slot) {
 #undef WGS_LAUNCH_G2P
         mark(6);
     } else {
+        HIP_TRY(hipMemsetAsync(dev.counters + CTR_NBLOCKS, 0, sizeof(uint32_t), s));
         mark(4);
         mark(5);
         mark(6);
@@ -351,7 +400,9 @@ wgs_status wgs_data_create(wgs_pipeline *pipeline, const wgs_sim_params *params,
         return fail(WGS_ERR_UNSUPPORTED, "at most 16 coupled colliders (grid.wgsl:230-240)");
     if (!(cell_width > 0.f)) return fail(WGS_ERR_INVALID_ARGUMENT, "cell_width must be > 0");
     if (grid_capacity == 0 || grid_capacity > (1u << 25)) return fail(WGS_ERR_INVALID_ARGUMENT, "grid_capacity out of range");
-    if (num_particles >= 0xfffffff0ull) return fail(WGS_ERR_INVALID_ARGUMENT, "too many particles");
+    // 32-bit byte offsets inside one ping-pong buffer (layout.h ldp/stp)
+    if (buffer_floats<D>((uint32_t)num_particles + 64) * 4 >= (1ull << 32))
+        return fail(WGS_ERR_UNSUPPORTED, "more than ~21M particles per wgs_data: shard across GPUs");
     *out = nullptr;
     HIP_TRY(hipSetDevice(pipeline->device));
     wgs_data *d = new wgs_data();
@@ -374,6 +425,7 @@ wgs_status wgs_data_create(wgs_pipeline *pipeline, const wgs_sim_params *params,
     dev.h = cell_width;
     dev.inv_h = 1.0f / cell_width;
     dev.model = WGS_MODEL_COROTATED;
+    dev.dbg = getenv("WGS_DEBUG") ? (uint32_t)strtoul(getenv("WGS_DEBUG"), nullptr, 0) : 0u;
     dev.n_colliders = (uint32_t)num_colliders;
     d->cpic = num_colliders > 0;
 
@@ -382,7 +434,7 @@ wgs_status wgs_data_create(wgs_pipeline *pipeline, const wgs_sim_params *params,
         st = dev_alloc(d, __VA_ARGS__);     \
         if (st != WGS_OK) return bail(st);  \
     } while (0)
-    const size_t plane_floats = (size_t)P::COUNT * dev.npad;
+    const size_t plane_floats = buffer_floats<D>(dev.npad);
     TRY_ALLOC(&dev.buf[0], plane_floats);
     TRY_ALLOC(&dev.buf[1], plane_floats);
     TRY_ALLOC(&dev.perm, (size_t)dev.npad);
@@ -390,6 +442,7 @@ wgs_status wgs_data_create(wgs_pipeline *pipeline, const wgs_sim_params *params,
     TRY_ALLOC(&dev.rank, (size_t)dev.npad);
     TRY_ALLOC(&dev.hkeys, (size_t)hcap);
     TRY_ALLOC(&dev.hvals, (size_t)hcap);
+    TRY_ALLOC(&dev.hstamp, (size_t)hcap);
     TRY_ALLOC(&dev.block_key, (size_t)dev.cap);
     TRY_ALLOC(&dev.block_count, (size_t)dev.cap);
     TRY_ALLOC(&dev.block_start, (size_t)dev.cap);
@@ -421,38 +474,47 @@ wgs_status wgs_data_create(wgs_pipeline *pipeline, const wgs_sim_params *params,
     const float deg = 3.14159265358979323846f / 180.0f;
     const float default_dp[6] = {35.0f * deg, 9.0f * deg, 0.2f, 10.0f * deg, -1.0f, -1.0f};  // DruckerPrager::new(-1, -1)
     bool plastic = false;
-    auto pl = [&](int p) { return soa.data() + (size_t)p * dev.npad; };
+    auto quad = [&](int qd, uint32_t i) { return soa.data() + ((size_t)qd * dev.npad + i) * 4; };
+    uint32_t *pid_plane = reinterpret_cast<uint32_t *>(soa.data() + (size_t)P::NQ * 4 * dev.npad);
     for (uint32_t i = 0; i < n; i++) {
         const wgs_particle &q = particles[i];
-        for (int k = 0; k < D; k++) {
-            pl(P::POS + k)[i] = q.position[k];
-            pl(P::VEL + k)[i] = q.dynamics.velocity[k];
-            pl(P::NRM + k)[i] = q.dynamics.cdf.normal[k];
-            pl(P::RVEL + k)[i] = q.dynamics.cdf.rigid_vel[k];
+        const wgs_particle_dynamics &dy = q.dynamics;
+        float aff_bits;
+        memcpy(&aff_bits, &dy.cdf.affinity, 4);
+        if constexpr (D == 3) {
+            using P3 = Pl<3>;
+            float *p;
+            p = quad(P3::XM, i); p[0] = q.position[0]; p[1] = q.position[1]; p[2] = q.position[D - 1]; p[3] = dy.mass;
+            p = quad(P3::CV0, i); p[0] = dy.affine[0]; p[1] = dy.affine[1]; p[2] = dy.affine[2]; p[3] = dy.affine[3];
+            p = quad(P3::CV0 + 1, i); p[0] = dy.affine[DD - 5]; p[1] = dy.affine[DD - 4]; p[2] = dy.affine[DD - 3]; p[3] = dy.affine[DD - 2];
+            p = quad(P3::CV2, i); p[0] = dy.affine[DD - 1]; p[1] = dy.velocity[0]; p[2] = dy.velocity[1]; p[3] = dy.velocity[D - 1];
+            p = quad(P3::F0, i); p[0] = dy.def_grad[0]; p[1] = dy.def_grad[1]; p[2] = dy.def_grad[2]; p[3] = dy.def_grad[3];
+            p = quad(P3::F0 + 1, i); p[0] = dy.def_grad[DD - 5]; p[1] = dy.def_grad[DD - 4]; p[2] = dy.def_grad[DD - 3]; p[3] = dy.def_grad[DD - 2];
+            p = quad(P3::F0 + 2, i); p[0] = dy.def_grad[DD - 1]; p[1] = dy.init_volume; p[2] = q.model.lambda; p[3] = q.model.mu;
+            p = quad(P3::CDF0, i); p[0] = dy.cdf.normal[0]; p[1] = dy.cdf.normal[1]; p[2] = dy.cdf.normal[D - 1]; p[3] = dy.cdf.signed_distance;
+            p = quad(P3::CDF1, i); p[0] = dy.cdf.rigid_vel[0]; p[1] = dy.cdf.rigid_vel[1]; p[2] = dy.cdf.rigid_vel[D - 1]; p[3] = aff_bits;
+        } else {
+            using P2 = Pl<2>;
+            float *p;
+            p = quad(P2::XM, i); p[0] = q.position[0]; p[1] = q.position[1]; p[2] = dy.mass; p[3] = dy.init_volume;
+            p = quad(P2::CV0, i); p[0] = dy.affine[0]; p[1] = dy.affine[1]; p[2] = dy.affine[2]; p[3] = dy.affine[3];
+            p = quad(P2::CV2, i); p[0] = dy.velocity[0]; p[1] = dy.velocity[1]; p[2] = q.model.lambda; p[3] = q.model.mu;
+            p = quad(P2::F0, i); p[0] = dy.def_grad[0]; p[1] = dy.def_grad[1]; p[2] = dy.def_grad[2]; p[3] = dy.def_grad[3];
+            p = quad(P2::CDF0, i); p[0] = dy.cdf.normal[0]; p[1] = dy.cdf.normal[1]; p[2] = dy.cdf.signed_distance; p[3] = aff_bits;
+            p = quad(P2::CDF1, i); p[0] = dy.cdf.rigid_vel[0]; p[1] = dy.cdf.rigid_vel[1]; p[2] = 0.f; p[3] = 0.f;
         }
-        for (int k = 0; k < DD; k++) {
-            pl(P::F + k)[i] = q.dynamics.def_grad[k];
-            pl(P::C + k)[i] = q.dynamics.affine[k];
-        }
-        pl(P::DIST)[i] = q.dynamics.cdf.signed_distance;
-        memcpy(&pl(P::AFF)[i], &q.dynamics.cdf.affinity, 4);
-        pl(P::MASS)[i] = q.dynamics.mass;
-        pl(P::VOL)[i] = q.dynamics.init_volume;
-        pl(P::LAM)[i] = q.model.lambda;
-        pl(P::MU)[i] = q.model.mu;
-        memcpy(&pl(P::PID)[i], &i, 4);
+        pid_plane[i] = i;
         const float *dp = q.has_plasticity ? &q.plasticity.h0 : default_dp;
-        for (int k = 0; k < 6; k++) {
-            pl(P::DP + k)[i] = dp[k];
-            s_dp[(size_t)i * 6 + k] = dp[k];
-        }
-        pl(P::DPS + 0)[i] = 1.0f;  // DruckerPragerPlasticState::default(), drucker_prager.rs:44-53
-        pl(P::DPS + 1)[i] = 1.0f;
-        pl(P::DPS + 2)[i] = 0.0f;
         const float phase = q.has_phase ? q.phase.phase : 0.0f;            // models/mod.rs:33-36
         const float max_stretch = q.has_phase ? q.phase.max_stretch : -1.0f;
-        pl(P::PHASE)[i] = phase;
-        pl(P::PHASE + 1)[i] = max_stretch;
+        {
+            float *p;
+            p = quad(P::DP0, i); p[0] = dp[0]; p[1] = dp[1]; p[2] = dp[2]; p[3] = dp[3];
+            // DruckerPragerPlasticState::default() = {1, 1, 0}, drucker_prager.rs:44-53
+            p = quad(P::DP1, i); p[0] = dp[4]; p[1] = dp[5]; p[2] = 1.0f; p[3] = 1.0f;
+            p = quad(P::DP2, i); p[0] = 0.0f; p[1] = phase; p[2] = max_stretch; p[3] = 0.f;
+        }
+        for (int k = 0; k < 6; k++) s_dp[(size_t)i * 6 + k] = dp[k];
         s_phase[(size_t)i * 2] = phase;
         s_phase[(size_t)i * 2 + 1] = max_stretch;
         s_radius[i] = q.dynamics.init_radius;
@@ -660,7 +722,7 @@ wgs_status wgs_read_blocks(wgs_data *d, wgs_block_record *out, size_t capacity, 
     }
     if (sorted_ids && d->dev.n) {
         // The buffer written by the last substep is in sorted order: its pid plane IS sorted_ids.
-        const float *pidp = d->dev.buf[d->side] + (size_t)P::PID * d->dev.npad;
+        const float *pidp = d->dev.buf[d->side] + (size_t)P::NQ * 4 * d->dev.npad;
         HIP_TRY(hipMemcpyAsync(sorted_ids, pidp, sizeof(uint32_t) * (size_t)d->dev.n, hipMemcpyDeviceToHost, d->stream));
         HIP_TRY(hipStreamSynchronize(d->stream));
     }

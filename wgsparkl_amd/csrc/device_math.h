@@ -50,37 +50,41 @@ __host__ __device__ inline uint32_t hash_key(uint32_t key) {
 // round() = ties-to-even and a true fp32 division. v_rndne_f32 + IEEE division (no fast-math).
 __device__ inline int assoc_cell(float x, float h) { return (int)(__builtin_rintf(x / h) - 1.0f); }
 
-// grid/grid.wgsl:167-184 find_block_header_id
-__device__ inline uint32_t hmap_find(const Dev &d, uint32_t key) {
+// The hash map is PERSISTENT across substeps (the reference rebuilds it every substep,
+// grid.wgsl:186-203 reset_hmap): blocks stay in the table and a per-slot epoch stamp says
+// whether a block is active in the current substep. Almost every touch is then a plain
+// L2-served lookup + an idempotent plain store; device-scope atomics (memory-side on
+// MI355X, ~1-2 us each and bandwidth-limited on a 32 KiB table) are only issued for blocks
+// never seen before. The table is cleared every REHASH_PERIOD substeps to drop stale blocks.
+constexpr uint32_t REHASH_PERIOD = 64;
+
+// grid/grid.wgsl:167-184 find_block_header_id (active blocks only)
+__device__ inline uint32_t hmap_find(const Dev &d, uint32_t key, uint32_t epoch) {
     uint32_t slot = hash_key(key) & d.hmask;
     for (uint32_t probe = 0; probe <= d.hmask; ++probe) {
         uint32_t st = d.hkeys[slot];
-        if (st == key) return d.hvals[slot];
+        if (st == key) return d.hstamp[slot] == epoch ? d.hvals[slot] : NONE;
         if (st == NONE) return NONE;
         slot = (slot + 1u) & d.hmask;
     }
     return NONE;
 }
 
-// grid/grid.wgsl:121-164 insertion_index + :323-334 mark_block_as_active.
-__device__ inline void activate_block(const Dev &d, uint32_t key) {
+// grid/grid.wgsl:121-164 insertion_index + :323-334 mark_block_as_active: make sure `key`
+// is in the table and stamp it active for `epoch`. Dense block ids are handed out afterwards
+// by k_assign_block_ids (a prefix sum over the table) instead of the reference's atomicAdd
+// on one counter (grid.wgsl:327): thousands of same-address atomics serialise at ~12 ns each.
+__device__ inline void activate_block(const Dev &d, uint32_t key, uint32_t epoch) {
     uint32_t slot = hash_key(key) & d.hmask;
     for (uint32_t probe = 0; probe <= d.hmask; ++probe) {
-        uint32_t cur = __hip_atomic_load(&d.hkeys[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (cur == key) return;
+        uint32_t cur = d.hkeys[slot];  // plain load: a stale NONE only costs one extra CAS below
         if (cur == NONE) {
-            uint32_t old = atomicCAS(&d.hkeys[slot], NONE, key);
-            if (old == NONE) {
-                uint32_t id = atomicAdd(&d.counters[CTR_NBLOCKS], 1u);
-                if (id < d.cap) {
-                    d.hvals[slot] = id;
-                    d.block_key[id] = key;
-                } else {
-                    atomicOr(&d.counters[CTR_ERRORS], ERRBIT_OVERFLOW);
-                }
-                return;
-            }
-            if (old == key) return;
+            cur = atomicCAS(&d.hkeys[slot], NONE, key);
+            if (cur == NONE) cur = key;
+        }
+        if (cur == key) {
+            d.hstamp[slot] = epoch;  // every writer stores the same value
+            return;
         }
         slot = (slot + 1u) & d.hmask;
     }

@@ -244,12 +244,15 @@ template <int D> __global__ __launch_bounds__(256) void k_particle_cdf(Dev d, in
 #pragma unroll
             for (int k = 0; k < D; k++) nrm[k] = 0.f;
             if (any) {
-                const uint32_t prev = __float_as_uint(buf[(size_t)P::AFF * npad + src]);
+                const float4 xm = ldq(buf, npad, P::XM, src);
+                const float4 cprev = ldq(buf, npad, D == 3 ? (int)P::CDF1 : (int)P::CDF0, src);
+                const uint32_t prev = __float_as_uint(cprev.w);
                 float x[D], ref[D], w[D][3];
+                x[0] = xm.x; x[1] = xm.y;
+                if constexpr (D == 3) x[2] = xm.z;
                 int tbase = 0, stride = 1;
 #pragma unroll
                 for (int k = 0; k < D; k++) {
-                    x[k] = buf[(size_t)(P::POS + k) * npad + src];
                     int c = assoc_cell(x[k], h);
                     ref[k] = (float)c * h - x[k];
                     eval_all(-ref[k] * inv_h, w[k]);
@@ -326,13 +329,13 @@ template <int D> __global__ __launch_bounds__(256) void k_particle_cdf(Dev d, in
                     aff = 0u;  // default_cdf()
                 }
             }
-#pragma unroll
-            for (int k = 0; k < D; k++) {
-                buf[(size_t)(P::NRM + k) * npad + src] = nrm[k];
-                buf[(size_t)(P::RVEL + k) * npad + src] = 0.f;
+            if constexpr (D == 3) {
+                stq(buf, npad, P::CDF0, src, make_float4(nrm[0], nrm[1], nrm[2], dist));
+                stq(buf, npad, P::CDF1, src, make_float4(0.f, 0.f, 0.f, __uint_as_float(aff)));
+            } else {
+                stq(buf, npad, P::CDF0, src, make_float4(nrm[0], nrm[1], dist, __uint_as_float(aff)));
+                stq(buf, npad, P::CDF1, src, make_float4(0.f, 0.f, 0.f, 0.f));
             }
-            buf[(size_t)P::DIST * npad + src] = dist;
-            buf[(size_t)P::AFF * npad + src] = __uint_as_float(aff);
         }
     }
 }

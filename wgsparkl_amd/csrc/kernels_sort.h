@@ -20,8 +20,10 @@ namespace wgs {
 constexpr int SORT_THREADS = 256;
 
 template <int D> __device__ inline void load_cell(const float *in, uint32_t npad, uint32_t i, float h, int *cell) {
-#pragma unroll
-    for (int k = 0; k < D; k++) cell[k] = assoc_cell(in[(size_t)(Pl<D>::POS + k) * npad + i], h);
+    const float4 xm = ldq(in, npad, Pl<D>::XM, i);
+    cell[0] = assoc_cell(xm.x, h);
+    cell[1] = assoc_cell(xm.y, h);
+    if constexpr (D == 3) cell[2] = assoc_cell(xm.z, h);
 }
 
 // sort.wgsl:26-36 touch_particle_blocks + grid.wgsl:323-334 mark_block_as_active.
@@ -30,7 +32,7 @@ template <int D> __device__ inline void load_cell(const float *in, uint32_t npad
 // are 1-3 of them), then 8 lanes per distinct block probe the global hash map. Global
 // atomics happen only for genuinely new blocks.
 constexpr int TOUCH_SET = 32;
-template <int D> __global__ __launch_bounds__(SORT_THREADS) void k_touch_blocks(Dev d, int side) {
+template <int D> __global__ __launch_bounds__(SORT_THREADS) void k_touch_blocks(Dev d, int side, uint32_t epoch) {
     constexpr int BS = Dim<D>::BSHIFT;
     constexpr int NN = Dim<D>::NNBR;
     __shared__ uint32_t s_keys[TOUCH_SET];
@@ -59,12 +61,13 @@ template <int D> __global__ __launch_bounds__(SORT_THREADS) void k_touch_blocks(
         }
     }
     const int lane = tid & 63;
+    if (d.dbg & 2u) { if (valid) d.cellid[i] = key; return; }  // ablation: load + cell math only
     unsigned long long todo = __ballot(valid);
     while (todo) {  // wave-uniform: one iteration per distinct block in the wave
         int leader = __ffsll((long long)todo) - 1;
         uint32_t k0 = __shfl(key, leader);
         todo &= ~__ballot(valid && key == k0);
-        if (lane == leader) {
+        if (lane == leader && !(d.dbg & 8u)) {
             // insert into the workgroup's LDS set; on overflow fall back to direct activation
             uint32_t slot = hash_key(k0) & (TOUCH_SET - 1);
             bool placed = false;
@@ -76,12 +79,13 @@ template <int D> __global__ __launch_bounds__(SORT_THREADS) void k_touch_blocks(
             if (!placed) {
                 for (int o = 0; o < NN; o++) {
                     int nb[3] = {b[0] + (o & 1), b[1] + ((o >> 1) & 1), b[2] + ((o >> 2) & 1)};
-                    activate_block(d, pack_key<D>(nb));
+                    activate_block(d, pack_key<D>(nb), epoch);
                 }
             }
         }
     }
     __syncthreads();
+    if (d.dbg & 1u) return;  // ablation: LDS part only
     // grid.wgsl:300-320: the 2^D blocks {b, b+1} per axis of every distinct block, one per thread
     {
         const int slot = tid >> 3, o = tid & 7;
@@ -90,14 +94,68 @@ template <int D> __global__ __launch_bounds__(SORT_THREADS) void k_touch_blocks(
             int lb[3] = {0, 0, 0};
             unpack_key<D>(k0, lb);
             int nb[3] = {lb[0] + (o & 1), lb[1] + ((o >> 1) & 1), lb[2] + ((o >> 2) & 1)};
-            activate_block(d, pack_key<D>(nb));
+            activate_block(d, pack_key<D>(nb), epoch);
         }
+    }
+}
+
+// grid.wgsl:323-334 mark_block_as_active, second half: number the occupied hash slots.
+// Exclusive prefix sum of "slot occupied" over the table -> dense block id (in slot order,
+// hence reproducible), hvals[slot] = id, block_key[id] = key, num_active_blocks = total.
+constexpr int ASSIGN_THREADS = 1024;
+constexpr int ASSIGN_ITEMS = 8;
+__global__ __launch_bounds__(ASSIGN_THREADS) void k_assign_block_ids(Dev d, uint32_t epoch) {
+    __shared__ uint32_t wave_sums[ASSIGN_THREADS / 64];
+    __shared__ uint32_t carry_s;
+    const uint32_t hcap = d.hmask + 1u;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) carry_s = 0;
+    __syncthreads();
+    for (uint32_t base = 0; base < hcap; base += ASSIGN_THREADS * ASSIGN_ITEMS) {
+        uint32_t keys[ASSIGN_ITEMS];
+        uint32_t sum = 0;
+        const uint32_t first = base + (uint32_t)tid * ASSIGN_ITEMS;
+#pragma unroll
+        for (int k = 0; k < ASSIGN_ITEMS; k++) {
+            keys[k] = (first + k < hcap && d.hstamp[first + k] == epoch) ? d.hkeys[first + k] : NONE;
+            sum += keys[k] != NONE;
+        }
+        uint32_t inc = sum;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            uint32_t t = __shfl_up(inc, off);
+            if (lane >= off) inc += t;
+        }
+        if (lane == 63) wave_sums[wave] = inc;
+        __syncthreads();
+        uint32_t wave_off = 0;
+        for (int w = 0; w < wave; w++) wave_off += wave_sums[w];
+        uint32_t run = carry_s + wave_off + inc - sum;
+#pragma unroll
+        for (int k = 0; k < ASSIGN_ITEMS; k++) {
+            if (keys[k] != NONE) {
+                if (run < d.cap) {
+                    d.hvals[first + k] = run;
+                    d.block_key[run] = keys[k];
+                } else {
+                    d.hvals[first + k] = NONE;
+                }
+                run++;
+            }
+        }
+        __syncthreads();
+        if (tid == ASSIGN_THREADS - 1) carry_s = run;
+        __syncthreads();
+    }
+    if (tid == 0) {
+        d.counters[CTR_NBLOCKS] = carry_s;
+        if (carry_s > d.cap) atomicOr(&d.counters[CTR_ERRORS], ERRBIT_OVERFLOW);
     }
 }
 
 // Neighbour links of every active block (replaces the per-thread hash lookups of
 // p2g.wgsl:238-275, g2p.wgsl:72-132) and reset of the per-block particle counter.
-template <int D> __global__ __launch_bounds__(SORT_THREADS) void k_block_links(Dev d) {
+template <int D> __global__ __launch_bounds__(SORT_THREADS) void k_block_links(Dev d, uint32_t epoch) {
     constexpr int NN = Dim<D>::NNBR;
     uint32_t B = min(d.counters[CTR_NBLOCKS], d.cap);
     uint32_t total = B * 16u;
@@ -111,7 +169,7 @@ template <int D> __global__ __launch_bounds__(SORT_THREADS) void k_block_links(D
         if ((int)o < NN) {
             int sgn = minus ? -1 : 1;
             int nb[3] = {b[0] + sgn * (int)(o & 1u), b[1] + sgn * (int)((o >> 1) & 1u), b[2] + sgn * (int)((o >> 2) & 1u)};
-            if (block_in_key_range<D>(nb)) res = hmap_find(d, pack_key<D>(nb));
+            if (block_in_key_range<D>(nb)) res = hmap_find(d, pack_key<D>(nb), epoch);
         }
         (minus ? d.nbr_minus : d.nbr_plus)[id * 8u + o] = res;
         if (j == 0) {
@@ -127,7 +185,7 @@ template <int D> __global__ __launch_bounds__(SORT_THREADS) void k_block_links(D
 // inside the wave's group from an LDS atomic, and one coalesced returning global atomic per
 // (wave, block) reserves the group's range inside each cell. rank_in_cell depends on the
 // arrival order of those atomics; k_canonical_order removes that dependence.
-template <int D> __global__ __launch_bounds__(SORT_THREADS) void k_count(Dev d, int side) {
+template <int D> __global__ __launch_bounds__(SORT_THREADS) void k_count(Dev d, int side, uint32_t epoch) {
     constexpr int BS = Dim<D>::BSHIFT, BW = Dim<D>::BW;
     __shared__ uint32_t s_hist[SORT_THREADS / 64][NPB];
     const float *in = d.buf[side];
@@ -159,7 +217,7 @@ template <int D> __global__ __launch_bounds__(SORT_THREADS) void k_count(Dev d, 
         todo &= ~same;
         uint32_t found = 0;
         if (lane == leader) {
-            found = hmap_find(d, k0);
+            found = hmap_find(d, k0, epoch);
             if (found != NONE) atomicAdd(&d.block_count[found], (uint32_t)__popcll(same));
         }
         found = __shfl(found, leader);
@@ -263,7 +321,7 @@ __global__ __launch_bounds__(SORT_THREADS) void k_scatter(Dev d) {
 template <int D> __global__ __launch_bounds__(SORT_THREADS) void k_canonical_order(Dev d, int side) {
     const uint32_t B = min(d.counters[CTR_NBLOCKS], d.cap);
     const uint32_t total = B * NPB;
-    const uint32_t *pid = reinterpret_cast<const uint32_t *>(d.buf[side] + (size_t)Pl<D>::PID * d.npad);
+    const uint32_t *pid = reinterpret_cast<const uint32_t *>(d.buf[side] + (size_t)Pl<D>::NQ * 4 * d.npad);
     for (uint32_t c = blockIdx.x * SORT_THREADS + threadIdx.x; c < total; c += gridDim.x * SORT_THREADS) {
         uint32_t s = d.cell_start[c], e = d.cell_cursor[c];
         for (uint32_t a = s + 1; a < e; a++) {  // insertion sort, ~8 elements

@@ -90,26 +90,27 @@ __global__ __launch_bounds__(P2GCfg<D>::THREADS) void k_p2g(Dev d, int side) {
             __syncthreads();
             for (uint32_t j = tid; j < m; j += Cfg::THREADS) {
                 const uint32_t src = d.perm[base + j];
-                float x[D], v[D], c[DD];
-#pragma unroll
-                for (int k = 0; k < D; k++) {
-                    x[k] = in[(size_t)(Pl<D>::POS + k) * npad + src];
-                    v[k] = in[(size_t)(Pl<D>::VEL + k) * npad + src];
-                }
-#pragma unroll
-                for (int k = 0; k < DD; k++) c[k] = in[(size_t)(Pl<D>::C + k) * npad + src];
-                const float mass = in[(size_t)Pl<D>::MASS * npad + src];
                 if constexpr (D == 3) {
-                    s_rec[j * 4 + 0] = make_float4(x[0], x[1], x[2], mass);
-                    s_rec[j * 4 + 1] = make_float4(v[0] * mass, v[1] * mass, v[2] * mass, c[0]);
-                    s_rec[j * 4 + 2] = make_float4(c[1], c[2], c[3], c[4]);
-                    s_rec[j * 4 + 3] = make_float4(c[5], c[6], c[7], c[8]);
+                    const float4 xm = ldq(in, npad, Pl<3>::XM, src);
+                    const float4 c0 = ldq(in, npad, Pl<3>::CV0, src);
+                    const float4 c1 = ldq(in, npad, Pl<3>::CV1, src);
+                    const float4 c2 = ldq(in, npad, Pl<3>::CV2, src);
+                    s_rec[j * 4 + 0] = xm;
+                    s_rec[j * 4 + 1] = make_float4(c2.y * xm.w, c2.z * xm.w, c2.w * xm.w, c0.x);  // m v, c0
+                    s_rec[j * 4 + 2] = make_float4(c0.y, c0.z, c0.w, c1.x);
+                    s_rec[j * 4 + 3] = make_float4(c1.y, c1.z, c1.w, c2.x);
                 } else {
-                    s_rec[j * 3 + 0] = make_float4(x[0], x[1], mass, 0.f);
-                    s_rec[j * 3 + 1] = make_float4(v[0] * mass, v[1] * mass, c[0], c[1]);
-                    s_rec[j * 3 + 2] = make_float4(c[2], c[3], 0.f, 0.f);
+                    const float4 xm = ldq(in, npad, Pl<2>::XM, src);   // x, y, m, V0
+                    const float4 c0 = ldq(in, npad, Pl<2>::CV0, src);
+                    const float4 vl = ldq(in, npad, Pl<2>::CV2, src);  // vx, vy, lambda, mu
+                    s_rec[j * 3 + 0] = make_float4(xm.x, xm.y, xm.z, 0.f);
+                    s_rec[j * 3 + 1] = make_float4(vl.x * xm.z, vl.y * xm.z, c0.x, c0.y);
+                    s_rec[j * 3 + 2] = make_float4(c0.z, c0.w, 0.f, 0.f);
                 }
-                if constexpr (CPIC) s_aff[j] = __float_as_uint(in[(size_t)Pl<D>::AFF * npad + src]);
+                if constexpr (CPIC) {
+                    const float4 cd = ldq(in, npad, D == 3 ? (int)Pl<D>::CDF1 : (int)Pl<D>::CDF0, src);
+                    s_aff[j] = __float_as_uint(cd.w);
+                }
             }
             __syncthreads();
             const uint32_t lo = max(cs, base), hi = min(ce, base + m);
@@ -249,9 +250,12 @@ template <int D> __global__ __launch_bounds__(256) void k_grid_update(Dev d) {
 // (reference: up to three times, quirk B8) and the result is written straight
 // into the other ping-pong buffer in sorted order.
 constexpr int G2P_THREADS = 256;
+#ifndef G2P_WAVES_PER_EU
+#define G2P_WAVES_PER_EU 3
+#endif
 
 template <int D, int MODEL, bool PLASTIC, bool CPIC>
-__global__ __launch_bounds__(G2P_THREADS) void k_g2p_update(Dev d, int side) {
+__global__ __launch_bounds__(G2P_THREADS, G2P_WAVES_PER_EU) void k_g2p_update(Dev d, int side) {
     constexpr int BW = Dim<D>::BW, BS = Dim<D>::BSHIFT, TW = Dim<D>::TW, TILE = Dim<D>::TILE, NN = Dim<D>::NNBR;
     constexpr int DD = D * D;
     using P = Pl<D>;
@@ -296,28 +300,39 @@ __global__ __launch_bounds__(G2P_THREADS) void k_g2p_update(Dev d, int side) {
 
         for (uint32_t j = start + tid; j < start + cnt; j += G2P_THREADS) {
             const uint32_t src = d.perm[j];
-            float x[D];
-#pragma unroll
-            for (int k = 0; k < D; k++) x[k] = in[(size_t)(P::POS + k) * npad + src];
-            float Fm[DD];
-#pragma unroll
-            for (int k = 0; k < DD; k++) Fm[k] = in[(size_t)(P::F + k) * npad + src];
-            const float mass = in[(size_t)P::MASS * npad + src];
-            const float vol0 = in[(size_t)P::VOL * npad + src];
-            const float lambda = in[(size_t)P::LAM * npad + src];
-            const float mu = in[(size_t)P::MU * npad + src];
-            const float pidf = in[(size_t)P::PID * npad + src];
+            float x[D], Fm[DD], mass, vol0, lambda, mu;
+            if constexpr (D == 3) {
+                const float4 xm = ldq(in, npad, P::XM, src);
+                const float4 f0 = ldq(in, npad, P::F0, src), f1 = ldq(in, npad, P::F1, src), f2 = ldq(in, npad, P::F2, src);
+                x[0] = xm.x; x[1] = xm.y; x[2] = xm.z; mass = xm.w;
+                Fm[0] = f0.x; Fm[1] = f0.y; Fm[2] = f0.z; Fm[3] = f0.w;
+                Fm[4] = f1.x; Fm[5] = f1.y; Fm[6] = f1.z; Fm[7] = f1.w;
+                Fm[8] = f2.x; vol0 = f2.y; lambda = f2.z; mu = f2.w;
+            } else {
+                const float4 xm = ldq(in, npad, P::XM, src);
+                const float4 f0 = ldq(in, npad, P::F0, src);
+                const float4 vl = ldq(in, npad, P::CV2, src);
+                x[0] = xm.x; x[1] = xm.y; mass = xm.z; vol0 = xm.w;
+                Fm[0] = f0.x; Fm[1] = f0.y; Fm[2] = f0.z; Fm[3] = f0.w;
+                lambda = vl.z; mu = vl.w;
+            }
+            const uint32_t pid = ldpid<D>(in, npad, src);
 
             float pvel[D], nrm[D], sdist = 0.f;
             uint32_t paff = 0;
             if constexpr (CPIC) {
-#pragma unroll
-                for (int k = 0; k < D; k++) {
-                    pvel[k] = in[(size_t)(P::VEL + k) * npad + src];
-                    nrm[k] = in[(size_t)(P::NRM + k) * npad + src];
+                const float4 c0 = ldq(in, npad, P::CDF0, src);
+                nrm[0] = c0.x; nrm[1] = c0.y;
+                if constexpr (D == 3) {
+                    const float4 cv = ldq(in, npad, P::CV2, src);
+                    const float4 c1 = ldq(in, npad, P::CDF1, src);
+                    nrm[2] = c0.z; sdist = c0.w; paff = __float_as_uint(c1.w);
+                    pvel[0] = cv.y; pvel[1] = cv.z; pvel[2] = cv.w;
+                } else {
+                    const float4 vl = ldq(in, npad, P::CV2, src);
+                    sdist = c0.z; paff = __float_as_uint(c0.w);
+                    pvel[0] = vl.x; pvel[1] = vl.y;
                 }
-                sdist = in[(size_t)P::DIST * npad + src];
-                paff = __float_as_uint(in[(size_t)P::AFF * npad + src]);
             }
 
             // ---- G2P (g2p.wgsl:150-218)
@@ -339,7 +354,9 @@ __global__ __launch_bounds__(G2P_THREADS) void k_g2p_update(Dev d, int side) {
 #pragma unroll
             for (int k = 0; k < DD; k++) grad[k] = 0.f;
             constexpr int SZN = D == 3 ? 3 : 1;
-#pragma unroll
+            // The z loop is kept rolled on purpose: fully unrolled, hipcc issues all 27
+            // ds_read_b128 up front (108 VGPRs of tile values) and the kernel drops to 2 waves/SIMD.
+#pragma unroll 1
             for (int sz = 0; sz < SZN; sz++)
 #pragma unroll
                 for (int sy = 0; sy < 3; sy++)
@@ -355,7 +372,7 @@ __global__ __launch_bounds__(G2P_THREADS) void k_g2p_update(Dev d, int side) {
                         dpt[1] = ref[1] + (float)sy * h;
                         if constexpr (D == 3) dpt[2] = ref[2] + (float)sz * h;
                         float wgt = w[0][sx] * w[1][sy];
-                        if constexpr (D == 3) wgt *= w[2][sz];
+                        if constexpr (D == 3) wgt *= (sz == 0 ? w[2][0] : (sz == 1 ? w[2][1] : w[2][2]));
                         if constexpr (CPIC) {
                             NodeCdf nc = s_cdf[idx];
                             if (!affinities_are_compatible(paff, nc.affinities)) {
@@ -441,12 +458,11 @@ __global__ __launch_bounds__(G2P_THREADS) void k_g2p_update(Dev d, int side) {
             Svd<D> sv;
             if constexpr (PLASTIC) {
                 float dp[6], st[3], phase, max_stretch;
-#pragma unroll
-                for (int k = 0; k < 6; k++) dp[k] = in[(size_t)(P::DP + k) * npad + src];
-#pragma unroll
-                for (int k = 0; k < 3; k++) st[k] = in[(size_t)(P::DPS + k) * npad + src];
-                phase = in[(size_t)P::PHASE * npad + src];
-                max_stretch = in[(size_t)(P::PHASE + 1) * npad + src];
+                {
+                    const float4 d0 = ldq(in, npad, P::DP0, src), d1 = ldq(in, npad, P::DP1, src), d2 = ldq(in, npad, P::DP2, src);
+                    dp[0] = d0.x; dp[1] = d0.y; dp[2] = d0.z; dp[3] = d0.w; dp[4] = d1.x; dp[5] = d1.y;
+                    st[0] = d1.z; st[1] = d1.w; st[2] = d2.x; phase = d2.y; max_stretch = d2.z;
+                }
                 if (phase > 0.f && max_stretch > 0.f) {  // particle_update.wgsl:98-116
                     svd<D>(Fm, sv);
                     have_svd = true;
@@ -460,12 +476,9 @@ __global__ __launch_bounds__(G2P_THREADS) void k_g2p_update(Dev d, int side) {
                     have_svd = true;
                     drucker_prager_project<D>(dp, st, Fm, sv);  // sv.s follows the projected F
                 }
-#pragma unroll
-                for (int k = 0; k < 6; k++) out[(size_t)(P::DP + k) * npad + j] = dp[k];
-#pragma unroll
-                for (int k = 0; k < 3; k++) out[(size_t)(P::DPS + k) * npad + j] = st[k];
-                out[(size_t)P::PHASE * npad + j] = phase;
-                out[(size_t)(P::PHASE + 1) * npad + j] = max_stretch;
+                stq(out, npad, P::DP0, j, make_float4(dp[0], dp[1], dp[2], dp[3]));
+                stq(out, npad, P::DP1, j, make_float4(dp[4], dp[5], st[0], st[1]));
+                stq(out, npad, P::DP2, j, make_float4(st[2], phase, max_stretch, 0.f));
             }
             if constexpr (MODEL == 1) {
                 kirchoff_neo_hookean<D>(lambda, mu, Fm, tau);
@@ -475,29 +488,32 @@ __global__ __launch_bounds__(G2P_THREADS) void k_g2p_update(Dev d, int side) {
             }
             // particle_update.wgsl:129-132: C' = grad * m - tau * (V0 * inv_d * dt)
             const float coeff = vol0 * invd * dt;
+            float Cn[DD];
 #pragma unroll
-            for (int k = 0; k < D; k++) {
-                out[(size_t)(P::POS + k) * npad + j] = xn[k];
-                out[(size_t)(P::VEL + k) * npad + j] = vel[k];
+            for (int k = 0; k < DD; k++) Cn[k] = grad[k] * mass - tau[k] * coeff;
+            if constexpr (D == 3) {
+                stq(out, npad, P::XM, j, make_float4(xn[0], xn[1], xn[2], mass));
+                stq(out, npad, P::CV0, j, make_float4(Cn[0], Cn[1], Cn[2], Cn[3]));
+                stq(out, npad, P::CV1, j, make_float4(Cn[4], Cn[5], Cn[6], Cn[7]));
+                stq(out, npad, P::CV2, j, make_float4(Cn[8], vel[0], vel[1], vel[2]));
+                stq(out, npad, P::F0, j, make_float4(Fm[0], Fm[1], Fm[2], Fm[3]));
+                stq(out, npad, P::F1, j, make_float4(Fm[4], Fm[5], Fm[6], Fm[7]));
+                stq(out, npad, P::F2, j, make_float4(Fm[8], vol0, lambda, mu));
+            } else {
+                stq(out, npad, P::XM, j, make_float4(xn[0], xn[1], mass, vol0));
+                stq(out, npad, P::CV0, j, make_float4(Cn[0], Cn[1], Cn[2], Cn[3]));
+                stq(out, npad, P::CV2, j, make_float4(vel[0], vel[1], lambda, mu));
+                stq(out, npad, P::F0, j, make_float4(Fm[0], Fm[1], Fm[2], Fm[3]));
             }
-#pragma unroll
-            for (int k = 0; k < DD; k++) {
-                out[(size_t)(P::F + k) * npad + j] = Fm[k];
-                out[(size_t)(P::C + k) * npad + j] = grad[k] * mass - tau[k] * coeff;
-            }
-            out[(size_t)P::MASS * npad + j] = mass;
-            out[(size_t)P::VOL * npad + j] = vol0;
-            out[(size_t)P::LAM * npad + j] = lambda;
-            out[(size_t)P::MU * npad + j] = mu;
-            out[(size_t)P::PID * npad + j] = pidf;
+            stpid<D>(out, npad, j, pid);
             if constexpr (CPIC) {
-#pragma unroll
-                for (int k = 0; k < D; k++) {
-                    out[(size_t)(P::NRM + k) * npad + j] = nrm[k];
-                    out[(size_t)(P::RVEL + k) * npad + j] = rvel[k];
+                if constexpr (D == 3) {
+                    stq(out, npad, P::CDF0, j, make_float4(nrm[0], nrm[1], nrm[2], sdist));
+                    stq(out, npad, P::CDF1, j, make_float4(rvel[0], rvel[1], rvel[2], __uint_as_float(paff)));
+                } else {
+                    stq(out, npad, P::CDF0, j, make_float4(nrm[0], nrm[1], sdist, __uint_as_float(paff)));
+                    stq(out, npad, P::CDF1, j, make_float4(rvel[0], rvel[1], 0.f, 0.f));
                 }
-                out[(size_t)P::DIST * npad + j] = sdist;
-                out[(size_t)P::AFF * npad + j] = __uint_as_float(paff);
             }
         }
     }

@@ -26,30 +26,44 @@ template <> struct Dim<2> {
     static constexpr int BW = 8, BSHIFT = 3, TW = 10, TILE = 100, NBH = 9, DD = 4, NNBR = 4, ANG = 1;
 };
 
-// Plane indices of a particle buffer.
-template <int D> struct Pl {
-    static constexpr int DD = D * D;
-    static constexpr int POS = 0;
-    static constexpr int VEL = POS + D;
-    static constexpr int F = VEL + D;
-    static constexpr int C = F + DD;        // APIC matrix C' (affine), particle3d.wgsl:12
-    static constexpr int MASS = C + DD;
-    static constexpr int VOL = MASS + 1;    // init_volume
-    static constexpr int LAM = VOL + 1;
-    static constexpr int MU = LAM + 1;
-    static constexpr int PID = MU + 1;      // persistent particle id (caller's index), u32 bits
-    static constexpr int NBASE = PID + 1;
-    // Plasticity / phase group (models/drucker_prager.wgsl:8-23, particle_update.wgsl:40-43)
-    static constexpr int DP = NBASE;        // h0,h1,h2,h3,lambda,mu
-    static constexpr int DPS = DP + 6;      // plastic det, hardening, log_vol_gain
-    static constexpr int PHASE = DPS + 3;   // phase, max_stretch
-    // CDF group (particle3d.wgsl:17-25)
-    static constexpr int NRM = PHASE + 2;
-    static constexpr int RVEL = NRM + D;
-    static constexpr int DIST = RVEL + D;
-    static constexpr int AFF = DIST + 1;    // u32 bits
-    static constexpr int COUNT = AFF + 1;
+// Particle buffer = structure of float4 arrays ("quads") + one u32 plane.
+// Quad q of a buffer starts at base + q * npad float4; every access is a 16-byte-per-lane
+// global_load/store_dwordx4 (coalescing sweet spot, and whole 16-byte sectors are used
+// when the read goes through the sort permutation). Quads are grouped by consumer:
+//   P2G reads XM + CV*            (64 B/particle in 3D = the algorithmic minimum)
+//   fused G2P+update reads XM + F* + pid, writes everything.
+template <int D> struct Pl;
+template <> struct Pl<3> {
+    static constexpr int XM = 0;    // x, y, z, mass
+    static constexpr int CV0 = 1;   // C'[0..3]           (APIC matrix, column-major; particle3d.wgsl:12)
+    static constexpr int CV1 = 2;   // C'[4..7]
+    static constexpr int CV2 = 3;   // C'[8], vx, vy, vz
+    static constexpr int F0 = 4;    // F[0..3]
+    static constexpr int F1 = 5;    // F[4..7]
+    static constexpr int F2 = 6;    // F[8], init_volume, lambda, mu
+    static constexpr int NBASE = 7;
+    static constexpr int DP0 = 7;   // h0, h1, h2, h3                    (models/drucker_prager.wgsl:8-16)
+    static constexpr int DP1 = 8;   // dp.lambda, dp.mu, plastic det, plastic hardening
+    static constexpr int DP2 = 9;   // log_vol_gain, phase, max_stretch, -
+    static constexpr int CDF0 = 10; // normal xyz, signed_distance      (particle3d.wgsl:17-25)
+    static constexpr int CDF1 = 11; // rigid_vel xyz, affinity (u32 bits)
+    static constexpr int NQ = 12;
 };
+template <> struct Pl<2> {
+    static constexpr int XM = 0;    // x, y, mass, init_volume
+    static constexpr int CV0 = 1;   // C'[0..3]
+    static constexpr int CV2 = 2;   // vx, vy, lambda, mu
+    static constexpr int F0 = 3;    // F[0..3]
+    static constexpr int NBASE = 4;
+    static constexpr int DP0 = 4;
+    static constexpr int DP1 = 5;
+    static constexpr int DP2 = 6;
+    static constexpr int CDF0 = 7;  // normal xy, signed_distance, affinity
+    static constexpr int CDF1 = 8;  // rigid_vel xy, -, -
+    static constexpr int NQ = 9;
+};
+// floats per particle slot of one buffer (NQ quads + the pid plane)
+template <int D> constexpr size_t buffer_floats(uint32_t npad) { return ((size_t)Pl<D>::NQ * 4 + 1) * npad; }
 
 struct SimParamsDev {   // solver/params.wgsl:3-10 + grid.cell_width; lives in HBM so graph replays see updates
     float gravity[3];
@@ -88,7 +102,8 @@ struct Dev {
     uint32_t *rank;      // per particle: position inside its cell (arrival order; canonicalised later)
     // sparse block grid (grid.wgsl:82-184): open-addressing hash of packed block keys
     uint32_t *hkeys;     // hcap: packed key or NONE
-    uint32_t *hvals;     // hcap: dense block id
+    uint32_t *hvals;     // hcap: dense block id (valid for slots stamped with the current epoch)
+    uint32_t *hstamp;    // hcap: epoch of the last substep that touched the slot's block
     uint32_t hmask;      // hcap - 1
     uint32_t cap;        // block capacity
     uint32_t *block_key;   // cap: packed virtual id
@@ -110,8 +125,28 @@ struct Dev {
     float h;             // cell width
     float inv_h;
     int model;           // WGS_MODEL_*
+    uint32_t dbg;        // debug/ablation switches (env WGS_DEBUG), 0 in production
 };
 
-__host__ __device__ inline float *plane(float *base, uint32_t npad, int p) { return base + (size_t)p * npad; }
+// Quad access = (one uniform 64-bit buffer base in SGPRs) + (32-bit per-lane byte offset):
+// `global_load_dwordx4 v[..], v_off, s[base:base+1]`. Valid while one ping-pong buffer is
+// < 4 GiB (checked in wgs_data_create).
+__device__ inline float4 ldq(const float *base, uint32_t npad, int q, uint32_t i) {
+    const uint32_t off = ((uint32_t)q * npad + i) * 16u;
+    return *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(base) + off);
+}
+__device__ inline void stq(float *base, uint32_t npad, int q, uint32_t i, float4 v) {
+    const uint32_t off = ((uint32_t)q * npad + i) * 16u;
+    *reinterpret_cast<float4 *>(reinterpret_cast<char *>(base) + off) = v;
+}
+// persistent particle id (the caller's index) lives after the quads
+template <int D> __device__ inline uint32_t ldpid(const float *base, uint32_t npad, uint32_t i) {
+    const uint32_t off = ((uint32_t)Pl<D>::NQ * 4u * npad + i) * 4u;
+    return *reinterpret_cast<const uint32_t *>(reinterpret_cast<const char *>(base) + off);
+}
+template <int D> __device__ inline void stpid(float *base, uint32_t npad, uint32_t i, uint32_t pid) {
+    const uint32_t off = ((uint32_t)Pl<D>::NQ * 4u * npad + i) * 4u;
+    *reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(base) + off) = pid;
+}
 
 }  // namespace wgs
