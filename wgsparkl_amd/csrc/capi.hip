@@ -328,9 +328,9 @@ template <bool TS> wgs_status enqueue_substep(wgs_data *d, int ts_slot) {
     if (n > 0) {
         // ---- "p2g"
         if (d->cpic)
-            hipLaunchKernelGGL((k_p2g<D, true>), dim3(grid_for(d, 2)), dim3(P2GCfg<D>::THREADS), 0, s, dev, side);
+            hipLaunchKernelGGL((k_p2g<D, true>), dim3(grid_for(d, 5)), dim3(P2GCfg<D>::NW * 64), 0, s, dev, side);
         else
-            hipLaunchKernelGGL((k_p2g<D, false>), dim3(grid_for(d, 2)), dim3(P2GCfg<D>::THREADS), 0, s, dev, side);
+            hipLaunchKernelGGL((k_p2g<D, false>), dim3(grid_for(d, 5)), dim3(P2GCfg<D>::NW * 64), 0, s, dev, side);
         mark(4);
         // ---- "grid_update"
         hipLaunchKernelGGL(k_grid_update<D>, dim3(grid_for(d, 4)), dim3(256), 0, s, dev);

@@ -2,13 +2,10 @@
 //
 // P2G (reference: solver/p2g.wgsl:69-236, a per-node gather over linked lists of
 // 8 blocks with ~3.4x redundant particle fetches) is re-expressed as a per-block
-// SCATTER with no atomics and a fixed summation order:
-//   1. a workgroup owns one block; its particles (contiguous, cell-sorted) are
-//      staged once into LDS as 64-byte records (coalesced HBM reads);
-//   2. thread (cell, sy, sz) walks the particles of its cell in order and keeps
-//      the three sx contributions in registers;
-//   3. the 64 x 27 partials are reduced per tile node in a fixed order and the
-//      (BW+2)^D tile is written with plain coalesced stores to the block's slab.
+// SCATTER with no atomics and a fixed summation order: a workgroup owns one block,
+// every thread accumulates in registers over the (cell-sorted) particles of its own
+// cell, and the (BW+2)^D tile (block + "+1" rim) is written with plain coalesced
+// stores to the block's slab.
 // The grid update then gathers, for every node, the (at most 2^D) slabs that
 // cover it, in a fixed order, and applies grid_update.wgsl:55-64 in the same
 // pass (the reference keeps P2G and grid update apart only because of WebGPU's
@@ -19,187 +16,206 @@
 namespace wgs {
 
 // ------------------------------------------------------------------- P2G
+// Work decomposition (3D): workgroup = one block, 3 waves; lane = cell of the block (64),
+// wave = z-offset sz of the target node. A thread walks the particles of ITS cell in
+// canonical order and accumulates the 9 (sx, sy) contributions for its sz in registers:
+// no cross-lane traffic, no atomics, a fixed summation order.
+// Particles are staged through LDS in rounds of P2G_J ranks per cell, transposed to
+// [rank][cell] so that the 64 lanes of a wave read 64 consecutive float4 (conflict-free
+// ds_read_b128) while the global side reads whole 64-byte runs of the cell-sorted arrays.
+constexpr int P2G_J = 4;
 template <int D> struct P2GCfg;
 template <> struct P2GCfg<3> {
-    static constexpr int TPC = 9;            // threads per cell: (sy, sz)
-    static constexpr int THREADS = 64 * 9;   // 576 = 9 waves
-    static constexpr int REC4 = 4;           // float4 per staged particle: x,m | mv,c0 | c1..c4 | c5..c8
-    static constexpr int CHUNK = 512;        // particles staged per pass (32 KiB)
+    static constexpr int NW = 3;        // waves per workgroup = sz values
+    static constexpr int NSXY = 9;      // (sx, sy) pairs per thread
+    static constexpr int NQ = 4;        // staged quads per particle: XM, CV0, CV1, CV2
 };
 template <> struct P2GCfg<2> {
-    static constexpr int TPC = 3;            // (sy)
-    static constexpr int THREADS = 64 * 3;   // 192 = 3 waves
-    static constexpr int REC4 = 3;           // x,y,m,0 | mvx,mvy,c0,c1 | c2,c3,0,0
-    static constexpr int CHUNK = 512;
+    static constexpr int NW = 1;
+    static constexpr int NSXY = 9;      // (sx, sy): the whole 3x3 stencil in one wave
+    static constexpr int NQ = 3;        // XM, CV0, CV2
 };
 
 template <int D, bool CPIC>
-__global__ __launch_bounds__(P2GCfg<D>::THREADS) void k_p2g(Dev d, int side) {
+__global__ __launch_bounds__(P2GCfg<D>::NW * 64) void k_p2g(Dev d, int side) {
     using Cfg = P2GCfg<D>;
-    constexpr int BW = Dim<D>::BW, BS = Dim<D>::BSHIFT, TW = Dim<D>::TW, TILE = Dim<D>::TILE, NBH = Dim<D>::NBH;
-    constexpr int DD = D * D;
-    __shared__ float4 s_rec[Cfg::CHUNK * Cfg::REC4];
-    __shared__ uint32_t s_aff[CPIC ? Cfg::CHUNK : 1];
-    __shared__ float4 s_partial[NPB * NBH];
+    constexpr int BW = Dim<D>::BW, BS = Dim<D>::BSHIFT, TW = Dim<D>::TW, TILE = Dim<D>::TILE;
+    constexpr int NT = Cfg::NW * 64;
+    constexpr int SLOTS = P2G_J * NPB;
+    __shared__ float4 s_q[Cfg::NQ][SLOTS];
+    __shared__ uint32_t s_aff[CPIC ? SLOTS : 1];
+    __shared__ float4 s_tile[Cfg::NW][TILE];
+    __shared__ uint32_t s_cs[NPB], s_cn[NPB];
 
     const float *in = d.buf[side];
     const uint32_t npad = d.npad;
     const float h = d.h, inv_h = d.inv_h;
     const int tid = threadIdx.x;
-    const int cell = tid / Cfg::TPC, sub = tid % Cfg::TPC;
-    const int sy = sub % 3, sz = sub / 3;
+    const int cell = tid & 63;
+    const int sz = D == 3 ? (tid >> 6) : 0;  // wave-uniform
     int lc[3];
     lc[0] = cell & (BW - 1);
     lc[1] = (cell >> BS) & (BW - 1);
     lc[2] = D == 3 ? (cell >> (2 * BS)) : 0;
+    const int tnode0 = lc[0] + TW * lc[1] + (D == 3 ? TW * TW * (lc[2] + sz) : 0);  // tile node of (sx,sy) = (0,0)
 
     const uint32_t B = min(d.counters[CTR_NBLOCKS], d.cap);
     for (uint32_t b = blockIdx.x; b < B; b += gridDim.x) {
         const uint32_t cnt = d.block_count[b];
         if (cnt == 0) continue;  // no particles: its slab is never read
-        const uint32_t start = d.block_start[b];
         int bc[3] = {0, 0, 0};
         unpack_key<D>(d.block_key[b], bc);
-        // world position of this thread's cell (= associated grid node of its particles)
+        const uint32_t cs = d.cell_start[b * NPB + cell];
+        const uint32_t cn = d.cell_cursor[b * NPB + cell] - cs;
+        __syncthreads();  // previous block fully consumed
+        if (tid < NPB) {
+            s_cs[cell] = cs;
+            s_cn[cell] = cn;
+        }
+        for (int n = cell; n < TILE; n += 64) s_tile[sz][n] = make_float4(0.f, 0.f, 0.f, 0.f);
+        uint32_t maxc = cn;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) maxc = max(maxc, (uint32_t)__shfl_xor((int)maxc, off));
         float cpos[D];
 #pragma unroll
         for (int k = 0; k < D; k++) cpos[k] = (float)(bc[k] * BW + lc[k]) * h;
-        const uint32_t cs = d.cell_start[b * NPB + cell];
-        const uint32_t ce = cell < NPB - 1 ? d.cell_start[b * NPB + cell + 1] : start + cnt;
-        // CPIC: affinities of this thread's three target nodes (p2g.wgsl:100-103)
-        uint32_t naff[3] = {0u, 0u, 0u};
-        if constexpr (CPIC) {
+        uint32_t naff[Cfg::NSXY];
+        if constexpr (CPIC) {  // affinities of this thread's nine target nodes (p2g.wgsl:100-103)
 #pragma unroll
-            for (int s = 0; s < 3; s++) {
-                int t[3] = {lc[0] + s, lc[1] + sy, lc[2] + sz};
+            for (int s = 0; s < 9; s++) {
+                int t[3] = {lc[0] + s % 3, lc[1] + s / 3, lc[2] + sz};
                 int o = (t[0] >= BW ? 1 : 0) | (t[1] >= BW ? 2 : 0) | (t[2] >= BW ? 4 : 0);
                 int ln = (t[0] & (BW - 1)) + ((t[1] & (BW - 1)) << BS) + (D == 3 ? ((t[2] & (BW - 1)) << (2 * BS)) : 0);
                 uint32_t nb = d.nbr_plus[b * 8u + o];
-                if (nb != NONE) naff[s] = d.node_cdf[(size_t)nb * NPB + ln].affinities;
+                naff[s] = nb != NONE ? d.node_cdf[(size_t)nb * NPB + ln].affinities : 0u;
             }
         }
-
-        float acc[3][D + 1];
+        float acc[Cfg::NSXY][D + 1];
 #pragma unroll
-        for (int s = 0; s < 3; s++)
+        for (int s = 0; s < 9; s++)
 #pragma unroll
             for (int k = 0; k <= D; k++) acc[s][k] = 0.f;
 
-        for (uint32_t base = start; base < start + cnt; base += Cfg::CHUNK) {
-            const uint32_t m = min((uint32_t)Cfg::CHUNK, start + cnt - base);
-            __syncthreads();
-            for (uint32_t j = tid; j < m; j += Cfg::THREADS) {
-                const uint32_t src = d.perm[base + j];
-                if constexpr (D == 3) {
-                    const float4 xm = ldq(in, npad, Pl<3>::XM, src);
-                    const float4 c0 = ldq(in, npad, Pl<3>::CV0, src);
-                    const float4 c1 = ldq(in, npad, Pl<3>::CV1, src);
-                    const float4 c2 = ldq(in, npad, Pl<3>::CV2, src);
-                    s_rec[j * 4 + 0] = xm;
-                    s_rec[j * 4 + 1] = make_float4(c2.y * xm.w, c2.z * xm.w, c2.w * xm.w, c0.x);  // m v, c0
-                    s_rec[j * 4 + 2] = make_float4(c0.y, c0.z, c0.w, c1.x);
-                    s_rec[j * 4 + 3] = make_float4(c1.y, c1.z, c1.w, c2.x);
-                } else {
-                    const float4 xm = ldq(in, npad, Pl<2>::XM, src);   // x, y, m, V0
-                    const float4 c0 = ldq(in, npad, Pl<2>::CV0, src);
-                    const float4 vl = ldq(in, npad, Pl<2>::CV2, src);  // vx, vy, lambda, mu
-                    s_rec[j * 3 + 0] = make_float4(xm.x, xm.y, xm.z, 0.f);
-                    s_rec[j * 3 + 1] = make_float4(vl.x * xm.z, vl.y * xm.z, c0.x, c0.y);
-                    s_rec[j * 3 + 2] = make_float4(c0.z, c0.w, 0.f, 0.f);
-                }
-                if constexpr (CPIC) {
-                    const float4 cd = ldq(in, npad, D == 3 ? (int)Pl<D>::CDF1 : (int)Pl<D>::CDF0, src);
-                    s_aff[j] = __float_as_uint(cd.w);
+        for (uint32_t r0 = 0; r0 < maxc; r0 += P2G_J) {
+            __syncthreads();  // s_cs/s_cn visible; previous round consumed
+            // stage ranks [r0, r0 + J) of every cell; thread -> (cell, j) with j fastest so that a
+            // cell's J particles are one contiguous 64-byte run of each quad
+            for (int sl = tid; sl < SLOTS; sl += NT) {
+                const int c = sl / P2G_J, j = sl % P2G_J;
+                const uint32_t rank = r0 + j;
+                if (rank < s_cn[c]) {
+                    const uint32_t src = d.perm[s_cs[c] + rank];
+                    const int dst = j * NPB + c;
+                    if constexpr (D == 3) {
+                        const float4 xm = ldq(in, npad, Pl<3>::XM, src);
+                        const float4 c0 = ldq(in, npad, Pl<3>::CV0, src);
+                        const float4 c1 = ldq(in, npad, Pl<3>::CV1, src);
+                        float4 c2 = ldq(in, npad, Pl<3>::CV2, src);
+                        c2.y *= xm.w; c2.z *= xm.w; c2.w *= xm.w;  // momentum m v
+                        s_q[0][dst] = xm; s_q[1][dst] = c0; s_q[2][dst] = c1; s_q[3][dst] = c2;
+                    } else {
+                        const float4 xm = ldq(in, npad, Pl<2>::XM, src);   // x, y, m, V0
+                        const float4 c0 = ldq(in, npad, Pl<2>::CV0, src);
+                        float4 vl = ldq(in, npad, Pl<2>::CV2, src);        // vx, vy, lambda, mu
+                        vl.x *= xm.z; vl.y *= xm.z;
+                        s_q[0][dst] = xm; s_q[1][dst] = c0; s_q[2][dst] = vl;
+                    }
+                    if constexpr (CPIC) {
+                        const float4 cd = ldq(in, npad, D == 3 ? (int)Pl<D>::CDF1 : (int)Pl<D>::CDF0, src);
+                        s_aff[dst] = __float_as_uint(cd.w);
+                    }
                 }
             }
             __syncthreads();
-            const uint32_t lo = max(cs, base), hi = min(ce, base + m);
-            for (uint32_t j = lo; j < hi; j++) {
-                const uint32_t r = j - base;
-                float x[D], mv[D], c[DD], mass;
+            const uint32_t jn = cn > r0 ? min((uint32_t)P2G_J, cn - r0) : 0u;
+            for (uint32_t j = 0; j < jn; j++) {
+                const int sl = j * NPB + cell;
+                float x[D], mv[D], c[D * D], mass;
                 if constexpr (D == 3) {
-                    float4 r0 = s_rec[r * 4 + 0], r1 = s_rec[r * 4 + 1], r2 = s_rec[r * 4 + 2], r3 = s_rec[r * 4 + 3];
-                    x[0] = r0.x; x[1] = r0.y; x[2] = r0.z; mass = r0.w;
-                    mv[0] = r1.x; mv[1] = r1.y; mv[2] = r1.z;
-                    c[0] = r1.w; c[1] = r2.x; c[2] = r2.y; c[3] = r2.z; c[4] = r2.w;
-                    c[5] = r3.x; c[6] = r3.y; c[7] = r3.z; c[8] = r3.w;
+                    const float4 xm = s_q[0][sl], c0 = s_q[1][sl], c1 = s_q[2][sl], c2 = s_q[3][sl];
+                    x[0] = xm.x; x[1] = xm.y; x[2] = xm.z; mass = xm.w;
+                    c[0] = c0.x; c[1] = c0.y; c[2] = c0.z; c[3] = c0.w;
+                    c[4] = c1.x; c[5] = c1.y; c[6] = c1.z; c[7] = c1.w; c[8] = c2.x;
+                    mv[0] = c2.y; mv[1] = c2.z; mv[2] = c2.w;
                 } else {
-                    float4 r0 = s_rec[r * 3 + 0], r1 = s_rec[r * 3 + 1], r2 = s_rec[r * 3 + 2];
-                    x[0] = r0.x; x[1] = r0.y; mass = r0.z;
-                    mv[0] = r1.x; mv[1] = r1.y;
-                    c[0] = r1.z; c[1] = r1.w; c[2] = r2.x; c[3] = r2.y;
+                    const float4 xm = s_q[0][sl], c0 = s_q[1][sl], vl = s_q[2][sl];
+                    x[0] = xm.x; x[1] = xm.y; mass = xm.z;
+                    c[0] = c0.x; c[1] = c0.y; c[2] = c0.z; c[3] = c0.w;
+                    mv[0] = vl.x; mv[1] = vl.y;
                 }
+                uint32_t paff = 0u;
+                if constexpr (CPIC) paff = s_aff[sl];
                 // p2g.wgsl:176-198: ref = assoc_node - x ; w = eval_all(-ref / h) ; dpt = ref + shift * h
-                float ref[D], wx[3], wy[3], wz[3];
+                float ref[D], wx[3], wy[3];
 #pragma unroll
                 for (int k = 0; k < D; k++) ref[k] = cpos[k] - x[k];
                 eval_all(-ref[0] * inv_h, wx);
                 eval_all(-ref[1] * inv_h, wy);
-                float wyz = wy[sy];
-                float dy = ref[1] + (float)sy * h;
-                float part[D];  // C[:,1..] * dpt[1..] + m v
+                float wzs = 1.f;
+                float base[D];  // C[:, 2] * dz + m v
                 if constexpr (D == 3) {
+                    float wz[3];
                     eval_all(-ref[2] * inv_h, wz);
-                    wyz *= wz[sz];
-                    float dz = ref[2] + (float)sz * h;
+                    wzs = sz == 0 ? wz[0] : (sz == 1 ? wz[1] : wz[2]);
+                    const float dz = ref[2] + (float)sz * h;
 #pragma unroll
-                    for (int k = 0; k < 3; k++) part[k] = c[3 + k] * dy + c[6 + k] * dz + mv[k];
+                    for (int k = 0; k < 3; k++) base[k] = c[6 + k] * dz + mv[k];
                 } else {
 #pragma unroll
-                    for (int k = 0; k < 2; k++) part[k] = c[2 + k] * dy + mv[k];
+                    for (int k = 0; k < 2; k++) base[k] = mv[k];
                 }
-                uint32_t paff = 0u;
-                if constexpr (CPIC) paff = s_aff[r];
 #pragma unroll
-                for (int s = 0; s < 3; s++) {
-                    if constexpr (CPIC) {
-                        // p2g.wgsl:200-228: incompatible pairs transfer nothing to the grid (their
-                        // momentum goes to the rigid body as an impulse: two-way coupling)
-                        if (!affinities_are_compatible(naff[s], paff)) continue;
+                for (int sy = 0; sy < 3; sy++) {
+                    const float dy = ref[1] + (float)sy * h;
+                    const float wyz = wy[sy] * wzs;
+                    float py[D];
+#pragma unroll
+                    for (int k = 0; k < D; k++) py[k] = c[D + k] * dy + base[k];
+#pragma unroll
+                    for (int sx = 0; sx < 3; sx++) {
+                        const int s = sx + 3 * sy;
+                        if constexpr (CPIC) {
+                            // p2g.wgsl:200-228: incompatible pairs transfer nothing to the grid (their momentum
+                            // becomes an impulse on the rigid body: two-way coupling)
+                            if (!affinities_are_compatible(naff[s], paff)) continue;
+                        }
+                        const float dx = ref[0] + (float)sx * h;
+                        const float w = wx[sx] * wyz;
+#pragma unroll
+                        for (int k = 0; k < D; k++) acc[s][k] += (c[k] * dx + py[k]) * w;
+                        acc[s][D] += mass * w;
                     }
-                    const float w = wx[s] * wyz;
-                    const float dx = ref[0] + (float)s * h;
-#pragma unroll
-                    for (int k = 0; k < D; k++) acc[s][k] += (c[k] * dx + part[k]) * w;
-                    acc[s][D] += mass * w;
                 }
             }
         }
-        // partials: [cell][sx + 3 sy + 9 sz]
+        // Per-wave tile: in phase (sx, sy) every lane (cell) owns a distinct node, so a plain
+        // read-add-write is race-free inside the wave; phases run in program order. The accesses
+        // are (relaxed, wavefront-scope) atomics only to stop the compiler from forwarding a
+        // lane's own stores past another lane's update.
+        {
+            float *tile = reinterpret_cast<float *>(&s_tile[sz][0]);
 #pragma unroll
-        for (int s = 0; s < 3; s++) {
-            float4 o;
-            if constexpr (D == 3) o = make_float4(acc[s][0], acc[s][1], acc[s][2], acc[s][3]);
-            else o = make_float4(acc[s][0], acc[s][1], acc[s][2], 0.f);
-            s_partial[cell * NBH + s + 3 * sub] = o;
+            for (int s = 0; s < 9; s++) {
+                const int node = tnode0 + (s % 3) + TW * (s / 3);
+#pragma unroll
+                for (int k = 0; k <= D; k++) {
+                    float *p = &tile[node * 4 + k];
+                    float old = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                    __hip_atomic_store(p, old + acc[s][k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                }
+            }
         }
         __syncthreads();
-        // ordered reduction per tile node, then one coalesced slab store
-        for (int n = tid; n < TILE; n += Cfg::THREADS) {
-            int t[3];
-            t[0] = n % TW;
-            t[1] = (n / TW) % TW;
-            t[2] = D == 3 ? n / (TW * TW) : 0;
-            float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
-            constexpr int SZN = D == 3 ? 3 : 1;
-            for (int z = 0; z < SZN; z++) {
-                int cz = t[2] - z;
-                if (D == 3 && (cz < 0 || cz >= BW)) continue;
-                for (int y = 0; y < 3; y++) {
-                    int cy = t[1] - y;
-                    if (cy < 0 || cy >= BW) continue;
-                    for (int xx = 0; xx < 3; xx++) {
-                        int cx = t[0] - xx;
-                        if (cx < 0 || cx >= BW) continue;
-                        int c = cx + (cy << BS) + (D == 3 ? (cz << (2 * BS)) : 0);
-                        float4 p = s_partial[c * NBH + xx + 3 * y + 9 * z];
-                        sum.x += p.x; sum.y += p.y; sum.z += p.z; sum.w += p.w;
-                    }
-                }
+        // combine the sz tiles in a fixed order; one coalesced slab store per node
+        for (int n = tid; n < TILE; n += NT) {
+            float4 sum = s_tile[0][n];
+#pragma unroll
+            for (int w = 1; w < Cfg::NW; w++) {
+                const float4 p = s_tile[w][n];
+                sum.x += p.x; sum.y += p.y; sum.z += p.z; sum.w += p.w;
             }
             d.slab[(size_t)b * TILE + n] = sum;
         }
-        __syncthreads();
     }
 }
 
