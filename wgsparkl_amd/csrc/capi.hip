@@ -221,18 +221,19 @@ __global__ void k_export_grid(Dev d, uint32_t nblocks, bool cpic, wgs_node_recor
     constexpr int BW = Dim<D>::BW, BS = Dim<D>::BSHIFT;
     const uint32_t total = nblocks * NPB;
     for (uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; t < total; t += gridDim.x * blockDim.x) {
-        const uint32_t b = t >> 6, ln = t & 63u;
+        const uint32_t b = d.active[t >> 6], ln = t & 63u;
+        const uint32_t node = b * NPB + ln;
         int bc[3] = {0, 0, 0};
         unpack_key<D>(d.block_key[b], bc);
         int l[3] = {(int)(ln & (BW - 1)), (int)((ln >> BS) & (BW - 1)), D == 3 ? (int)(ln >> (2 * BS)) : 0};
         wgs_node_record r;
         for (int k = 0; k < D; k++) r.cell[k] = bc[k] * BW + l[k];
-        float4 v = d.nodes[t];
+        float4 v = d.nodes[node];
         r.velocity[0] = v.x;
         r.velocity[1] = v.y;
         if (D == 3) { r.velocity[D - 1] = v.z; r.mass = v.w; } else { r.mass = v.z; }
         NodeCdf c = {0.f, 0u, NONE, 0u};
-        if (cpic) c = d.node_cdf[t];
+        if (cpic) c = d.node_cdf[node];
         r.cdf_distance = c.distance;
         r.cdf_affinities = c.affinities;
         r.cdf_closest_id = c.closest_id;
@@ -241,14 +242,15 @@ __global__ void k_export_grid(Dev d, uint32_t nblocks, bool cpic, wgs_node_recor
 }
 
 __global__ void k_export_blocks(Dev d, uint32_t nblocks, wgs_block_record *out) {
-    for (uint32_t b = blockIdx.x * blockDim.x + threadIdx.x; b < nblocks; b += gridDim.x * blockDim.x) {
+    for (uint32_t a = blockIdx.x * blockDim.x + threadIdx.x; a < nblocks; a += gridDim.x * blockDim.x) {
+        const uint32_t b = d.active[a];
         int bc[3] = {0, 0, 0};
         unpack_key<D>(d.block_key[b], bc);
         wgs_block_record r;
         for (int k = 0; k < D; k++) r.virtual_id[k] = bc[k];
         r.first_particle = d.block_start[b];
         r.num_particles = d.block_count[b];
-        out[b] = r;
+        out[a] = r;
     }
 }
 
@@ -301,15 +303,13 @@ template <bool TS> wgs_status enqueue_substep(wgs_data *d, int ts_slot) {
     const uint32_t epoch = (uint32_t)(d->substeps + 1);
     if (d->substeps % REHASH_PERIOD == 0) {  // reset_hmap, amortised (device_math.h)
         HIP_TRY(hipMemsetAsync(dev.hkeys, 0xff, sizeof(uint32_t) * ((size_t)dev.hmask + 1), s));
-        HIP_TRY(hipMemsetAsync(dev.hstamp, 0, sizeof(uint32_t) * ((size_t)dev.hmask + 1), s));
+        HIP_TRY(hipMemsetAsync(dev.hvals, 0xff, sizeof(uint32_t) * ((size_t)dev.hmask + 1), s));
+        HIP_TRY(hipMemsetAsync(dev.counters + CTR_NPHYS, 0, sizeof(uint32_t), s));
     }
     if (n > 0) {
-        hipLaunchKernelGGL(k_touch_blocks<D>, dim3(pgrid), dim3(SORT_THREADS), 0, s, dev, side, epoch);
-        hipLaunchKernelGGL(k_assign_block_ids, dim3(1), dim3(ASSIGN_THREADS), 0, s, dev, epoch);
-        hipLaunchKernelGGL(k_block_links<D>, dim3(grid_for(d, 4)), dim3(SORT_THREADS), 0, s, dev, epoch);
-        hipLaunchKernelGGL(k_count<D>, dim3(pgrid), dim3(SORT_THREADS), 0, s, dev, side, epoch);
-        hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(SCAN_THREADS), 0, s, dev);
-        hipLaunchKernelGGL(k_cell_offsets, dim3(grid_for(d, 4)), dim3(SORT_THREADS), 0, s, dev);
+        hipLaunchKernelGGL(k_bin<D>, dim3(pgrid), dim3(SORT_THREADS), 0, s, dev, side, epoch);
+        hipLaunchKernelGGL(k_scan_active, dim3(1), dim3(SCAN_THREADS), 0, s, dev, epoch);
+        hipLaunchKernelGGL(k_block_setup<D>, dim3(grid_for(d, 4)), dim3(SORT_THREADS), 0, s, dev, epoch);
         hipLaunchKernelGGL(k_scatter, dim3(pgrid), dim3(SORT_THREADS), 0, s, dev);
         if (d->deterministic)
             hipLaunchKernelGGL(k_canonical_order<D>, dim3(grid_for(d, 4)), dim3(SORT_THREADS), 0, s, dev, side);
@@ -442,9 +442,11 @@ wgs_status wgs_data_create(wgs_pipeline *pipeline, const wgs_sim_params *params,
     TRY_ALLOC(&dev.rank, (size_t)dev.npad);
     TRY_ALLOC(&dev.hkeys, (size_t)hcap);
     TRY_ALLOC(&dev.hvals, (size_t)hcap);
-    TRY_ALLOC(&dev.hstamp, (size_t)hcap);
     TRY_ALLOC(&dev.block_key, (size_t)dev.cap);
     TRY_ALLOC(&dev.block_count, (size_t)dev.cap);
+    TRY_ALLOC(&dev.block_stamp, (size_t)dev.cap);
+    TRY_ALLOC(&dev.block_acc, (size_t)dev.cap);
+    TRY_ALLOC(&dev.active, (size_t)dev.cap);
     TRY_ALLOC(&dev.block_start, (size_t)dev.cap);
     TRY_ALLOC(&dev.nbr_plus, (size_t)dev.cap * 8);
     TRY_ALLOC(&dev.nbr_minus, (size_t)dev.cap * 8);

@@ -51,19 +51,24 @@ __host__ __device__ inline uint32_t hash_key(uint32_t key) {
 __device__ inline int assoc_cell(float x, float h) { return (int)(__builtin_rintf(x / h) - 1.0f); }
 
 // The hash map is PERSISTENT across substeps (the reference rebuilds it every substep,
-// grid.wgsl:186-203 reset_hmap): blocks stay in the table and a per-slot epoch stamp says
-// whether a block is active in the current substep. Almost every touch is then a plain
-// L2-served lookup + an idempotent plain store; device-scope atomics (memory-side on
-// MI355X, ~1-2 us each and bandwidth-limited on a 32 KiB table) are only issued for blocks
-// never seen before. The table is cleared every REHASH_PERIOD substeps to drop stale blocks.
+// grid.wgsl:186-203 reset_hmap): blocks keep their slot and their physical id, and a
+// per-block epoch stamp says whether the block is active in the current substep. Almost
+// every touch is then a plain L2-served lookup + an idempotent plain store; device-scope
+// atomics (memory-side on MI355X, ~1-2 us each and bandwidth-limited on a small table)
+// are only issued for blocks never seen before. The table is cleared every REHASH_PERIOD
+// substeps to drop blocks that stopped being active.
 constexpr uint32_t REHASH_PERIOD = 64;
+constexpr uint32_t ID_OVERFLOW = 0xfffffffeu;
 
 // grid/grid.wgsl:167-184 find_block_header_id (active blocks only)
 __device__ inline uint32_t hmap_find(const Dev &d, uint32_t key, uint32_t epoch) {
     uint32_t slot = hash_key(key) & d.hmask;
     for (uint32_t probe = 0; probe <= d.hmask; ++probe) {
-        uint32_t st = d.hkeys[slot];
-        if (st == key) return d.hstamp[slot] == epoch ? d.hvals[slot] : NONE;
+        const uint32_t st = d.hkeys[slot];
+        if (st == key) {
+            const uint32_t id = d.hvals[slot];
+            return (id < d.cap && d.block_stamp[id] == epoch) ? id : NONE;
+        }
         if (st == NONE) return NONE;
         slot = (slot + 1u) & d.hmask;
     }
@@ -71,24 +76,49 @@ __device__ inline uint32_t hmap_find(const Dev &d, uint32_t key, uint32_t epoch)
 }
 
 // grid/grid.wgsl:121-164 insertion_index + :323-334 mark_block_as_active: make sure `key`
-// is in the table and stamp it active for `epoch`. Dense block ids are handed out afterwards
-// by k_assign_block_ids (a prefix sum over the table) instead of the reference's atomicAdd
-// on one counter (grid.wgsl:327): thousands of same-address atomics serialise at ~12 ns each.
-__device__ inline void activate_block(const Dev &d, uint32_t key, uint32_t epoch) {
+// is in the table, stamp its block active for `epoch` and return the block's physical id.
+__device__ inline uint32_t activate_block(const Dev &d, uint32_t key, uint32_t epoch) {
     uint32_t slot = hash_key(key) & d.hmask;
-    for (uint32_t probe = 0; probe <= d.hmask; ++probe) {
+    uint32_t result = NONE;
+    bool done = false;
+    for (uint32_t probe = 0; probe <= d.hmask && !done; ++probe) {
         uint32_t cur = d.hkeys[slot];  // plain load: a stale NONE only costs one extra CAS below
+        bool won = false;
         if (cur == NONE) {
             cur = atomicCAS(&d.hkeys[slot], NONE, key);
-            if (cur == NONE) cur = key;
+            won = cur == NONE;
+            if (won) cur = key;
+        }
+        // Winners first, in program order and WITHOUT leaving the divergent region: lanes of the
+        // same wave that lost the race for this very slot wait below for hvals, and would spin
+        // forever if the winner's branch were scheduled after their loop.
+        if (won) {  // slot claimed: hand out a physical id (rare: new block)
+            uint32_t id = atomicAdd(&d.counters[CTR_NPHYS], 1u);
+            if (id < d.cap) {
+                d.block_key[id] = key;
+            } else {
+                atomicOr(&d.counters[CTR_ERRORS], ERRBIT_OVERFLOW);
+                id = ID_OVERFLOW;
+            }
+            __hip_atomic_store(&d.hvals[slot], id, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         if (cur == key) {
-            d.hstamp[slot] = epoch;  // every writer stores the same value
-            return;
+            uint32_t id = d.hvals[slot];
+            // a thread of ANOTHER wave may still be between its CAS and its hvals store: bounded wait
+            for (int spin = 0; id == NONE && spin < (1 << 16); spin++) {
+                __builtin_amdgcn_s_sleep(1);
+                id = __hip_atomic_load(&d.hvals[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            if (id < d.cap) {
+                d.block_stamp[id] = epoch;  // every writer stores the same value
+                result = id;
+            }
+            done = true;
         }
         slot = (slot + 1u) & d.hmask;
     }
-    atomicOr(&d.counters[CTR_ERRORS], ERRBIT_OVERFLOW);
+    if (!done) atomicOr(&d.counters[CTR_ERRORS], ERRBIT_OVERFLOW);
+    return result;
 }
 
 // ------------------------------------------------------- quadratic B-spline

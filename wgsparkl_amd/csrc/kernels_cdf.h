@@ -127,7 +127,8 @@ template <int D> __global__ __launch_bounds__(256) void k_node_cdf(Dev d) {
     const uint32_t total = B * NPB;
     const float cap = d.h * 1.5f;
     for (uint32_t t = blockIdx.x * 256 + threadIdx.x; t < total; t += gridDim.x * 256) {
-        const uint32_t b = t >> 6, ln = t & 63u;
+        const uint32_t b = d.active[t >> 6], ln = t & 63u;
+        const uint32_t node = b * NPB + ln;
         int bc[3] = {0, 0, 0};
         unpack_key<D>(d.block_key[b], bc);
         int l[3] = {(int)(ln & (BW - 1)), (int)((ln >> BS) & (BW - 1)), D == 3 ? (int)(ln >> (2 * BS)) : 0};
@@ -156,7 +157,7 @@ template <int D> __global__ __launch_bounds__(256) void k_node_cdf(Dev d) {
                 cdf.affinities |= (inside ? 0x00010001u : 0x00000001u) << i;
             }
         }
-        d.node_cdf[t] = cdf;
+        d.node_cdf[node] = cdf;
         if (cdf.affinities != 0u) d.block_cdf_flag[b] = 1u;  // benign race: every writer stores 1
     }
 }
@@ -208,7 +209,8 @@ template <int D> __global__ __launch_bounds__(256) void k_particle_cdf(Dev d, in
     const float h = d.h, inv_h = d.inv_h;
     const int tid = threadIdx.x;
     const uint32_t B = min(d.counters[CTR_NBLOCKS], d.cap);
-    for (uint32_t b = blockIdx.x; b < B; b += gridDim.x) {
+    for (uint32_t a = blockIdx.x; a < B; a += gridDim.x) {
+        const uint32_t b = d.active[a];
         const uint32_t cnt = d.block_count[b];
         if (cnt == 0) continue;
         const uint32_t start = d.block_start[b];

@@ -60,7 +60,8 @@ __global__ __launch_bounds__(P2GCfg<D>::NW * 64) void k_p2g(Dev d, int side) {
     const int tnode0 = lc[0] + TW * lc[1] + (D == 3 ? TW * TW * (lc[2] + sz) : 0);  // tile node of (sx,sy) = (0,0)
 
     const uint32_t B = min(d.counters[CTR_NBLOCKS], d.cap);
-    for (uint32_t b = blockIdx.x; b < B; b += gridDim.x) {
+    for (uint32_t a = blockIdx.x; a < B; a += gridDim.x) {
+        const uint32_t b = d.active[a];
         const uint32_t cnt = d.block_count[b];
         if (cnt == 0) continue;  // no particles: its slab is never read
         int bc[3] = {0, 0, 0};
@@ -229,7 +230,8 @@ template <int D> __global__ __launch_bounds__(256) void k_grid_update(Dev d) {
     const float lim = d.h / dt;
     float g[3] = {d.sp->gravity[0], d.sp->gravity[1], d.sp->gravity[2]};
     for (uint32_t t = blockIdx.x * 256 + threadIdx.x; t < total; t += gridDim.x * 256) {
-        const uint32_t b = t >> 6, ln = t & 63u;
+        const uint32_t b = d.active[t >> 6], ln = t & 63u;
+        const uint32_t node = b * NPB + ln;
         int l[3];
         l[0] = ln & (BW - 1);
         l[1] = (ln >> BS) & (BW - 1);
@@ -255,7 +257,7 @@ template <int D> __global__ __launch_bounds__(256) void k_grid_update(Dev d) {
             float vel = (mom[k] + mass * g[k] * dt) * inv_mass;
             v[k] = fminf(fmaxf(vel, -lim), lim);
         }
-        d.nodes[t] = D == 3 ? make_float4(v[0], v[1], v[2], mass) : make_float4(v[0], v[1], mass, 0.f);
+        d.nodes[node] = D == 3 ? make_float4(v[0], v[1], v[2], mass) : make_float4(v[0], v[1], mass, 0.f);
     }
 }
 
@@ -287,7 +289,8 @@ __global__ __launch_bounds__(G2P_THREADS, G2P_WAVES_PER_EU) void k_g2p_update(De
     const int tid = threadIdx.x;
 
     const uint32_t B = min(d.counters[CTR_NBLOCKS], d.cap);
-    for (uint32_t b = blockIdx.x; b < B; b += gridDim.x) {
+    for (uint32_t a = blockIdx.x; a < B; a += gridDim.x) {
+        const uint32_t b = d.active[a];
         const uint32_t cnt = d.block_count[b];
         if (cnt == 0) continue;
         const uint32_t start = d.block_start[b];

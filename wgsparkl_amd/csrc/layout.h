@@ -89,7 +89,7 @@ struct NodeCdf {        // grid.wgsl:233-240
 };
 
 // Counter slots in Dev::counters
-enum { CTR_NBLOCKS = 0, CTR_ERRORS = 1, CTR_COUNT = 8 };
+enum { CTR_NBLOCKS = 0, CTR_ERRORS = 1, CTR_NPHYS = 2, CTR_COUNT = 8 };
 enum { ERRBIT_OVERFLOW = 1u, ERRBIT_KEYRANGE = 2u };
 
 // Everything a kernel needs, passed by value.
@@ -102,15 +102,18 @@ struct Dev {
     uint32_t *rank;      // per particle: position inside its cell (arrival order; canonicalised later)
     // sparse block grid (grid.wgsl:82-184): open-addressing hash of packed block keys
     uint32_t *hkeys;     // hcap: packed key or NONE
-    uint32_t *hvals;     // hcap: dense block id (valid for slots stamped with the current epoch)
-    uint32_t *hstamp;    // hcap: epoch of the last substep that touched the slot's block
+    uint32_t *hvals;     // hcap: physical block id of the slot's key (NONE while the insert is in flight)
     uint32_t hmask;      // hcap - 1
     uint32_t cap;        // block capacity
+    // per physical block id (ids persist while the block stays in the hash map)
     uint32_t *block_key;   // cap: packed virtual id
-    uint32_t *block_count; // cap: particles whose associated cell is in the block
-    uint32_t *block_start; // cap: exclusive scan of block_count (first_particle)
-    uint32_t *nbr_plus;    // cap*8: dense ids of b + {0,1}^D (always active)
-    uint32_t *nbr_minus;   // cap*8: dense ids of b - {0,1}^D or NONE
+    uint32_t *block_stamp; // cap: epoch of the last substep in which the block was active
+    uint32_t *block_acc;   // cap: particle counter being accumulated by k_bin (zero at rest)
+    uint32_t *block_count; // cap: particles whose associated cell is in the block (num_particles)
+    uint32_t *block_start; // cap: exclusive scan of block_count over the active list (first_particle)
+    uint32_t *active;      // cap: physical ids of the blocks active in this substep, [0, num_active_blocks)
+    uint32_t *nbr_plus;    // cap*8: physical ids of b + {0,1}^D (always active)
+    uint32_t *nbr_minus;   // cap*8: physical ids of b - {0,1}^D, NONE when inactive
     uint32_t *cell_count;  // cap*64 (zero outside the sort)
     uint32_t *cell_start;  // cap*64
     uint32_t *cell_cursor; // cap*64: end of the cell's range in perm
