@@ -310,9 +310,9 @@ template <bool TS> wgs_status enqueue_substep(wgs_data *d, int ts_slot) {
         hipLaunchKernelGGL(k_bin<D>, dim3(pgrid), dim3(SORT_THREADS), 0, s, dev, side, epoch);
         hipLaunchKernelGGL(k_scan_active, dim3(1), dim3(SCAN_THREADS), 0, s, dev, epoch);
         hipLaunchKernelGGL(k_block_setup<D>, dim3(grid_for(d, 4)), dim3(SORT_THREADS), 0, s, dev, epoch);
-        hipLaunchKernelGGL(k_scatter, dim3(pgrid), dim3(SORT_THREADS), 0, s, dev);
+        hipLaunchKernelGGL(k_scatter<D>, dim3(pgrid), dim3(SORT_THREADS), 0, s, dev, side);
         if (d->deterministic)
-            hipLaunchKernelGGL(k_canonical_order<D>, dim3(grid_for(d, 4)), dim3(SORT_THREADS), 0, s, dev, side);
+            hipLaunchKernelGGL(k_canonical_order, dim3(grid_for(d, 4)), dim3(SORT_THREADS), 0, s, dev);
     }
     mark(1);
     // ---- "grid_update_cdf" + "g2p_cdf" (collide.wgsl, grid_update_cdf.wgsl, g2p_cdf.wgsl)
@@ -438,6 +438,7 @@ wgs_status wgs_data_create(wgs_pipeline *pipeline, const wgs_sim_params *params,
     TRY_ALLOC(&dev.buf[0], plane_floats);
     TRY_ALLOC(&dev.buf[1], plane_floats);
     TRY_ALLOC(&dev.perm, (size_t)dev.npad);
+    TRY_ALLOC(&dev.perm_pid, (size_t)dev.npad);
     TRY_ALLOC(&dev.cellid, (size_t)dev.npad);
     TRY_ALLOC(&dev.rank, (size_t)dev.npad);
     TRY_ALLOC(&dev.hkeys, (size_t)hcap);

@@ -123,11 +123,22 @@ template <int D> __global__ __launch_bounds__(SORT_THREADS) void k_bin(Dev d, in
         const unsigned long long same = __ballot(mine);
         todo &= ~same;
         if (lane == leader) atomicAdd(&d.block_acc[id0], (uint32_t)__popcll(same));
-        // cross-lane traffic through LDS inside one wave: (relaxed, wavefront-scope) atomic accesses
-        // so the compiler may not forward this lane's own stores to its loads
+        // Rank inside the group = number of lower lanes with the same cell (buffer order, hence
+        // deterministic and already canonical for particles that did not change cell); an LDS
+        // atomic would hand out ranks in hardware arbitration order.
+        // Cross-lane traffic through LDS inside one wave uses (relaxed, wavefront-scope) atomic
+        // accesses so the compiler may not forward this lane's own stores to its loads.
         __hip_atomic_store(&hist[lane], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
         uint32_t r = 0;
-        if (mine) r = __hip_atomic_fetch_add(&hist[local], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+        unsigned long long cells_todo = same;
+        while (cells_todo) {  // one iteration per distinct cell of the group (~8 on sorted input)
+            const int l1 = __ffsll((long long)cells_todo) - 1;
+            const uint32_t c0 = __shfl(local, l1);
+            const unsigned long long m = __ballot(mine && local == c0);
+            cells_todo &= ~m;
+            if (mine && local == c0) r = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+            if (lane == l1) __hip_atomic_store(&hist[c0], (uint32_t)__popcll(m), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+        }
         const uint32_t cnt = __hip_atomic_load(&hist[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
         uint32_t base = 0;
         if (cnt) base = atomicAdd(&d.cell_count[id0 * NPB + lane], cnt);
@@ -239,63 +250,75 @@ template <int D> __global__ __launch_bounds__(SORT_THREADS) void k_block_setup(D
     }
 }
 
-// sort.wgsl:117-127 finalize_particles_sort (the sorted-ids half).
-__global__ __launch_bounds__(SORT_THREADS) void k_scatter(Dev d) {
+// sort.wgsl:117-127 finalize_particles_sort (the sorted-ids half). Also writes the particle
+// ids in sorted order (= the reference's sorted_particle_ids) so that the canonical-order
+// pass reads them contiguously instead of gathering through `perm`.
+template <int D> __global__ __launch_bounds__(SORT_THREADS) void k_scatter(Dev d, int side) {
     uint32_t i = blockIdx.x * SORT_THREADS + threadIdx.x;
     if (i >= d.n) return;
     uint32_t cid = d.cellid[i];
     if (cid == NONE) return;
-    d.perm[d.cell_start[cid] + d.rank[i]] = i;
+    const uint32_t r = d.cell_start[cid] + d.rank[i];
+    d.perm[r] = i;
+    d.perm_pid[r] = ldpid<D>(d.buf[side], d.npad, i);
 }
 
-// Canonical order inside each cell: ascending persistent particle id. One thread per cell;
-// up to CANON_REG entries are sorted in registers (two memory round trips), longer runs fall
-// back to an in-memory insertion sort.
+// Canonical order inside each cell: ascending persistent particle id. One thread per cell.
+// Cells whose membership did not change since the last substep are already sorted (the buffer
+// is written in canonical order), so the common case is one contiguous read and an early exit.
 constexpr int CANON_REG = 12;
-template <int D> __global__ __launch_bounds__(SORT_THREADS) void k_canonical_order(Dev d, int side) {
+__global__ __launch_bounds__(SORT_THREADS) void k_canonical_order(Dev d) {
     const uint32_t B = min(d.counters[CTR_NBLOCKS], d.cap);
     const uint32_t total = B * NPB;
-    const uint32_t *pid = reinterpret_cast<const uint32_t *>(d.buf[side] + (size_t)Pl<D>::NQ * 4 * d.npad);
     for (uint32_t t = blockIdx.x * SORT_THREADS + threadIdx.x; t < total; t += gridDim.x * SORT_THREADS) {
         const uint32_t c = d.active[t >> 6] * NPB + (t & 63u);
         const uint32_t s = d.cell_start[c], e = d.cell_cursor[c];
         const uint32_t m = e - s;
         if (m < 2) continue;
+        if (d.dbg & 16u) { if (m > 1000000u) d.perm[s] = 0; continue; }
         if (m <= CANON_REG) {
-            uint32_t p[CANON_REG], k[CANON_REG];
+            uint32_t k[CANON_REG];
 #pragma unroll
-            for (int q = 0; q < CANON_REG; q++) p[q] = (uint32_t)q < m ? d.perm[s + q] : NONE;
-#pragma unroll
-            for (int q = 0; q < CANON_REG; q++) k[q] = (uint32_t)q < m ? pid[p[q]] : NONE;  // NONE sorts last
+            for (int q = 0; q < CANON_REG; q++) k[q] = (uint32_t)q < m ? d.perm_pid[s + q] : NONE;  // NONE sorts last
             bool sorted = true;
 #pragma unroll
             for (int q = 1; q < CANON_REG; q++) sorted = sorted && k[q - 1] <= k[q];
-            if (sorted) continue;
+            if (sorted || (d.dbg & 32u)) continue;
+            // (pid << 32 | perm) packed so that one 64-bit compare-exchange moves both;
             // odd-even transposition sort: fixed network, no run-time register indexing
+            unsigned long long kp[CANON_REG];
+#pragma unroll
+            for (int q = 0; q < CANON_REG; q++)
+                kp[q] = ((unsigned long long)k[q] << 32) | ((uint32_t)q < m ? d.perm[s + q] : NONE);
 #pragma unroll
             for (int pass = 0; pass < CANON_REG; pass++) {
 #pragma unroll
                 for (int q = pass & 1; q + 1 < CANON_REG; q += 2) {
-                    const bool sw = k[q] > k[q + 1];
-                    const uint32_t ka = sw ? k[q + 1] : k[q], kb = sw ? k[q] : k[q + 1];
-                    const uint32_t pa = sw ? p[q + 1] : p[q], pb = sw ? p[q] : p[q + 1];
-                    k[q] = ka; k[q + 1] = kb; p[q] = pa; p[q + 1] = pb;
+                    const unsigned long long lo = kp[q] < kp[q + 1] ? kp[q] : kp[q + 1];
+                    const unsigned long long hi = kp[q] < kp[q + 1] ? kp[q + 1] : kp[q];
+                    kp[q] = lo;
+                    kp[q + 1] = hi;
                 }
             }
 #pragma unroll
             for (int q = 0; q < CANON_REG; q++)
-                if ((uint32_t)q < m) d.perm[s + q] = p[q];
+                if ((uint32_t)q < m) {
+                    d.perm[s + q] = (uint32_t)kp[q];
+                    d.perm_pid[s + q] = (uint32_t)(kp[q] >> 32);
+                }
         } else {
             for (uint32_t a = s + 1; a < e; a++) {
-                const uint32_t pa = d.perm[a], ka = pid[pa];
+                const uint32_t pa = d.perm[a], ka = d.perm_pid[a];
                 uint32_t j = a;
                 while (j > s) {
-                    const uint32_t pj = d.perm[j - 1];
-                    if (pid[pj] <= ka) break;
-                    d.perm[j] = pj;
+                    const uint32_t kj = d.perm_pid[j - 1];
+                    if (kj <= ka) break;
+                    d.perm[j] = d.perm[j - 1];
+                    d.perm_pid[j] = kj;
                     j--;
                 }
                 d.perm[j] = pa;
+                d.perm_pid[j] = ka;
             }
         }
     }

@@ -98,6 +98,7 @@ struct Dev {
     uint32_t npad;       // plane stride (floats)
     float *buf[2];       // ping-pong particle buffers
     uint32_t *perm;      // sorted slot -> index in the current buffer
+    uint32_t *perm_pid;  // sorted slot -> persistent particle id (the reference's sorted_particle_ids)
     uint32_t *cellid;    // per particle (current-buffer index): dense block id * 64 + cell in block
     uint32_t *rank;      // per particle: position inside its cell (arrival order; canonicalised later)
     // sparse block grid (grid.wgsl:82-184): open-addressing hash of packed block keys
