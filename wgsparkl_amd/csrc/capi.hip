@@ -336,7 +336,7 @@ template <bool TS> wgs_status enqueue_substep(wgs_data *d, int ts_slot) {
         hipLaunchKernelGGL(k_grid_update<D>, dim3(grid_for(d, 4)), dim3(256), 0, s, dev);
         mark(5);
         // ---- "g2p" + "particles_update", fused
-        const int g = grid_for(d, 4);
+        const int g = (int)((n + G2P_THREADS - 1) / G2P_THREADS);
 #define WGS_LAUNCH_G2P(MODEL, PL, CP) \
     hipLaunchKernelGGL((k_g2p_update<D, MODEL, PL, CP>), dim3(g), dim3(G2P_THREADS), 0, s, dev, side)
         const int sel = (dev.model == WGS_MODEL_NEO_HOOKEAN ? 4 : 0) | (d->plastic ? 2 : 0) | (d->cpic ? 1 : 0);
@@ -439,6 +439,7 @@ wgs_status wgs_data_create(wgs_pipeline *pipeline, const wgs_sim_params *params,
     TRY_ALLOC(&dev.buf[1], plane_floats);
     TRY_ALLOC(&dev.perm, (size_t)dev.npad);
     TRY_ALLOC(&dev.perm_pid, (size_t)dev.npad);
+    TRY_ALLOC(&dev.perm_cell, (size_t)dev.npad);
     TRY_ALLOC(&dev.cellid, (size_t)dev.npad);
     TRY_ALLOC(&dev.rank, (size_t)dev.npad);
     TRY_ALLOC(&dev.hkeys, (size_t)hcap);

@@ -260,6 +260,7 @@ template <int D> __global__ __launch_bounds__(SORT_THREADS) void k_scatter(Dev d
     if (cid == NONE) return;
     const uint32_t r = d.cell_start[cid] + d.rank[i];
     d.perm[r] = i;
+    d.perm_cell[r] = cid;
     d.perm_pid[r] = ldpid<D>(d.buf[side], d.npad, i);
 }
 

@@ -237,14 +237,19 @@ template <int D> __global__ __launch_bounds__(256) void k_grid_update(Dev d) {
         l[1] = (ln >> BS) & (BW - 1);
         l[2] = D == 3 ? (ln >> (2 * BS)) : 0;
         float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
+        uint32_t srcs[NN];
+        int tis[NN];
 #pragma unroll
         for (int o = 0; o < NN; o++) {
+            srcs[o] = NONE;
             int tt[3] = {l[0] + BW * (o & 1), l[1] + BW * ((o >> 1) & 1), l[2] + BW * ((o >> 2) & 1)};
             bool in_tile = tt[0] < TW && tt[1] < TW && (D == 2 || tt[2] < TW);
             if (!in_tile) continue;
             uint32_t src = d.nbr_minus[b * 8u + o];
             if (src == NONE || d.block_count[src] == 0) continue;
             int ti = tt[0] + TW * tt[1] + (D == 3 ? TW * TW * tt[2] : 0);
+            srcs[o] = src;
+            tis[o] = ti;
             float4 p = d.slab[(size_t)src * TILE + ti];
             sum.x += p.x; sum.y += p.y; sum.z += p.z; sum.w += p.w;
         }
@@ -257,7 +262,15 @@ template <int D> __global__ __launch_bounds__(256) void k_grid_update(Dev d) {
             float vel = (mom[k] + mass * g[k] * dt) * inv_mass;
             v[k] = fminf(fmaxf(vel, -lim), lim);
         }
-        d.nodes[node] = D == 3 ? make_float4(v[0], v[1], v[2], mass) : make_float4(v[0], v[1], mass, 0.f);
+        const float4 nv = D == 3 ? make_float4(v[0], v[1], v[2], mass) : make_float4(v[0], v[1], mass, 0.f);
+        // Write the node back into every slab entry it was gathered from: each (block, tile
+        // index) pair is read and written by exactly this thread, so the slabs turn in place
+        // from per-block momentum tiles into per-block VELOCITY tiles, which is what the fused
+        // G2P kernel stages (one contiguous 3.4 KiB read per block, no neighbour indirection).
+#pragma unroll
+        for (int o = 0; o < NN; o++)
+            if (srcs[o] != NONE) d.slab[(size_t)srcs[o] * TILE + tis[o]] = nv;
+        d.nodes[node] = nv;
     }
 }
 
@@ -267,7 +280,12 @@ template <int D> __global__ __launch_bounds__(256) void k_grid_update(Dev d) {
 // through the `affine` buffer, g2p.wgsl:230-232), the SVD is computed once
 // (reference: up to three times, quirk B8) and the result is written straight
 // into the other ping-pong buffer in sorted order.
-constexpr int G2P_THREADS = 256;
+// Launch shape: one 64-lane workgroup per 64 consecutive SORTED particles (no per-block
+// serial loop: ~16 k independent waves at 1 M particles, so the hardware overlaps the
+// perm -> particle-load -> node-tile -> compute -> store chains of many waves). The wave
+// stages the node tile of its particles' block in LDS itself (3.4 KiB); the 1-in-8 waves
+// that straddle a block boundary do it once per distinct block.
+constexpr int G2P_THREADS = 64;
 #ifndef G2P_WAVES_PER_EU
 #define G2P_WAVES_PER_EU 3
 #endif
@@ -288,72 +306,77 @@ __global__ __launch_bounds__(G2P_THREADS, G2P_WAVES_PER_EU) void k_g2p_update(De
     const float invd = 4.0f / (h * h);  // kernel.wgsl:56-58
     const int tid = threadIdx.x;
 
-    const uint32_t B = min(d.counters[CTR_NBLOCKS], d.cap);
-    for (uint32_t a = blockIdx.x; a < B; a += gridDim.x) {
-        const uint32_t b = d.active[a];
-        const uint32_t cnt = d.block_count[b];
-        if (cnt == 0) continue;
-        const uint32_t start = d.block_start[b];
+    const uint32_t j = blockIdx.x * G2P_THREADS + tid;  // slot in sorted order = output index
+    const bool valid = j < d.n;
+    const uint32_t src = valid ? d.perm[j] : 0u;
+    const uint32_t cid = valid ? d.perm_cell[j] : NONE;  // physical block id * 64 + cell in block
+    const uint32_t myblock = cid == NONE ? NONE : (cid >> 6);
+
+    // Particle state: issued before the tile staging so both latencies overlap.
+    float x[D], Fm[DD], mass, vol0, lambda, mu;
+    if constexpr (D == 3) {
+        const float4 xm = ldq(in, npad, P::XM, src);
+        const float4 f0 = ldq(in, npad, P::F0, src), f1 = ldq(in, npad, P::F1, src), f2 = ldq(in, npad, P::F2, src);
+        x[0] = xm.x; x[1] = xm.y; x[2] = xm.z; mass = xm.w;
+        Fm[0] = f0.x; Fm[1] = f0.y; Fm[2] = f0.z; Fm[3] = f0.w;
+        Fm[4] = f1.x; Fm[5] = f1.y; Fm[6] = f1.z; Fm[7] = f1.w;
+        Fm[8] = f2.x; vol0 = f2.y; lambda = f2.z; mu = f2.w;
+    } else {
+        const float4 xm = ldq(in, npad, P::XM, src);
+        const float4 f0 = ldq(in, npad, P::F0, src);
+        const float4 vl = ldq(in, npad, P::CV2, src);
+        x[0] = xm.x; x[1] = xm.y; mass = xm.z; vol0 = xm.w;
+        Fm[0] = f0.x; Fm[1] = f0.y; Fm[2] = f0.z; Fm[3] = f0.w;
+        lambda = vl.z; mu = vl.w;
+    }
+    const uint32_t pid = ldpid<D>(in, npad, src);
+
+    float pvel[D], nrm[D], sdist = 0.f;
+    uint32_t paff = 0;
+    if constexpr (CPIC) {
+        const float4 c0 = ldq(in, npad, P::CDF0, src);
+        nrm[0] = c0.x; nrm[1] = c0.y;
+        if constexpr (D == 3) {
+            const float4 cv = ldq(in, npad, P::CV2, src);
+            const float4 c1 = ldq(in, npad, P::CDF1, src);
+            nrm[2] = c0.z; sdist = c0.w; paff = __float_as_uint(c1.w);
+            pvel[0] = cv.y; pvel[1] = cv.z; pvel[2] = cv.w;
+        } else {
+            const float4 vl = ldq(in, npad, P::CV2, src);
+            sdist = c0.z; paff = __float_as_uint(c0.w);
+            pvel[0] = vl.x; pvel[1] = vl.y;
+        }
+    }
+
+    unsigned long long todo = __ballot(myblock != NONE);
+    while (todo) {  // wave-uniform: one iteration per distinct block among the 64 particles (1 or 2)
+        const int leader = __ffsll((long long)todo) - 1;
+        const uint32_t b = __shfl(myblock, leader);
+        const bool mine = myblock == b;
+        todo &= ~__ballot(mine);
         int bc[3] = {0, 0, 0};
         unpack_key<D>(d.block_key[b], bc);
-        __syncthreads();
-        // g2p.wgsl:72-132: nodes of the block and of its +1 neighbours -> LDS tile
+        __syncthreads();  // single-wave workgroup: orders the LDS tile reuse
+        // g2p.wgsl:72-132: velocities of the block's nodes and of its +1 rim -> LDS tile. The grid
+        // update left them as a contiguous per-block tile (slab), so this is one coalesced read.
         for (int n = tid; n < TILE; n += G2P_THREADS) {
-            int t[3];
-            t[0] = n % TW;
-            t[1] = (n / TW) % TW;
-            t[2] = D == 3 ? n / (TW * TW) : 0;
-            int o = (t[0] >= BW ? 1 : 0) | (t[1] >= BW ? 2 : 0) | (t[2] >= BW ? 4 : 0);
-            int ln = (t[0] & (BW - 1)) + ((t[1] & (BW - 1)) << BS) + (D == 3 ? ((t[2] & (BW - 1)) << (2 * BS)) : 0);
-            uint32_t nb = d.nbr_plus[b * 8u + o];
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            NodeCdf cdf = {0.f, 0u, NONE, 0u};
-            if (nb != NONE) {
-                v = d.nodes[(size_t)nb * NPB + ln];
-                if constexpr (CPIC) cdf = d.node_cdf[(size_t)nb * NPB + ln];
+            s_node[n] = d.slab[(size_t)b * TILE + n];
+            if constexpr (CPIC) {
+                int t[3];
+                t[0] = n % TW;
+                t[1] = (n / TW) % TW;
+                t[2] = D == 3 ? n / (TW * TW) : 0;
+                int o = (t[0] >= BW ? 1 : 0) | (t[1] >= BW ? 2 : 0) | (t[2] >= BW ? 4 : 0);
+                int ln = (t[0] & (BW - 1)) + ((t[1] & (BW - 1)) << BS) + (D == 3 ? ((t[2] & (BW - 1)) << (2 * BS)) : 0);
+                uint32_t nb = d.nbr_plus[b * 8u + o];
+                NodeCdf cdf = {0.f, 0u, NONE, 0u};
+                if (nb != NONE) cdf = d.node_cdf[(size_t)nb * NPB + ln];
+                s_cdf[n] = cdf;
             }
-            s_node[n] = v;
-            if constexpr (CPIC) s_cdf[n] = cdf;
         }
         __syncthreads();
 
-        for (uint32_t j = start + tid; j < start + cnt; j += G2P_THREADS) {
-            const uint32_t src = d.perm[j];
-            float x[D], Fm[DD], mass, vol0, lambda, mu;
-            if constexpr (D == 3) {
-                const float4 xm = ldq(in, npad, P::XM, src);
-                const float4 f0 = ldq(in, npad, P::F0, src), f1 = ldq(in, npad, P::F1, src), f2 = ldq(in, npad, P::F2, src);
-                x[0] = xm.x; x[1] = xm.y; x[2] = xm.z; mass = xm.w;
-                Fm[0] = f0.x; Fm[1] = f0.y; Fm[2] = f0.z; Fm[3] = f0.w;
-                Fm[4] = f1.x; Fm[5] = f1.y; Fm[6] = f1.z; Fm[7] = f1.w;
-                Fm[8] = f2.x; vol0 = f2.y; lambda = f2.z; mu = f2.w;
-            } else {
-                const float4 xm = ldq(in, npad, P::XM, src);
-                const float4 f0 = ldq(in, npad, P::F0, src);
-                const float4 vl = ldq(in, npad, P::CV2, src);
-                x[0] = xm.x; x[1] = xm.y; mass = xm.z; vol0 = xm.w;
-                Fm[0] = f0.x; Fm[1] = f0.y; Fm[2] = f0.z; Fm[3] = f0.w;
-                lambda = vl.z; mu = vl.w;
-            }
-            const uint32_t pid = ldpid<D>(in, npad, src);
-
-            float pvel[D], nrm[D], sdist = 0.f;
-            uint32_t paff = 0;
-            if constexpr (CPIC) {
-                const float4 c0 = ldq(in, npad, P::CDF0, src);
-                nrm[0] = c0.x; nrm[1] = c0.y;
-                if constexpr (D == 3) {
-                    const float4 cv = ldq(in, npad, P::CV2, src);
-                    const float4 c1 = ldq(in, npad, P::CDF1, src);
-                    nrm[2] = c0.z; sdist = c0.w; paff = __float_as_uint(c1.w);
-                    pvel[0] = cv.y; pvel[1] = cv.z; pvel[2] = cv.w;
-                } else {
-                    const float4 vl = ldq(in, npad, P::CV2, src);
-                    sdist = c0.z; paff = __float_as_uint(c0.w);
-                    pvel[0] = vl.x; pvel[1] = vl.y;
-                }
-            }
-
+        if (mine) {
             // ---- G2P (g2p.wgsl:150-218)
             int lcell[D];
             float ref[D], w[D][3];
@@ -534,8 +557,8 @@ __global__ __launch_bounds__(G2P_THREADS, G2P_WAVES_PER_EU) void k_g2p_update(De
                     stq(out, npad, P::CDF1, j, make_float4(rvel[0], rvel[1], 0.f, 0.f));
                 }
             }
-        }
-    }
+        }  // mine
+    }  // distinct blocks
 }
 
 }  // namespace wgs

@@ -99,6 +99,7 @@ struct Dev {
     float *buf[2];       // ping-pong particle buffers
     uint32_t *perm;      // sorted slot -> index in the current buffer
     uint32_t *perm_pid;  // sorted slot -> persistent particle id (the reference's sorted_particle_ids)
+    uint32_t *perm_cell; // sorted slot -> physical block id * 64 + cell in block
     uint32_t *cellid;    // per particle (current-buffer index): dense block id * 64 + cell in block
     uint32_t *rank;      // per particle: position inside its cell (arrival order; canonicalised later)
     // sparse block grid (grid.wgsl:82-184): open-addressing hash of packed block keys
@@ -120,7 +121,7 @@ struct Dev {
     uint32_t *cell_cursor; // cap*64: end of the cell's range in perm
     float4 *nodes;         // cap*64: velocity|momentum xyz, mass (2D: vx, vy, mass, 0)
     NodeCdf *node_cdf;     // cap*64
-    float4 *slab;          // cap*TILE: per-block P2G tile (block + its "+1" rim)
+    float4 *slab;          // cap*TILE: per-block tile (block + its "+1" rim): momentum after P2G, velocity after the grid update
     uint32_t *block_cdf_flag; // cap: block has a node with non-zero affinity
     uint32_t *counters;    // CTR_COUNT
     const SimParamsDev *sp;
@@ -135,21 +136,28 @@ struct Dev {
 // Quad access = (one uniform 64-bit buffer base in SGPRs) + (32-bit per-lane byte offset):
 // `global_load_dwordx4 v[..], v_off, s[base:base+1]`. Valid while one ping-pong buffer is
 // < 4 GiB (checked in wgs_data_create).
+// The empty asm pins the 32-bit offset in a VGPR right at the access: otherwise LICM turns
+// (base + off) into loop-invariant 64-bit VGPR address pairs, one per quad, live for the
+// whole kernel.
 __device__ inline float4 ldq(const float *base, uint32_t npad, int q, uint32_t i) {
-    const uint32_t off = ((uint32_t)q * npad + i) * 16u;
+    uint32_t off = ((uint32_t)q * npad + i) * 16u;
+    asm volatile("" : "+v"(off));
     return *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(base) + off);
 }
 __device__ inline void stq(float *base, uint32_t npad, int q, uint32_t i, float4 v) {
-    const uint32_t off = ((uint32_t)q * npad + i) * 16u;
+    uint32_t off = ((uint32_t)q * npad + i) * 16u;
+    asm volatile("" : "+v"(off));
     *reinterpret_cast<float4 *>(reinterpret_cast<char *>(base) + off) = v;
 }
 // persistent particle id (the caller's index) lives after the quads
 template <int D> __device__ inline uint32_t ldpid(const float *base, uint32_t npad, uint32_t i) {
-    const uint32_t off = ((uint32_t)Pl<D>::NQ * 4u * npad + i) * 4u;
+    uint32_t off = ((uint32_t)Pl<D>::NQ * 4u * npad + i) * 4u;
+    asm volatile("" : "+v"(off));
     return *reinterpret_cast<const uint32_t *>(reinterpret_cast<const char *>(base) + off);
 }
 template <int D> __device__ inline void stpid(float *base, uint32_t npad, uint32_t i, uint32_t pid) {
-    const uint32_t off = ((uint32_t)Pl<D>::NQ * 4u * npad + i) * 4u;
+    uint32_t off = ((uint32_t)Pl<D>::NQ * 4u * npad + i) * 4u;
+    asm volatile("" : "+v"(off));
     *reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(base) + off) = pid;
 }
 
