@@ -1,0 +1,46 @@
+"""Seeded scenes shared by tests/golden/make_golden.py (which stores the oracle's answers) and the
+tests that compare against the stored answers."""
+import numpy as np
+
+from wgsparkl_amd import scenes
+from wgsparkl_amd.models import DruckerPrager, ParticlePhase
+from wgsparkl_amd.solver import Collider, SimulationParams
+
+
+def cloud3d():
+    ps = scenes.random_cloud(1500, dim=3, seed=21, phase=ParticlePhase(1.0, -1.0))
+    return dict(particles=ps, params=SimulationParams((0.0, -9.81, 0.0), 1e-3), colliders=[], cell_width=1.0,
+                grid_capacity=2048, model=0)
+
+
+def cloud2d():
+    ps = scenes.random_cloud(1200, dim=2, seed=22, phase=ParticlePhase(1.0, -1.0))
+    return dict(particles=ps, params=SimulationParams((0.0, -9.81), 1e-3), colliders=[], cell_width=1.0,
+                grid_capacity=512, model=1)
+
+
+def sand3d():
+    ps = scenes.random_cloud(1200, dim=3, seed=23, young=1e6, plasticity=DruckerPrager.new(1e6, 0.25), phase=None)
+    return dict(particles=ps, params=SimulationParams((0.0, -9.81, 0.0), 5e-4), colliders=[], cell_width=1.0,
+                grid_capacity=2048, model=0)
+
+
+def floor3d():
+    sc = scenes.neo_hookean_cube(n_side=10, with_floor=True)
+    sc["particles"].pos[:, 1] -= 5.9
+    sc["particles"].vel[:, 1] = -3.0
+    sc["grid_capacity"] = 1024
+    return sc
+
+
+def tilted_box2d():
+    sc = scenes.elastic_block_2d(nx=24, ny=24, with_floor=False)
+    sc["particles"].pos[:, 1] -= 3.8
+    sc["particles"].vel[:, 1] = -2.0
+    sc["colliders"] = [Collider.cuboid((50.0, 1.0), (10.0, 1.2), rotation=(0.15,)),
+                       Collider.ball(2.0, (14.0, 6.0), linvel=(0.5, 0.0, 0.0), angvel=(1.0,))]
+    return sc
+
+
+CASES = {"cloud3d": (cloud3d, 3), "cloud2d": (cloud2d, 3), "sand3d": (sand3d, 2), "floor3d": (floor3d, 20),
+         "tilted_box2d": (tilted_box2d, 20)}
