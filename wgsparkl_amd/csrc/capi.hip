@@ -319,7 +319,7 @@ template <bool TS> wgs_status enqueue_substep(wgs_data *d, int ts_slot) {
     if (d->cpic && n > 0) {
         hipLaunchKernelGGL(k_node_cdf<D>, dim3(grid_for(d, 4)), dim3(256), 0, s, dev);
         mark(2);
-        hipLaunchKernelGGL(k_particle_cdf<D>, dim3(grid_for(d, 4)), dim3(G2P_THREADS), 0, s, dev, side);
+        hipLaunchKernelGGL(k_particle_cdf<D>, dim3(grid_for(d, 4)), dim3(256), 0, s, dev, side);
         mark(3);
     } else {
         mark(2);
