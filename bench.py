@@ -45,7 +45,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--n-side", type=int, default=100, help="particles per cube edge (100 -> 1M, the named config)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-floor", action="store_true")
+    ap.add_argument("--no-floor", action="store_true", help="drop the floor cuboid of SURVEY 8d C2 (no CPIC passes)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -62,7 +62,7 @@ def main():
     import numpy as np
     from wgsparkl_amd import MpmData, MpmPipeline, scenes
 
-    scene = scenes.neo_hookean_cube(n_side=args.n_side, with_floor=False)
+    scene = scenes.neo_hookean_cube(n_side=args.n_side, with_floor=not args.no_floor)
     ps = scene["particles"]
     n = ps.n
     pipe = MpmPipeline(dev_index, 3)
@@ -115,7 +115,7 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": f"wgsparkl3d neo-Hookean elastic cube, {n} particles/GPU, 128^3-cell domain, "
-                                   f"h=1, dt=1/1200, 8 particles/cell, no collider",
+                                   f"h=1, dt=1/1200, 8 particles/cell, " + ("no collider" if args.no_floor else "floor cuboid (CPIC passes on)"),
                        "particles_per_gpu": n, "active_blocks": stats["num_active_blocks"],
                        "parallelism": "1 GPU" if world == 1 else f"{world} independent slabs (no halo exchange yet)"},
             "roofline": {"bound": "hbm", "kernel": "k_g2p_update (fused G2P + particle update)",

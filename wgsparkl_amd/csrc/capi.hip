@@ -318,6 +318,7 @@ template <bool TS> wgs_status enqueue_substep(wgs_data *d, int ts_slot) {
     // ---- "grid_update_cdf" + "g2p_cdf" (collide.wgsl, grid_update_cdf.wgsl, g2p_cdf.wgsl)
     if (d->cpic && n > 0) {
         hipLaunchKernelGGL(k_node_cdf<D>, dim3(grid_for(d, 4)), dim3(256), 0, s, dev);
+        hipLaunchKernelGGL(k_block_class<D>, dim3(grid_for(d, 1)), dim3(256), 0, s, dev);
         mark(2);
         hipLaunchKernelGGL(k_particle_cdf<D>, dim3(grid_for(d, 4)), dim3(256), 0, s, dev, side);
         mark(3);
@@ -327,29 +328,38 @@ template <bool TS> wgs_status enqueue_substep(wgs_data *d, int ts_slot) {
     }
     if (n > 0) {
         // ---- "p2g"
-        if (d->cpic)
-            hipLaunchKernelGGL((k_p2g<D, true>), dim3(grid_for(d, 5)), dim3(P2GCfg<D>::NW * 64), 0, s, dev, side);
-        else
-            hipLaunchKernelGGL((k_p2g<D, false>), dim3(grid_for(d, 5)), dim3(P2GCfg<D>::NW * 64), 0, s, dev, side);
+        const dim3 p2g_grid(grid_for(d, 5)), p2g_block(P2GCfg<D>::NW * 64);
+        if (d->cpic) {
+            hipLaunchKernelGGL((k_p2g<D, false>), p2g_grid, p2g_block, 0, s, dev, side, 1);
+            hipLaunchKernelGGL((k_p2g<D, true>), p2g_grid, p2g_block, 0, s, dev, side, 2);
+        } else {
+            hipLaunchKernelGGL((k_p2g<D, false>), p2g_grid, p2g_block, 0, s, dev, side, 0);
+        }
         mark(4);
         // ---- "grid_update"
         hipLaunchKernelGGL(k_grid_update<D>, dim3(grid_for(d, 4)), dim3(256), 0, s, dev);
         mark(5);
         // ---- "g2p" + "particles_update", fused
         const int g = (int)((n + G2P_THREADS - 1) / G2P_THREADS);
-#define WGS_LAUNCH_G2P(MODEL, PL, CP) \
-    hipLaunchKernelGGL((k_g2p_update<D, MODEL, PL, CP>), dim3(g), dim3(G2P_THREADS), 0, s, dev, side)
-        const int sel = (dev.model == WGS_MODEL_NEO_HOOKEAN ? 4 : 0) | (d->plastic ? 2 : 0) | (d->cpic ? 1 : 0);
+#define WGS_LAUNCH_G2P(MODEL, PL, CM) \
+    hipLaunchKernelGGL((k_g2p_update<D, MODEL, PL, CM>), dim3(g), dim3(G2P_THREADS), 0, s, dev, side)
+#define WGS_LAUNCH_G2P_MP(MODEL, PL)        \
+    do {                                    \
+        if (d->cpic) {                      \
+            WGS_LAUNCH_G2P(MODEL, PL, 1);   \
+            WGS_LAUNCH_G2P(MODEL, PL, 2);   \
+        } else {                            \
+            WGS_LAUNCH_G2P(MODEL, PL, 0);   \
+        }                                   \
+    } while (0)
+        const int sel = (dev.model == WGS_MODEL_NEO_HOOKEAN ? 2 : 0) | (d->plastic ? 1 : 0);
         switch (sel) {
-            case 0: WGS_LAUNCH_G2P(0, false, false); break;
-            case 1: WGS_LAUNCH_G2P(0, false, true); break;
-            case 2: WGS_LAUNCH_G2P(0, true, false); break;
-            case 3: WGS_LAUNCH_G2P(0, true, true); break;
-            case 4: WGS_LAUNCH_G2P(1, false, false); break;
-            case 5: WGS_LAUNCH_G2P(1, false, true); break;
-            case 6: WGS_LAUNCH_G2P(1, true, false); break;
-            default: WGS_LAUNCH_G2P(1, true, true); break;
+            case 0: WGS_LAUNCH_G2P_MP(0, false); break;
+            case 1: WGS_LAUNCH_G2P_MP(0, true); break;
+            case 2: WGS_LAUNCH_G2P_MP(1, false); break;
+            default: WGS_LAUNCH_G2P_MP(1, true); break;
         }
+#undef WGS_LAUNCH_G2P_MP
 #undef WGS_LAUNCH_G2P
         mark(6);
     } else {
@@ -459,6 +469,8 @@ wgs_status wgs_data_create(wgs_pipeline *pipeline, const wgs_sim_params *params,
     TRY_ALLOC(&dev.node_cdf, (size_t)dev.cap * NPB);
     TRY_ALLOC(&dev.slab, (size_t)dev.cap * Dim<D>::TILE);
     TRY_ALLOC(&dev.block_cdf_flag, (size_t)dev.cap);
+    TRY_ALLOC(&dev.block_cpic, (size_t)dev.cap);
+    TRY_ALLOC(&dev.cpic_list, (size_t)dev.cap);
     TRY_ALLOC(&dev.counters, (size_t)CTR_COUNT);
     TRY_ALLOC(&d->sp, (size_t)1);
     TRY_ALLOC(&d->colliders, (size_t)WGS_MAX_COLLIDERS);

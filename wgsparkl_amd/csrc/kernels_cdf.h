@@ -198,35 +198,46 @@ template <int N> __device__ inline float det_small(const float *m) {
     }
 }
 
+// Class of every active block: does any node of its (BW+2)^D tile (the block and its +1
+// neighbours) carry a collider affinity? Blocks that do not are plain MLS-MPM this substep:
+// every particle cdf is default_cdf() (g2p_cdf.wgsl:246-249), nothing reads it (P2G / G2P take the
+// plain path for the block) and the G2P launch for such blocks writes the default into the next
+// buffer. The reference runs the full CDF machinery for every block (PERF note at
+// grid_update_cdf.wgsl:34-36).
+template <int D> __global__ __launch_bounds__(256) void k_block_class(Dev d) {
+    constexpr int NN = Dim<D>::NNBR;
+    const uint32_t B = min(d.counters[CTR_NBLOCKS], d.cap);
+    for (uint32_t a = blockIdx.x * 256 + threadIdx.x; a < B; a += gridDim.x * 256) {
+        const uint32_t b = d.active[a];
+        uint32_t any = 0;
+#pragma unroll
+        for (int o = 0; o < NN; o++) {
+            const uint32_t nb = d.nbr_plus[b * 8u + o];
+            if (nb != NONE) any |= d.block_cdf_flag[nb];
+        }
+        d.block_cpic[b] = any;
+        if (any && d.block_count[b] > 0) d.cpic_list[atomicAdd(&d.counters[CTR_NCPIC], 1u)] = b;  // few blocks
+    }
+}
+
 template <int D> __global__ __launch_bounds__(256) void k_particle_cdf(Dev d, int side) {
     constexpr int BW = Dim<D>::BW, BS = Dim<D>::BSHIFT, TW = Dim<D>::TW, TILE = Dim<D>::TILE, NN = Dim<D>::NNBR;
     constexpr int N = D + 1;
     using P = Pl<D>;
     __shared__ NodeCdf s_cdf[TILE];
-    __shared__ uint32_t s_any;
     float *buf = d.buf[side];
     const uint32_t npad = d.npad;
     const float h = d.h, inv_h = d.inv_h;
     const int tid = threadIdx.x;
-    const uint32_t B = min(d.counters[CTR_NBLOCKS], d.cap);
+    const uint32_t B = min(d.counters[CTR_NCPIC], d.cap);  // only blocks near a collider (k_block_class)
     for (uint32_t a = blockIdx.x; a < B; a += gridDim.x) {
-        const uint32_t b = d.active[a];
+        const uint32_t b = d.cpic_list[a];
         const uint32_t cnt = d.block_count[b];
-        if (cnt == 0) continue;
         const uint32_t start = d.block_start[b];
         int bc[3] = {0, 0, 0};
         unpack_key<D>(d.block_key[b], bc);
         __syncthreads();
-        if (tid == 0) {
-            uint32_t any = 0;
-            for (int o = 0; o < NN; o++) {
-                uint32_t nb = d.nbr_plus[b * 8u + o];
-                if (nb != NONE) any |= d.block_cdf_flag[nb];
-            }
-            s_any = any;
-        }
-        __syncthreads();
-        const bool any = s_any != 0u;  // no node of the tile is near a collider -> default_cdf()
+        const bool any = true;
         if (any) {
             for (int n = tid; n < TILE; n += 256) {
                 int t[3] = {n % TW, (n / TW) % TW, D == 3 ? n / (TW * TW) : 0};

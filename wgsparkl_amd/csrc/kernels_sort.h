@@ -204,7 +204,10 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan_active(Dev d, uint32_t ep
         if (tid == SCAN_THREADS - 1) carry_s = run;
         __syncthreads();
     }
-    if (tid == 0) d.counters[CTR_NBLOCKS] = (uint32_t)(carry_s >> 32);
+    if (tid == 0) {
+        d.counters[CTR_NBLOCKS] = (uint32_t)(carry_s >> 32);
+        d.counters[CTR_NCPIC] = 0;
+    }
 }
 
 // Per active block, one wave: neighbour links (replaces the per-thread hash lookups of

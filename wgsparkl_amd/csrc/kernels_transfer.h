@@ -36,8 +36,11 @@ template <> struct P2GCfg<2> {
     static constexpr int NQ = 3;        // XM, CV0, CV2
 };
 
+// `filter`: 0 = every block; in collider simulations the pass is launched twice, CPIC = false with
+// filter 1 (blocks whose tile sees no collider: every affinity is 0, plain MLS-MPM) and CPIC = true
+// with filter 2 (blocks near a collider).
 template <int D, bool CPIC>
-__global__ __launch_bounds__(P2GCfg<D>::NW * 64) void k_p2g(Dev d, int side) {
+__global__ __launch_bounds__(P2GCfg<D>::NW * 64) void k_p2g(Dev d, int side, int filter) {
     using Cfg = P2GCfg<D>;
     constexpr int BW = Dim<D>::BW, BS = Dim<D>::BSHIFT, TW = Dim<D>::TW, TILE = Dim<D>::TILE;
     constexpr int NT = Cfg::NW * 64;
@@ -59,11 +62,13 @@ __global__ __launch_bounds__(P2GCfg<D>::NW * 64) void k_p2g(Dev d, int side) {
     lc[2] = D == 3 ? (cell >> (2 * BS)) : 0;
     const int tnode0 = lc[0] + TW * lc[1] + (D == 3 ? TW * TW * (lc[2] + sz) : 0);  // tile node of (sx,sy) = (0,0)
 
-    const uint32_t B = min(d.counters[CTR_NBLOCKS], d.cap);
+    // filter 2 walks the (short) list of blocks near a collider, the others the active list
+    const uint32_t B = min(d.counters[filter == 2 ? CTR_NCPIC : CTR_NBLOCKS], d.cap);
     for (uint32_t a = blockIdx.x; a < B; a += gridDim.x) {
-        const uint32_t b = d.active[a];
+        const uint32_t b = filter == 2 ? d.cpic_list[a] : d.active[a];
         const uint32_t cnt = d.block_count[b];
         if (cnt == 0) continue;  // no particles: its slab is never read
+        if (filter == 1 && d.block_cpic[b] != 0u) continue;
         int bc[3] = {0, 0, 0};
         unpack_key<D>(d.block_key[b], bc);
         const uint32_t cs = d.cell_start[b * NPB + cell];
@@ -290,8 +295,12 @@ constexpr int G2P_THREADS = 64;
 #define G2P_WAVES_PER_EU 3
 #endif
 
-template <int D, int MODEL, bool PLASTIC, bool CPIC>
+// CMODE: 0 = simulation without colliders; 1 = collider simulation, this launch handles the blocks
+// whose tile sees no collider (plain MLS-MPM maths, writes default_cdf()); 2 = collider simulation,
+// blocks near a collider (full CPIC). Modes 1 and 2 are launched back to back and partition the blocks.
+template <int D, int MODEL, bool PLASTIC, int CMODE>
 __global__ __launch_bounds__(G2P_THREADS, G2P_WAVES_PER_EU) void k_g2p_update(Dev d, int side) {
+    constexpr bool CPIC = CMODE == 2;
     constexpr int BW = Dim<D>::BW, BS = Dim<D>::BSHIFT, TW = Dim<D>::TW, TILE = Dim<D>::TILE, NN = Dim<D>::NNBR;
     constexpr int DD = D * D;
     using P = Pl<D>;
@@ -310,7 +319,12 @@ __global__ __launch_bounds__(G2P_THREADS, G2P_WAVES_PER_EU) void k_g2p_update(De
     const bool valid = j < d.n;
     const uint32_t src = valid ? d.perm[j] : 0u;
     const uint32_t cid = valid ? d.perm_cell[j] : NONE;  // physical block id * 64 + cell in block
-    const uint32_t myblock = cid == NONE ? NONE : (cid >> 6);
+    uint32_t myblock = cid == NONE ? NONE : (cid >> 6);
+    if constexpr (CMODE != 0) {
+        // lanes whose block belongs to the other launch drop out before touching particle state
+        if (myblock != NONE && (d.block_cpic[myblock] != 0u) != (CMODE == 2)) myblock = NONE;
+        if (__ballot(myblock != NONE) == 0ull) return;
+    }
 
     // Particle state: issued before the tile staging so both latencies overlap.
     float x[D], Fm[DD], mass, vol0, lambda, mu;
@@ -548,6 +562,10 @@ __global__ __launch_bounds__(G2P_THREADS, G2P_WAVES_PER_EU) void k_g2p_update(De
                 stq(out, npad, P::F0, j, make_float4(Fm[0], Fm[1], Fm[2], Fm[3]));
             }
             stpid<D>(out, npad, j, pid);
+            if constexpr (CMODE == 1) {  // g2p_cdf.wgsl:246-249: no collider in reach -> default_cdf()
+                stq(out, npad, P::CDF0, j, make_float4(0.f, 0.f, 0.f, 0.f));
+                stq(out, npad, P::CDF1, j, make_float4(0.f, 0.f, 0.f, 0.f));
+            }
             if constexpr (CPIC) {
                 if constexpr (D == 3) {
                     stq(out, npad, P::CDF0, j, make_float4(nrm[0], nrm[1], nrm[2], sdist));

@@ -89,7 +89,7 @@ struct NodeCdf {        // grid.wgsl:233-240
 };
 
 // Counter slots in Dev::counters
-enum { CTR_NBLOCKS = 0, CTR_ERRORS = 1, CTR_NPHYS = 2, CTR_COUNT = 8 };
+enum { CTR_NBLOCKS = 0, CTR_ERRORS = 1, CTR_NPHYS = 2, CTR_NCPIC = 3, CTR_COUNT = 8 };
 enum { ERRBIT_OVERFLOW = 1u, ERRBIT_KEYRANGE = 2u };
 
 // Everything a kernel needs, passed by value.
@@ -123,6 +123,8 @@ struct Dev {
     NodeCdf *node_cdf;     // cap*64
     float4 *slab;          // cap*TILE: per-block tile (block + its "+1" rim): momentum after P2G, velocity after the grid update
     uint32_t *block_cdf_flag; // cap: block has a node with non-zero affinity
+    uint32_t *block_cpic;     // cap: some node of the block's (BW+2)^D tile has non-zero affinity
+    uint32_t *cpic_list;      // cap: particle-bearing blocks with block_cpic set, [0, counters[CTR_NCPIC])
     uint32_t *counters;    // CTR_COUNT
     const SimParamsDev *sp;
     const ColliderDev *colliders;
