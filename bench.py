@@ -103,7 +103,8 @@ def main():
         algo_bytes = 160.0 * n + 16.0 * n_nodes
         achieved = algo_bytes / (g2p_ms * 1e-3) / 1e9 if g2p_ms > 0 else 0.0
         traffic = None
-        prof = os.path.join(ROOT, "profiles", "r01_pmc_g2p.json")
+        prof = sorted(__import__("glob").glob(os.path.join(ROOT, "profiles", "r*_pmc_g2p.json")))[-1:] or [""]
+        prof = prof[0]
         if os.path.exists(prof):
             try:
                 traffic = json.load(open(prof)).get("hbm_bytes_per_launch")

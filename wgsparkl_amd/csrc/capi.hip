@@ -340,7 +340,7 @@ template <bool TS> wgs_status enqueue_substep(wgs_data *d, int ts_slot) {
         hipLaunchKernelGGL(k_grid_update<D>, dim3(grid_for(d, 4)), dim3(256), 0, s, dev);
         mark(5);
         // ---- "g2p" + "particles_update", fused
-        const int g = (int)((n + G2P_THREADS - 1) / G2P_THREADS);
+        const int g = (int)(((n + G2P_THREADS - 1) / G2P_THREADS + 7) / 8) * 8;  // multiple of 8: XCD-aware mapping
 #define WGS_LAUNCH_G2P(MODEL, PL, CM) \
     hipLaunchKernelGGL((k_g2p_update<D, MODEL, PL, CM>), dim3(g), dim3(G2P_THREADS), 0, s, dev, side)
 #define WGS_LAUNCH_G2P_MP(MODEL, PL)        \

@@ -315,7 +315,12 @@ __global__ __launch_bounds__(G2P_THREADS, G2P_WAVES_PER_EU) void k_g2p_update(De
     const float invd = 4.0f / (h * h);  // kernel.wgsl:56-58
     const int tid = threadIdx.x;
 
-    const uint32_t j = blockIdx.x * G2P_THREADS + tid;  // slot in sorted order = output index
+    // XCD-aware chunk mapping: workgroups are dealt round-robin to the 8 XCDs (blockIdx % 8), each with
+    // its own L2. Give every XCD one contiguous eighth of the sorted particles, so that the ~8 waves
+    // that share a block (and therefore its node tile) hit the same L2 instead of eight different ones.
+    const uint32_t per_xcd = gridDim.x >> 3;
+    const uint32_t chunk = (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
+    const uint32_t j = chunk * G2P_THREADS + tid;  // slot in sorted order = output index
     const bool valid = j < d.n;
     const uint32_t src = valid ? d.perm[j] : 0u;
     const uint32_t cid = valid ? d.perm_cell[j] : NONE;  // physical block id * 64 + cell in block
@@ -362,6 +367,21 @@ __global__ __launch_bounds__(G2P_THREADS, G2P_WAVES_PER_EU) void k_g2p_update(De
         }
     }
 
+    if (d.dbg & 64u) {  // ablation: memory traffic of the kernel without tile staging / maths
+        if (valid) {
+            if constexpr (D == 3) {
+                stq(out, npad, P::XM, j, make_float4(x[0], x[1], x[2], mass));
+                stq(out, npad, P::CV0, j, make_float4(Fm[0], Fm[1], Fm[2], Fm[3]));
+                stq(out, npad, P::CV1, j, make_float4(Fm[4], Fm[5], Fm[6], Fm[7]));
+                stq(out, npad, P::CV2, j, make_float4(Fm[8], x[0], x[1], x[2]));
+                stq(out, npad, P::F0, j, make_float4(Fm[0], Fm[1], Fm[2], Fm[3]));
+                stq(out, npad, P::F1, j, make_float4(Fm[4], Fm[5], Fm[6], Fm[7]));
+                stq(out, npad, P::F2, j, make_float4(Fm[8], vol0, lambda, mu));
+            }
+            stpid<D>(out, npad, j, pid);
+        }
+        return;
+    }
     unsigned long long todo = __ballot(myblock != NONE);
     while (todo) {  // wave-uniform: one iteration per distinct block among the 64 particles (1 or 2)
         const int leader = __ffsll((long long)todo) - 1;
@@ -392,44 +412,95 @@ __global__ __launch_bounds__(G2P_THREADS, G2P_WAVES_PER_EU) void k_g2p_update(De
 
         if (mine) {
             // ---- G2P (g2p.wgsl:150-218)
-            int lcell[D];
+            // The associated cell comes from the sort (perm_cell = block * 64 + cell in block, computed
+            // by k_bin from this very position with the bit-exact rule), so no fp32 division here.
             float ref[D], w[D][3];
-            int tbase = 0, stride = 1;
+            int tbase = 0;
+            {
+                const uint32_t lc = cid & 63u;
+                int lcell[3] = {(int)(lc & (BW - 1)), (int)((lc >> BS) & (BW - 1)), D == 3 ? (int)(lc >> (2 * BS)) : 0};
+                int stride = 1;
 #pragma unroll
-            for (int k = 0; k < D; k++) {
-                int c = assoc_cell(x[k], h);
-                lcell[k] = c - bc[k] * BW;  // in [0, BW)
-                ref[k] = (float)c * h - x[k];
-                eval_all(-ref[k] * inv_h, w[k]);
-                tbase += lcell[k] * stride;
-                stride *= TW;
+                for (int k = 0; k < D; k++) {
+                    ref[k] = (float)(bc[k] * BW + lcell[k]) * h - x[k];
+                    eval_all(-ref[k] * inv_h, w[k]);
+                    tbase += lcell[k] * stride;
+                    stride *= TW;
+                }
             }
             float vel[D], grad[DD];
-#pragma unroll
-            for (int k = 0; k < D; k++) vel[k] = 0.f;
-#pragma unroll
-            for (int k = 0; k < DD; k++) grad[k] = 0.f;
             constexpr int SZN = D == 3 ? 3 : 1;
-            // The z loop is kept rolled on purpose: fully unrolled, hipcc issues all 27
-            // ds_read_b128 up front (108 VGPRs of tile values) and the kernel drops to 2 waves/SIMD.
+            if constexpr (!CPIC) {
+                // Tensor-product evaluation of
+                //   v = sum_n w_n v_n ,  G_c = sum_n w_n s_c(n) v_n   (s = node offset in {0,1,2}^D)
+                // reducing along x, then y, then z: ~240 VALU instead of ~570 for the 27 direct terms.
+                // grad = inv_d * sum_n w_n v_n (x) (ref + s h) = inv_d * (v (x) ref + h * [G_x G_y G_z]).
+                float G[D][D];  // G[c][r]
+#pragma unroll
+                for (int k = 0; k < D; k++) vel[k] = 0.f;
+#pragma unroll
+                for (int c = 0; c < D; c++)
+#pragma unroll
+                    for (int r = 0; r < D; r++) G[c][r] = 0.f;
+                const float wx1 = w[0][1], wx2 = 2.0f * w[0][2];
 #pragma unroll 1
-            for (int sz = 0; sz < SZN; sz++)
+                for (int sz = 0; sz < SZN; sz++) {
+                    float Pz[D], Gxz[D], Gyz[D];
 #pragma unroll
-                for (int sy = 0; sy < 3; sy++)
+                    for (int k = 0; k < D; k++) { Pz[k] = 0.f; Gxz[k] = 0.f; Gyz[k] = 0.f; }
 #pragma unroll
-                    for (int sx = 0; sx < 3; sx++) {
-                        const int idx = tbase + sx + TW * sy + (D == 3 ? TW * TW * sz : 0);
-                        float4 nd = s_node[idx];
-                        float nv[D];
-                        nv[0] = nd.x; nv[1] = nd.y;
-                        if constexpr (D == 3) nv[2] = nd.z;
-                        float dpt[D];
-                        dpt[0] = ref[0] + (float)sx * h;
-                        dpt[1] = ref[1] + (float)sy * h;
-                        if constexpr (D == 3) dpt[2] = ref[2] + (float)sz * h;
-                        float wgt = w[0][sx] * w[1][sy];
-                        if constexpr (D == 3) wgt *= (sz == 0 ? w[2][0] : (sz == 1 ? w[2][1] : w[2][2]));
-                        if constexpr (CPIC) {
+                    for (int sy = 0; sy < 3; sy++) {
+                        const int idx = tbase + TW * sy + (D == 3 ? TW * TW * sz : 0);
+                        const float4 n0 = s_node[idx], n1 = s_node[idx + 1], n2 = s_node[idx + 2];
+                        float a0[3] = {n0.x, n0.y, n0.z}, a1[3] = {n1.x, n1.y, n1.z}, a2[3] = {n2.x, n2.y, n2.z};
+                        const float wy = w[1][sy];
+#pragma unroll
+                        for (int k = 0; k < D; k++) {
+                            const float p = w[0][0] * a0[k] + w[0][1] * a1[k] + w[0][2] * a2[k];
+                            const float gx = wx1 * a1[k] + wx2 * a2[k];
+                            Pz[k] += wy * p;
+                            Gxz[k] += wy * gx;
+                            if (sy > 0) Gyz[k] += ((float)sy * wy) * p;
+                        }
+                    }
+                    float wz = 1.f;
+                    if constexpr (D == 3) wz = sz == 0 ? w[2][0] : (sz == 1 ? w[2][1] : w[2][2]);
+#pragma unroll
+                    for (int k = 0; k < D; k++) {
+                        vel[k] += wz * Pz[k];
+                        G[0][k] += wz * Gxz[k];
+                        G[1][k] += wz * Gyz[k];
+                        if constexpr (D == 3) G[2][k] += ((float)sz * wz) * Pz[k];
+                    }
+                }
+#pragma unroll
+                for (int c = 0; c < D; c++)
+#pragma unroll
+                    for (int r = 0; r < D; r++) grad[c * D + r] = invd * (vel[r] * ref[c] + h * G[c][r]);
+            } else {
+#pragma unroll
+                for (int k = 0; k < D; k++) vel[k] = 0.f;
+#pragma unroll
+                for (int k = 0; k < DD; k++) grad[k] = 0.f;
+                // The z loop is kept rolled on purpose: fully unrolled, hipcc issues all 27
+                // ds_read_b128 up front (108 VGPRs of tile values) and the kernel drops to 2 waves/SIMD.
+#pragma unroll 1
+                for (int sz = 0; sz < SZN; sz++)
+#pragma unroll
+                    for (int sy = 0; sy < 3; sy++)
+#pragma unroll
+                        for (int sx = 0; sx < 3; sx++) {
+                            const int idx = tbase + sx + TW * sy + (D == 3 ? TW * TW * sz : 0);
+                            float4 nd = s_node[idx];
+                            float nv[D];
+                            nv[0] = nd.x; nv[1] = nd.y;
+                            if constexpr (D == 3) nv[2] = nd.z;
+                            float dpt[D];
+                            dpt[0] = ref[0] + (float)sx * h;
+                            dpt[1] = ref[1] + (float)sy * h;
+                            if constexpr (D == 3) dpt[2] = ref[2] + (float)sz * h;
+                            float wgt = w[0][sx] * w[1][sy];
+                            if constexpr (D == 3) wgt *= (sz == 0 ? w[2][0] : (sz == 1 ? w[2][1] : w[2][2]));
                             NodeCdf nc = s_cdf[idx];
                             if (!affinities_are_compatible(paff, nc.affinities)) {
                                 if (nc.closest_id != NONE && nc.closest_id < d.n_colliders) {
@@ -448,15 +519,15 @@ __global__ __launch_bounds__(G2P_THREADS, G2P_WAVES_PER_EU) void k_g2p_update(De
                                     for (int k = 0; k < D; k++) nv[k] = pvel[k];
                                 }
                             }
+                            const float wi = wgt * invd;
+#pragma unroll
+                            for (int k = 0; k < D; k++) vel[k] += nv[k] * wgt;
+#pragma unroll
+                            for (int c = 0; c < D; c++)
+#pragma unroll
+                                for (int r = 0; r < D; r++) grad[c * D + r] += wi * (nv[r] * dpt[c]);
                         }
-                        const float wi = wgt * invd;
-#pragma unroll
-                        for (int k = 0; k < D; k++) vel[k] += nv[k] * wgt;
-#pragma unroll
-                        for (int c = 0; c < D; c++)
-#pragma unroll
-                            for (int r = 0; r < D; r++) grad[c * D + r] += wi * (nv[r] * dpt[c]);
-                    }
+            }
 
             float rvel[D];
 #pragma unroll
