@@ -1,0 +1,96 @@
+"""-m gpu: BASELINE.json's full sizes, checked through size-independent properties (the oracle is too
+slow there): the sort is a permutation grouped by block, grid mass = particle mass, total momentum follows
+m g t in free fall, uniform motion is preserved exactly, two runs are bit-identical."""
+import numpy as np
+import pytest
+
+from wgsparkl_amd import scenes
+from wgsparkl_amd.solver import SimulationParams
+
+from helpers import run_gpu
+
+pytestmark = pytest.mark.gpu
+
+
+def check_sort_structure(data, n):
+    vid, first, num, ids = data.read_blocks()
+    assert num.sum() == n                                     # every particle is in exactly one block
+    assert np.array_equal(np.sort(ids), np.arange(n, dtype=np.uint32))   # sorted ids are a permutation
+    order = np.argsort(first, kind="stable")
+    has = num[order] > 0
+    f, c = first[order][has], num[order][has]
+    assert f[0] == 0 and np.array_equal(f[1:], np.cumsum(c)[:-1])        # contiguous, disjoint ranges
+    return vid, first, num, ids
+
+
+def test_c2_one_million_neo_hookean(hip_libs):
+    """configs[1]: 1M particles, neo-Hookean cube in a 128^3 domain."""
+    sc = scenes.neo_hookean_cube(n_side=100)
+    ps = sc["particles"]
+    k = 20
+    data = run_gpu(sc, k)
+    vid, first, num, ids = check_sort_structure(data, ps.n)
+    assert len(vid) == data.stats()["num_active_blocks"] and data.stats()["overflow"] == 0
+    # particle -> block membership is bit-exact with the cell rule applied on the host to the pre-step positions?
+    # (positions moved since; check the weaker, size-independent statement on the final state instead)
+    got = data.read_particles()
+    cells, vm, *_ = data.read_grid()
+    m = ps.mass.astype(np.float64)
+    assert abs(vm[:, 3].astype(np.float64).sum() - m.sum()) < 1e-5 * m.sum()            # P2G conserves mass
+    # free fall of an unconstrained body: total momentum = M g t; uniform field -> F stays I
+    g, dt = np.array([0.0, -9.81, 0.0]), sc["params"].dt
+    p = (m[:, None] * got.vel.astype(np.float64)).sum(0)
+    assert np.allclose(p, m.sum() * g * dt * k, rtol=1e-5, atol=1e-6 * m.sum())
+    assert np.abs(got.def_grad - np.eye(3, dtype=np.float32).reshape(-1)).max() < 1e-5
+    assert np.allclose(got.vel, (g * dt * k).astype(np.float32), atol=1e-5)
+    assert np.array_equal(got.mass, ps.mass) and np.array_equal(got.init_volume, ps.init_volume)
+
+
+def test_c2_with_floor_collides_and_stays_finite(hip_libs):
+    sc = scenes.neo_hookean_cube(n_side=64, with_floor=True)
+    sc["particles"].pos[:, 1] -= 5.7
+    sc["particles"].vel[:, 1] = -3.0
+    data = run_gpu(sc, 200)
+    got = data.read_particles()
+    check_sort_structure(data, got.n)
+    assert np.isfinite(got.pos).all() and np.isfinite(got.affine).all()
+    assert got.pos[:, 1].min() > 1.5 and (got.cdf_affinity & 1).sum() > 1000
+    # the block deforms: F is no longer the identity near the floor
+    assert np.abs(got.def_grad - np.eye(3, dtype=np.float32).reshape(-1)).max() > 1e-3
+
+
+def test_c3_sand_column_four_million(hip_libs):
+    """configs[2]: Drucker-Prager sand, 4M particles, 256^3 domain (sand3.rs material)."""
+    sc = scenes.sand_column(nx=100, ny=400, nz=100)
+    n = sc["particles"].n
+    assert n == 4_000_000
+    data = run_gpu(sc, 5)
+    check_sort_structure(data, n)
+    pos = data.read_positions()
+    assert np.isfinite(pos).all()
+    s = data.stats()
+    assert s["overflow"] == 0 and s["num_active_blocks"] > 10_000
+
+
+def test_bit_identical_reruns_at_scale(hip_libs):
+    sc = scenes.neo_hookean_cube(n_side=64)
+    rng = np.random.default_rng(2)
+    sc["particles"].vel[:] = rng.normal(0, 1.0, sc["particles"].vel.shape).astype(np.float32)
+    a = run_gpu(sc, 30).read_particles()
+    b = run_gpu(sc, 30).read_particles()
+    for f in ("pos", "vel", "def_grad", "affine"):
+        assert np.array_equal(getattr(a, f), getattr(b, f)), f
+
+
+def test_momentum_conserved_without_gravity(hip_libs):
+    """Internal (elastic) forces and APIC transfers conserve linear momentum to fp32 round-off."""
+    sc = scenes.neo_hookean_cube(n_side=48)
+    ps = sc["particles"]
+    rng = np.random.default_rng(5)
+    ps.vel[:] = rng.normal(0, 2.0, ps.vel.shape).astype(np.float32)
+    sc["params"] = SimulationParams(gravity=(0.0, 0.0, 0.0), dt=sc["params"].dt)
+    p0 = (ps.mass[:, None].astype(np.float64) * ps.vel).sum(0)
+    got = run_gpu(sc, 50).read_particles()
+    p1 = (got.mass[:, None].astype(np.float64) * got.vel).sum(0)
+    scale = (ps.mass[:, None].astype(np.float64) * np.abs(ps.vel)).sum()
+    assert np.abs(p1 - p0).max() < 2e-5 * scale
