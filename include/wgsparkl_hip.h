@@ -210,6 +210,37 @@ wgs_status wgs_read_blocks(wgs_data *data, wgs_block_record *out, size_t capacit
 wgs_status wgs_read_timings(wgs_data *data, float ms[WGS_NUM_PASSES]);
 wgs_status wgs_get_stats(wgs_data *data, wgs_stats *out);
 
+/* ---------------------------------------------------------------------------------------------
+ * Multi-GPU (x-slab domain decomposition). NEW DESIGN: the reference is single-GPU (one wgpu::Device,
+ * src/pipeline.rs:176-193; SURVEY.md sections 5 and 8e). One process per GPU owns the particles whose
+ * associated block has bx in [block_lo, block_hi). The host (wgsparkl_amd/sharded.py, or any MPI-like
+ * driver) moves the packed device buffers between neighbours (RCCL send/recv over xGMI).
+ * One substep:  step_begin -> pack_halo(both faces) -> exchange -> add_halo -> step_end ->
+ *               pack_migrants -> exchange -> add_migrants.
+ * `global_ids` are the particles' ids in the global scene (the canonical summation order is by id, so a
+ * sharded run reproduces the single-GPU sums). All ranks must pass the same `force_plastic`. */
+wgs_status wgs_data_create_sharded(wgs_pipeline *pipeline, const wgs_sim_params *params,
+                                   const wgs_particle *particles, size_t num_particles, const uint32_t *global_ids,
+                                   const wgs_collider *colliders, size_t num_colliders, float cell_width,
+                                   uint32_t grid_capacity, uint32_t particle_capacity, int32_t block_lo,
+                                   int32_t block_hi, int32_t force_plastic, wgs_data **out);
+uint32_t wgs_shard_halo_record_bytes(void);      /* key + partial sums of the two interface node layers of a block */
+uint32_t wgs_shard_particle_record_bytes(void);  /* full particle state */
+/* sort, CDF, P2G, gather of the partial node sums (asynchronous) */
+wgs_status wgs_shard_step_begin(wgs_pipeline *pipeline, wgs_data *data);
+/* partial sums of the active blocks of layer `layer_bx` (= this rank's block_hi, or its block_lo) into a device
+ * buffer of capacity_records records; *count is valid on return (blocking) */
+wgs_status wgs_shard_pack_halo(wgs_data *data, int32_t layer_bx, void *device_buf, uint32_t capacity_records, uint32_t *count);
+/* add a neighbour's partial sums (stream-ordered) */
+wgs_status wgs_shard_add_halo(wgs_data *data, const void *device_buf, uint32_t count);
+/* grid update + fused G2P / particle update (asynchronous) */
+wgs_status wgs_shard_step_end(wgs_pipeline *pipeline, wgs_data *data);
+/* particles that left [block_lo, block_hi): counts[0] crossed the lower face (-> dev_lo), counts[1] the upper one (blocking) */
+wgs_status wgs_shard_pack_migrants(wgs_data *data, void *dev_lo, void *dev_hi, uint32_t capacity_records, uint32_t counts[2]);
+wgs_status wgs_shard_add_migrants(wgs_data *data, const void *device_buf, uint32_t count);
+/* full records of every particle currently owned (read-back of a sharded run; blocking) */
+wgs_status wgs_shard_export(wgs_data *data, void *device_buf, uint32_t capacity_records, uint32_t *count);
+
 #ifdef __cplusplus
 }
 #endif

@@ -20,6 +20,10 @@ EXPORTS = (
     "wgs_data_destroy", "wgs_set_constitutive_model", "wgs_step", "wgs_sync", "wgs_set_sim_params",
     "wgs_set_collider_poses", "wgs_set_body_velocities", "wgs_read_positions", "wgs_read_particles",
     "wgs_read_grid", "wgs_read_blocks", "wgs_read_timings", "wgs_get_stats",
+    # multi-GPU (x-slab decomposition; new design, no reference counterpart)
+    "wgs_data_create_sharded", "wgs_shard_halo_record_bytes", "wgs_shard_particle_record_bytes",
+    "wgs_shard_step_begin", "wgs_shard_pack_halo", "wgs_shard_add_halo", "wgs_shard_step_end",
+    "wgs_shard_pack_migrants", "wgs_shard_add_migrants", "wgs_shard_export",
 )
 
 
@@ -133,6 +137,19 @@ def load(dim: int):
                                     C.POINTER(C.c_uint32)]
     lib.wgs_read_timings.argtypes = [vp, C.POINTER(C.c_float)]
     lib.wgs_get_stats.argtypes = [vp, C.POINTER(T.Stats)]
+    u32p = C.POINTER(C.c_uint32)
+    lib.wgs_data_create_sharded.argtypes = [vp, C.POINTER(T.SimParams), C.POINTER(T.Particle), C.c_size_t, u32p,
+                                            C.POINTER(T.Collider), C.c_size_t, C.c_float, C.c_uint32, C.c_uint32,
+                                            C.c_int32, C.c_int32, C.c_int32, C.POINTER(vp)]
+    lib.wgs_shard_halo_record_bytes.restype = C.c_uint32
+    lib.wgs_shard_particle_record_bytes.restype = C.c_uint32
+    lib.wgs_shard_step_begin.argtypes = [vp, vp]
+    lib.wgs_shard_step_end.argtypes = [vp, vp]
+    lib.wgs_shard_pack_halo.argtypes = [vp, C.c_int32, vp, C.c_uint32, u32p]
+    lib.wgs_shard_add_halo.argtypes = [vp, vp, C.c_uint32]
+    lib.wgs_shard_pack_migrants.argtypes = [vp, vp, vp, C.c_uint32, u32p]
+    lib.wgs_shard_add_migrants.argtypes = [vp, vp, C.c_uint32]
+    lib.wgs_shard_export.argtypes = [vp, vp, C.c_uint32, u32p]
     for name in EXPORTS:
         fn = getattr(lib, name)
         if fn.restype is C.c_int:  # default restype -> wgs_status

@@ -10,6 +10,8 @@
 #include "../../include/wgsparkl_hip.h"
 
 #include <cfloat>
+#include <climits>
+#include <cstdint>
 #include <cstddef>
 #include <cstdio>
 #include <cstdlib>
@@ -18,6 +20,7 @@
 #include <vector>
 
 #include "kernels_cdf.h"
+#include "kernels_shard.h"
 #include "kernels_sort.h"
 #include "kernels_transfer.h"
 
@@ -71,6 +74,8 @@ struct wgs_data {
     uint64_t device_bytes = 0;
     uint32_t sticky_errors = 0;
     uint32_t last_nblocks = 0;
+    uint32_t capacity = 0;      // particle slots allocated
+    uint32_t *shard_counts = nullptr;  // device scratch for pack kernels
     std::vector<void *> allocs;
     // by-pid static tables (never reordered)
     float *static_radius = nullptr;
@@ -289,7 +294,9 @@ void resolve_timings(wgs_data *d) {
 }
 
 // One substep = pipeline.rs:201-280 (MPM passes), enqueued on the data's stream.
-template <bool TS> wgs_status enqueue_substep(wgs_data *d, int ts_slot) {
+// part 0 = the whole substep (single GPU); sharded runs split it around the halo exchange:
+// part 1 = sort .. P2G + gather of the partial node sums, part 2 = grid update + fused G2P.
+template <bool TS> wgs_status enqueue_substep(wgs_data *d, int ts_slot, int part) {
     Dev &dev = d->dev;
     hipStream_t s = d->stream;
     const int side = d->side;
@@ -298,49 +305,60 @@ template <bool TS> wgs_status enqueue_substep(wgs_data *d, int ts_slot) {
     auto mark = [&](int m) {
         if (TS) hipEventRecord(d->events.ev[ts_slot][m], s);
     };
-    mark(0);
-    // ---- "grid sort" (grid.rs:30-207)
     const uint32_t epoch = (uint32_t)(d->substeps + 1);
-    if (d->substeps % REHASH_PERIOD == 0) {  // reset_hmap, amortised (device_math.h)
-        HIP_TRY(hipMemsetAsync(dev.hkeys, 0xff, sizeof(uint32_t) * ((size_t)dev.hmask + 1), s));
-        HIP_TRY(hipMemsetAsync(dev.hvals, 0xff, sizeof(uint32_t) * ((size_t)dev.hmask + 1), s));
-        HIP_TRY(hipMemsetAsync(dev.counters + CTR_NPHYS, 0, sizeof(uint32_t), s));
-    }
-    if (n > 0) {
-        hipLaunchKernelGGL(k_bin<D>, dim3(pgrid), dim3(SORT_THREADS), 0, s, dev, side, epoch);
-        hipLaunchKernelGGL(k_scan_active, dim3(1), dim3(SCAN_THREADS), 0, s, dev, epoch);
-        hipLaunchKernelGGL(k_block_setup<D>, dim3(grid_for(d, 4)), dim3(SORT_THREADS), 0, s, dev, epoch);
-        hipLaunchKernelGGL(k_scatter<D>, dim3(pgrid), dim3(SORT_THREADS), 0, s, dev, side);
-        if (d->deterministic)
-            hipLaunchKernelGGL(k_canonical_order, dim3(grid_for(d, 4)), dim3(SORT_THREADS), 0, s, dev);
-    }
-    mark(1);
-    // ---- "grid_update_cdf" + "g2p_cdf" (collide.wgsl, grid_update_cdf.wgsl, g2p_cdf.wgsl)
-    if (d->cpic && n > 0) {
-        hipLaunchKernelGGL(k_node_cdf<D>, dim3(grid_for(d, 4)), dim3(256), 0, s, dev);
-        hipLaunchKernelGGL(k_block_class<D>, dim3(grid_for(d, 1)), dim3(256), 0, s, dev);
-        mark(2);
-        hipLaunchKernelGGL(k_particle_cdf<D>, dim3(grid_for(d, 4)), dim3(256), 0, s, dev, side);
-        mark(3);
-    } else {
-        mark(2);
-        mark(3);
-    }
-    if (n > 0) {
-        // ---- "p2g"
-        const dim3 p2g_grid(grid_for(d, 5)), p2g_block(P2GCfg<D>::NW * 64);
-        if (d->cpic) {
-            hipLaunchKernelGGL((k_p2g<D, false>), p2g_grid, p2g_block, 0, s, dev, side, 1);
-            hipLaunchKernelGGL((k_p2g<D, true>), p2g_grid, p2g_block, 0, s, dev, side, 2);
+    if (part != 2) {
+        mark(0);
+        // ---- "grid sort" (grid.rs:30-207)
+        if (d->substeps % REHASH_PERIOD == 0) {  // reset_hmap, amortised (device_math.h)
+            HIP_TRY(hipMemsetAsync(dev.hkeys, 0xff, sizeof(uint32_t) * ((size_t)dev.hmask + 1), s));
+            HIP_TRY(hipMemsetAsync(dev.hvals, 0xff, sizeof(uint32_t) * ((size_t)dev.hmask + 1), s));
+            HIP_TRY(hipMemsetAsync(dev.counters + CTR_NPHYS, 0, sizeof(uint32_t), s));
+        }
+        if (n > 0) {
+            hipLaunchKernelGGL(k_bin<D>, dim3(pgrid), dim3(SORT_THREADS), 0, s, dev, side, epoch);
+            hipLaunchKernelGGL(k_scan_active, dim3(1), dim3(SCAN_THREADS), 0, s, dev, epoch);
+            hipLaunchKernelGGL(k_block_setup<D>, dim3(grid_for(d, 4)), dim3(SORT_THREADS), 0, s, dev, epoch);
+            hipLaunchKernelGGL(k_scatter<D>, dim3(pgrid), dim3(SORT_THREADS), 0, s, dev, side);
+            if (d->deterministic)
+                hipLaunchKernelGGL(k_canonical_order, dim3(grid_for(d, 4)), dim3(SORT_THREADS), 0, s, dev);
         } else {
-            hipLaunchKernelGGL((k_p2g<D, false>), p2g_grid, p2g_block, 0, s, dev, side, 0);
+            HIP_TRY(hipMemsetAsync(dev.counters + CTR_NBLOCKS, 0, sizeof(uint32_t), s));
+        }
+        mark(1);
+        // ---- "grid_update_cdf" + "g2p_cdf" (collide.wgsl, grid_update_cdf.wgsl, g2p_cdf.wgsl)
+        if (d->cpic && n > 0) {
+            hipLaunchKernelGGL(k_node_cdf<D>, dim3(grid_for(d, 4)), dim3(256), 0, s, dev);
+            hipLaunchKernelGGL(k_block_class<D>, dim3(grid_for(d, 1)), dim3(256), 0, s, dev);
+            mark(2);
+            hipLaunchKernelGGL(k_particle_cdf<D>, dim3(grid_for(d, 4)), dim3(256), 0, s, dev, side);
+            mark(3);
+        } else {
+            mark(2);
+            mark(3);
+        }
+        if (n > 0) {
+            // ---- "p2g"
+            const dim3 p2g_grid(grid_for(d, 5)), p2g_block(P2GCfg<D>::NW * 64);
+            if (d->cpic) {
+                hipLaunchKernelGGL((k_p2g<D, false>), p2g_grid, p2g_block, 0, s, dev, side, 1);
+                hipLaunchKernelGGL((k_p2g<D, true>), p2g_grid, p2g_block, 0, s, dev, side, 2);
+            } else {
+                hipLaunchKernelGGL((k_p2g<D, false>), p2g_grid, p2g_block, 0, s, dev, side, 0);
+            }
         }
         mark(4);
-        // ---- "grid_update"
-        hipLaunchKernelGGL(k_grid_update<D>, dim3(grid_for(d, 4)), dim3(256), 0, s, dev);
+        if (part == 1 && n > 0) hipLaunchKernelGGL((k_grid_update<D, 1>), dim3(grid_for(d, 4)), dim3(256), 0, s, dev);
+    }
+    if (part != 1) {
+        if (n > 0) {
+            // ---- "grid_update"
+            if (part == 0) hipLaunchKernelGGL((k_grid_update<D, 0>), dim3(grid_for(d, 4)), dim3(256), 0, s, dev);
+            else hipLaunchKernelGGL((k_grid_update<D, 2>), dim3(grid_for(d, 4)), dim3(256), 0, s, dev);
+        }
         mark(5);
-        // ---- "g2p" + "particles_update", fused
-        const int g = (int)(((n + G2P_THREADS - 1) / G2P_THREADS + 7) / 8) * 8;  // multiple of 8: XCD-aware mapping
+        if (dev.nv > 0) {
+            // ---- "g2p" + "particles_update", fused
+            const int g = (int)(((dev.nv + G2P_THREADS - 1) / G2P_THREADS + 7) / 8) * 8;  // multiple of 8: XCD-aware mapping
 #define WGS_LAUNCH_G2P(MODEL, PL, CM) \
     hipLaunchKernelGGL((k_g2p_update<D, MODEL, PL, CM>), dim3(g), dim3(G2P_THREADS), 0, s, dev, side)
 #define WGS_LAUNCH_G2P_MP(MODEL, PL)        \
@@ -352,25 +370,22 @@ template <bool TS> wgs_status enqueue_substep(wgs_data *d, int ts_slot) {
             WGS_LAUNCH_G2P(MODEL, PL, 0);   \
         }                                   \
     } while (0)
-        const int sel = (dev.model == WGS_MODEL_NEO_HOOKEAN ? 2 : 0) | (d->plastic ? 1 : 0);
-        switch (sel) {
-            case 0: WGS_LAUNCH_G2P_MP(0, false); break;
-            case 1: WGS_LAUNCH_G2P_MP(0, true); break;
-            case 2: WGS_LAUNCH_G2P_MP(1, false); break;
-            default: WGS_LAUNCH_G2P_MP(1, true); break;
-        }
+            const int sel = (dev.model == WGS_MODEL_NEO_HOOKEAN ? 2 : 0) | (d->plastic ? 1 : 0);
+            switch (sel) {
+                case 0: WGS_LAUNCH_G2P_MP(0, false); break;
+                case 1: WGS_LAUNCH_G2P_MP(0, true); break;
+                case 2: WGS_LAUNCH_G2P_MP(1, false); break;
+                default: WGS_LAUNCH_G2P_MP(1, true); break;
+            }
 #undef WGS_LAUNCH_G2P_MP
 #undef WGS_LAUNCH_G2P
+        }
         mark(6);
-    } else {
-        HIP_TRY(hipMemsetAsync(dev.counters + CTR_NBLOCKS, 0, sizeof(uint32_t), s));
-        mark(4);
-        mark(5);
-        mark(6);
+        d->side ^= 1;
+        d->substeps++;
+        dev.n = dev.nv;  // the buffer just written holds the valid particles only, in sorted order
     }
     HIP_TRY(hipGetLastError());
-    d->side ^= 1;
-    d->substeps++;
     return WGS_OK;
 }
 
@@ -400,9 +415,10 @@ wgs_status wgs_pipeline_create(int32_t hip_device, wgs_pipeline **out) {
 
 void wgs_pipeline_destroy(wgs_pipeline *pipeline) { delete pipeline; }
 
-wgs_status wgs_data_create(wgs_pipeline *pipeline, const wgs_sim_params *params, const wgs_particle *particles,
-                           size_t num_particles, const wgs_collider *colliders, size_t num_colliders, float cell_width,
-                           uint32_t grid_capacity, wgs_data **out) {
+static wgs_status create_impl(wgs_pipeline *pipeline, const wgs_sim_params *params, const wgs_particle *particles,
+                              size_t num_particles, const uint32_t *global_ids, const wgs_collider *colliders,
+                              size_t num_colliders, float cell_width, uint32_t grid_capacity, size_t particle_capacity,
+                              bool sharded, int32_t block_lo, int32_t block_hi, int32_t force_plastic, wgs_data **out) {
     if (!pipeline || !params || !out) return fail(WGS_ERR_INVALID_ARGUMENT, "NULL argument");
     if (num_particles && !particles) return fail(WGS_ERR_INVALID_ARGUMENT, "particles is NULL");
     if (num_colliders && !colliders) return fail(WGS_ERR_INVALID_ARGUMENT, "colliders is NULL");
@@ -411,7 +427,8 @@ wgs_status wgs_data_create(wgs_pipeline *pipeline, const wgs_sim_params *params,
     if (!(cell_width > 0.f)) return fail(WGS_ERR_INVALID_ARGUMENT, "cell_width must be > 0");
     if (grid_capacity == 0 || grid_capacity > (1u << 25)) return fail(WGS_ERR_INVALID_ARGUMENT, "grid_capacity out of range");
     // 32-bit byte offsets inside one ping-pong buffer (layout.h ldp/stp)
-    if (buffer_floats<D>((uint32_t)num_particles + 64) * 4 >= (1ull << 32))
+    if (particle_capacity < num_particles) particle_capacity = num_particles;
+    if (buffer_floats<D>((uint32_t)particle_capacity + 64) * 4 >= (1ull << 32))
         return fail(WGS_ERR_UNSUPPORTED, "more than ~21M particles per wgs_data: shard across GPUs");
     *out = nullptr;
     HIP_TRY(hipSetDevice(pipeline->device));
@@ -427,7 +444,12 @@ wgs_status wgs_data_create(wgs_pipeline *pipeline, const wgs_sim_params *params,
     Dev &dev = d->dev;
     const uint32_t n = (uint32_t)num_particles;
     dev.n = n;
-    dev.npad = ((n + 63u) / 64u) * 64u;
+    dev.nv = n;
+    dev.sharded = sharded ? 1u : 0u;
+    dev.shard_lo = sharded ? block_lo : INT32_MIN;
+    dev.shard_hi = sharded ? block_hi : INT32_MAX;
+    d->capacity = (uint32_t)particle_capacity;
+    dev.npad = (((uint32_t)particle_capacity + 63u) / 64u) * 64u;
     if (dev.npad == 0) dev.npad = 64;
     dev.cap = next_pow2(grid_capacity);  // grid.rs:283
     const uint32_t hcap = dev.cap * 2u;  // half-full table (reference: exactly cap slots, quirk B4)
@@ -478,6 +500,7 @@ wgs_status wgs_data_create(wgs_pipeline *pipeline, const wgs_sim_params *params,
     TRY_ALLOC(&d->static_dp, (size_t)dev.npad * 6);
     TRY_ALLOC(&d->static_phase, (size_t)dev.npad * 2);
     TRY_ALLOC(&d->static_flags, (size_t)dev.npad);
+    TRY_ALLOC(&d->shard_counts, (size_t)4);
 #undef TRY_ALLOC
     dev.sp = d->sp;
     dev.colliders = d->colliders;
@@ -519,7 +542,7 @@ wgs_status wgs_data_create(wgs_pipeline *pipeline, const wgs_sim_params *params,
             p = quad(P2::CDF0, i); p[0] = dy.cdf.normal[0]; p[1] = dy.cdf.normal[1]; p[2] = dy.cdf.signed_distance; p[3] = aff_bits;
             p = quad(P2::CDF1, i); p[0] = dy.cdf.rigid_vel[0]; p[1] = dy.cdf.rigid_vel[1]; p[2] = 0.f; p[3] = 0.f;
         }
-        pid_plane[i] = i;
+        pid_plane[i] = global_ids ? global_ids[i] : i;
         const float *dp = q.has_plasticity ? &q.plasticity.h0 : default_dp;
         const float phase = q.has_phase ? q.phase.phase : 0.0f;            // models/mod.rs:33-36
         const float max_stretch = q.has_phase ? q.phase.max_stretch : -1.0f;
@@ -539,7 +562,7 @@ wgs_status wgs_data_create(wgs_pipeline *pipeline, const wgs_sim_params *params,
         // (particle_update.wgsl:98-122; max_stretch >= FLT_MAX can never be exceeded by a finite F)
         if ((phase == 0.0f && dp[4] != 0.0f) || (phase > 0.0f && max_stretch > 0.0f && max_stretch < FLT_MAX)) plastic = true;
     }
-    d->plastic = plastic;
+    d->plastic = plastic || force_plastic != 0;
 #define H2D(dst, src, bytes)                                                               \
     if (hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, d->stream) != hipSuccess)   \
         return bail(fail(WGS_ERR_HIP, "hipMemcpy H2D failed"));
@@ -560,6 +583,104 @@ wgs_status wgs_data_create(wgs_pipeline *pipeline, const wgs_sim_params *params,
     if (hipStreamSynchronize(d->stream) != hipSuccess) return bail(fail(WGS_ERR_HIP, "initial upload failed"));
     *out = d;
     return WGS_OK;
+}
+
+wgs_status wgs_data_create(wgs_pipeline *pipeline, const wgs_sim_params *params, const wgs_particle *particles,
+                           size_t num_particles, const wgs_collider *colliders, size_t num_colliders, float cell_width,
+                           uint32_t grid_capacity, wgs_data **out) {
+    return create_impl(pipeline, params, particles, num_particles, nullptr, colliders, num_colliders, cell_width,
+                       grid_capacity, num_particles, false, 0, 0, 0, out);
+}
+
+wgs_status wgs_data_create_sharded(wgs_pipeline *pipeline, const wgs_sim_params *params, const wgs_particle *particles,
+                                   size_t num_particles, const uint32_t *global_ids, const wgs_collider *colliders,
+                                   size_t num_colliders, float cell_width, uint32_t grid_capacity,
+                                   uint32_t particle_capacity, int32_t block_lo, int32_t block_hi, int32_t force_plastic,
+                                   wgs_data **out) {
+    if (block_lo >= block_hi) return fail(WGS_ERR_INVALID_ARGUMENT, "empty shard range");
+    return create_impl(pipeline, params, particles, num_particles, global_ids, colliders, num_colliders, cell_width,
+                       grid_capacity, particle_capacity, true, block_lo, block_hi, force_plastic, out);
+}
+
+uint32_t wgs_shard_halo_record_bytes(void) { return (uint32_t)(HaloCfg<D>::REC_F4 * sizeof(float4)); }
+uint32_t wgs_shard_particle_record_bytes(void) { return (uint32_t)(particle_record_floats<D>() * sizeof(float)); }
+
+wgs_status wgs_shard_step_begin(wgs_pipeline *pipeline, wgs_data *d) {
+    if (!pipeline || !d) return fail(WGS_ERR_INVALID_ARGUMENT, "NULL argument");
+    if (!d->dev.sharded) return fail(WGS_ERR_INVALID_ARGUMENT, "not a sharded wgs_data");
+    HIP_TRY(hipSetDevice(pipeline->device));
+    return enqueue_substep<false>(d, 0, 1);
+}
+
+wgs_status wgs_shard_step_end(wgs_pipeline *pipeline, wgs_data *d) {
+    if (!pipeline || !d) return fail(WGS_ERR_INVALID_ARGUMENT, "NULL argument");
+    if (!d->dev.sharded) return fail(WGS_ERR_INVALID_ARGUMENT, "not a sharded wgs_data");
+    HIP_TRY(hipSetDevice(pipeline->device));
+    return enqueue_substep<false>(d, 0, 2);
+}
+
+wgs_status wgs_shard_pack_halo(wgs_data *d, int32_t layer_bx, void *device_buf, uint32_t capacity_records, uint32_t *count) {
+    if (!d || !device_buf || !count) return fail(WGS_ERR_INVALID_ARGUMENT, "NULL argument");
+    HIP_TRY(hipSetDevice(d->pipeline->device));
+    HIP_TRY(hipMemsetAsync(d->shard_counts, 0, sizeof(uint32_t) * 4, d->stream));
+    hipLaunchKernelGGL(k_pack_halo<D>, dim3(grid_for(d, 4)), dim3(64), 0, d->stream, d->dev, layer_bx,
+                       static_cast<float4 *>(device_buf), capacity_records, d->shard_counts);
+    HIP_TRY(hipMemcpyAsync(count, d->shard_counts, sizeof(uint32_t), hipMemcpyDeviceToHost, d->stream));
+    HIP_TRY(hipStreamSynchronize(d->stream));
+    if (*count > capacity_records) return fail(WGS_ERR_INVALID_ARGUMENT, "halo buffer too small");
+    return WGS_OK;
+}
+
+wgs_status wgs_shard_add_halo(wgs_data *d, const void *device_buf, uint32_t count) {
+    if (!d || (!device_buf && count)) return fail(WGS_ERR_INVALID_ARGUMENT, "NULL argument");
+    HIP_TRY(hipSetDevice(d->pipeline->device));
+    if (count == 0) return WGS_OK;
+    const uint32_t epoch = (uint32_t)(d->substeps + 1);
+    hipLaunchKernelGGL(k_add_halo<D>, dim3(count < 4096u ? count : 4096u), dim3(64), 0, d->stream, d->dev,
+                       static_cast<const float4 *>(device_buf), count, epoch);
+    HIP_TRY(hipGetLastError());
+    return WGS_OK;
+}
+
+static wgs_status pack_particles(wgs_data *d, int mode, void *dev_lo, void *dev_hi, uint32_t capacity_records, uint32_t counts[2]) {
+    HIP_TRY(hipSetDevice(d->pipeline->device));
+    HIP_TRY(hipMemsetAsync(d->shard_counts, 0, sizeof(uint32_t) * 4, d->stream));
+    if (d->dev.n > 0)
+        hipLaunchKernelGGL(k_pack_migrants<D>, dim3(grid_for(d, 4)), dim3(256), 0, d->stream, d->dev, d->side, mode,
+                           static_cast<float *>(dev_lo), static_cast<float *>(dev_hi), capacity_records, d->shard_counts);
+    HIP_TRY(hipMemcpyAsync(counts, d->shard_counts, sizeof(uint32_t) * 2, hipMemcpyDeviceToHost, d->stream));
+    HIP_TRY(hipStreamSynchronize(d->stream));
+    if (counts[0] > capacity_records || counts[1] > capacity_records) return fail(WGS_ERR_INVALID_ARGUMENT, "particle buffer too small");
+    return WGS_OK;
+}
+
+wgs_status wgs_shard_pack_migrants(wgs_data *d, void *dev_lo, void *dev_hi, uint32_t capacity_records, uint32_t counts[2]) {
+    if (!d || !dev_lo || !dev_hi || !counts) return fail(WGS_ERR_INVALID_ARGUMENT, "NULL argument");
+    wgs_status st = pack_particles(d, 0, dev_lo, dev_hi, capacity_records, counts);
+    if (st != WGS_OK) return st;
+    d->dev.nv -= counts[0] + counts[1];  // their slots stay (vacated) until the next substep compacts them away
+    return WGS_OK;
+}
+
+wgs_status wgs_shard_add_migrants(wgs_data *d, const void *device_buf, uint32_t count) {
+    if (!d || (!device_buf && count)) return fail(WGS_ERR_INVALID_ARGUMENT, "NULL argument");
+    HIP_TRY(hipSetDevice(d->pipeline->device));
+    if (count == 0) return WGS_OK;
+    if ((uint64_t)d->dev.n + count > d->capacity) return fail(WGS_ERR_INVALID_ARGUMENT, "particle_capacity exceeded by incoming particles");
+    hipLaunchKernelGGL(k_append_migrants<D>, dim3((count + 255) / 256), dim3(256), 0, d->stream, d->dev, d->side,
+                       static_cast<const float *>(device_buf), count, d->dev.n);
+    HIP_TRY(hipGetLastError());
+    d->dev.n += count;
+    d->dev.nv += count;
+    return WGS_OK;
+}
+
+wgs_status wgs_shard_export(wgs_data *d, void *device_buf, uint32_t capacity_records, uint32_t *count) {
+    if (!d || !device_buf || !count) return fail(WGS_ERR_INVALID_ARGUMENT, "NULL argument");
+    uint32_t counts[2] = {0, 0};
+    wgs_status st = pack_particles(d, 1, device_buf, device_buf, capacity_records, counts);
+    *count = counts[0];
+    return st;
 }
 
 void wgs_data_destroy(wgs_data *d) {
@@ -594,10 +715,10 @@ wgs_status wgs_step(wgs_pipeline *pipeline, wgs_data *d, uint32_t num_substeps, 
     for (uint32_t i = 0; i < num_substeps; i++) {
         wgs_status st;
         if (timestamps && d->events.used < Events::MAX_SUBSTEPS) {
-            st = enqueue_substep<true>(d, d->events.used);
+            st = enqueue_substep<true>(d, d->events.used, 0);
             d->events.used++;
         } else {
-            st = enqueue_substep<false>(d, 0);
+            st = enqueue_substep<false>(d, 0, 0);
         }
         if (st != WGS_OK) return st;
     }

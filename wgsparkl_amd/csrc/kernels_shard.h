@@ -1,0 +1,119 @@
+// kernels_shard.h — x-slab domain decomposition across GPUs (new design: the reference is
+// single-GPU). One process per GPU owns the particles whose associated
+// block has bx in [shard_lo, shard_hi). Because the stencil of a particle only reaches
+// nodes c .. c+2 of its associated cell c, a rank's particles write into, and read from, the
+// first two node layers (lx in {0,1}) of the block layer bx = shard_hi owned by the next
+// rank, and into nothing on the lower side. Per substep two small neighbour exchanges:
+//   1. after the P2G gather: partial (momentum, mass) sums of the interface node layers,
+//      both ways; each side adds what it received (a + b == b + a bitwise), so both ranks
+//      hold identical totals and run the grid update redundantly on those nodes;
+//   2. after the particle update: particles whose associated block left the rank's range
+//      (at most one block per substep because of the h/dt velocity clamps) move, full state.
+#pragma once
+#include "device_math.h"
+
+namespace wgs {
+
+constexpr uint32_t PID_DEAD = 0xffffffffu;  // slot vacated by a migrated particle
+
+template <int D> struct HaloCfg {
+    static constexpr int BW = Dim<D>::BW;
+    static constexpr int NODES = D == 3 ? 2 * BW * BW : 2 * BW;  // two x-layers of a block
+    static constexpr int REC_F4 = NODES + 1;                     // [key,0,0,0] + node partial sums
+};
+
+// local index of interface node q of a block: lx = q & 1, then y (, z)
+template <int D> __device__ inline uint32_t halo_node(int q) {
+    constexpr int BW = Dim<D>::BW, BS = Dim<D>::BSHIFT;
+    const int lx = q & 1, ly = (q >> 1) & (BW - 1), lz = D == 3 ? (q >> (1 + BS)) : 0;
+    return (uint32_t)(lx + (ly << BS) + (D == 3 ? (lz << (2 * BS)) : 0));
+}
+
+// Pack the partial sums of the interface layer `layer_bx` (active blocks only).
+template <int D> __global__ __launch_bounds__(64) void k_pack_halo(Dev d, int layer_bx, float4 *out, uint32_t cap, uint32_t *count) {
+    using H = HaloCfg<D>;
+    const uint32_t B = min(d.counters[CTR_NBLOCKS], d.cap);
+    const int lane = threadIdx.x;
+    for (uint32_t a = blockIdx.x; a < B; a += gridDim.x) {
+        const uint32_t b = d.active[a];
+        int bc[3] = {0, 0, 0};
+        unpack_key<D>(d.block_key[b], bc);
+        if (bc[0] != layer_bx) continue;  // wave-uniform
+        uint32_t slot = 0;
+        if (lane == 0) slot = atomicAdd(count, 1u);
+        slot = __shfl(slot, 0);
+        if (slot >= cap) continue;  // reported by the host through *count > cap
+        float4 *rec = out + (size_t)slot * H::REC_F4;
+        if (lane == 0) rec[0] = make_float4(__uint_as_float(d.block_key[b]), 0.f, 0.f, 0.f);
+        if (lane < H::NODES) rec[1 + lane] = d.nodes[(size_t)b * NPB + halo_node<D>(lane)];
+    }
+}
+
+// Add a neighbour's partial sums to the blocks this rank has active.
+template <int D> __global__ __launch_bounds__(64) void k_add_halo(Dev d, const float4 *in, uint32_t n_rec, uint32_t epoch) {
+    using H = HaloCfg<D>;
+    const int lane = threadIdx.x;
+    for (uint32_t r = blockIdx.x; r < n_rec; r += gridDim.x) {
+        const float4 *rec = in + (size_t)r * H::REC_F4;
+        const uint32_t key = __float_as_uint(rec[0].x);
+        const uint32_t b = hmap_find(d, key, epoch);
+        if (b == NONE) continue;  // not active here: nobody on this rank reads those nodes
+        if (lane < H::NODES) {
+            const size_t node = (size_t)b * NPB + halo_node<D>(lane);
+            const float4 a = d.nodes[node], p = rec[1 + lane];
+            d.nodes[node] = make_float4(a.x + p.x, a.y + p.y, a.z + p.z, a.w + p.w);
+        }
+    }
+}
+
+// Full-state record of one particle: NQ quads + pid.
+template <int D> constexpr int particle_record_floats() { return Pl<D>::NQ * 4 + 1; }
+
+// Particles whose associated block left [shard_lo, shard_hi): copy them to the outbox of the face
+// they crossed and vacate their slot. mode 1 = export every valid particle instead (read-back).
+template <int D> __global__ __launch_bounds__(256) void k_pack_migrants(Dev d, int side, int mode, float *out_lo, float *out_hi,
+                                                                        uint32_t cap, uint32_t *counts) {
+    constexpr int BS = Dim<D>::BSHIFT, NQ = Pl<D>::NQ, RF = particle_record_floats<D>();
+    float *buf = d.buf[side];
+    const uint32_t npad = d.npad;
+    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < d.n; i += gridDim.x * 256) {
+        const uint32_t pid = ldpid<D>(buf, npad, i);
+        if (pid == PID_DEAD) continue;
+        int face = -1;
+        if (mode == 1) {
+            face = 0;
+        } else {
+            const float4 xm = ldq(buf, npad, Pl<D>::XM, i);
+            const int bx = assoc_cell(xm.x, d.h) >> BS;
+            if (bx < d.shard_lo) face = 0;
+            else if (bx >= d.shard_hi) face = 1;
+        }
+        if (face < 0) continue;
+        const uint32_t slot = atomicAdd(&counts[face], 1u);  // a handful of particles per substep
+        if (slot < cap) {
+            float *rec = (face ? out_hi : out_lo) + (size_t)slot * RF;
+#pragma unroll
+            for (int q = 0; q < NQ; q++) {
+                const float4 v = ldq(buf, npad, q, i);
+                rec[q * 4 + 0] = v.x; rec[q * 4 + 1] = v.y; rec[q * 4 + 2] = v.z; rec[q * 4 + 3] = v.w;
+            }
+            rec[NQ * 4] = __uint_as_float(pid);
+        }
+        if (mode == 0) stpid<D>(buf, npad, i, PID_DEAD);
+    }
+}
+
+// Append received particles after the current ones.
+template <int D> __global__ __launch_bounds__(256) void k_append_migrants(Dev d, int side, const float *in, uint32_t n_rec, uint32_t first_slot) {
+    constexpr int NQ = Pl<D>::NQ, RF = particle_record_floats<D>();
+    float *buf = d.buf[side];
+    for (uint32_t r = blockIdx.x * 256 + threadIdx.x; r < n_rec; r += gridDim.x * 256) {
+        const float *rec = in + (size_t)r * RF;
+        const uint32_t i = first_slot + r;
+#pragma unroll
+        for (int q = 0; q < NQ; q++) stq(buf, d.npad, q, i, make_float4(rec[q * 4], rec[q * 4 + 1], rec[q * 4 + 2], rec[q * 4 + 3]));
+        stpid<D>(buf, d.npad, i, __float_as_uint(rec[NQ * 4]));
+    }
+}
+
+}  // namespace wgs

@@ -43,6 +43,7 @@ template <int D> __global__ __launch_bounds__(SORT_THREADS) void k_bin(Dev d, in
     __syncthreads();
     const uint32_t i = blockIdx.x * SORT_THREADS + tid;
     bool valid = i < d.n;
+    if (d.sharded && valid) valid = ldpid<D>(in, d.npad, i) != 0xffffffffu;  // slot vacated by a migrated particle
     int b[3] = {0, 0, 0};
     uint32_t key = NONE, local = 0;
     if (valid) {

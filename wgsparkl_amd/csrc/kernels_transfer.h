@@ -227,7 +227,9 @@ __global__ __launch_bounds__(P2GCfg<D>::NW * 64) void k_p2g(Dev d, int side, int
 
 // ------------------------------------------------------------ grid update
 // Gather of the slabs covering each node + solver/grid_update.wgsl:55-64.
-template <int D> __global__ __launch_bounds__(256) void k_grid_update(Dev d) {
+// PHASE 0: gather + update in one pass (single GPU). Sharded runs split it around the halo exchange:
+// PHASE 1 = gather only (partial momentum/mass sums into nodes[]), PHASE 2 = update from nodes[].
+template <int D, int PHASE> __global__ __launch_bounds__(256) void k_grid_update(Dev d) {
     constexpr int BW = Dim<D>::BW, BS = Dim<D>::BSHIFT, TW = Dim<D>::TW, TILE = Dim<D>::TILE, NN = Dim<D>::NNBR;
     const uint32_t B = min(d.counters[CTR_NBLOCKS], d.cap);
     const uint32_t total = B * NPB;
@@ -255,9 +257,16 @@ template <int D> __global__ __launch_bounds__(256) void k_grid_update(Dev d) {
             int ti = tt[0] + TW * tt[1] + (D == 3 ? TW * TW * tt[2] : 0);
             srcs[o] = src;
             tis[o] = ti;
-            float4 p = d.slab[(size_t)src * TILE + ti];
-            sum.x += p.x; sum.y += p.y; sum.z += p.z; sum.w += p.w;
+            if constexpr (PHASE != 2) {
+                float4 p = d.slab[(size_t)src * TILE + ti];
+                sum.x += p.x; sum.y += p.y; sum.z += p.z; sum.w += p.w;
+            }
         }
+        if constexpr (PHASE == 1) {
+            d.nodes[node] = sum;
+            continue;
+        }
+        if constexpr (PHASE == 2) sum = d.nodes[node];
         float mass = D == 3 ? sum.w : sum.z;
         float inv_mass = mass > 0.f ? 1.0f / mass : 0.f;
         float mom[3] = {sum.x, sum.y, sum.z};
@@ -321,7 +330,7 @@ __global__ __launch_bounds__(G2P_THREADS, G2P_WAVES_PER_EU) void k_g2p_update(De
     const uint32_t per_xcd = gridDim.x >> 3;
     const uint32_t chunk = (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
     const uint32_t j = chunk * G2P_THREADS + tid;  // slot in sorted order = output index
-    const bool valid = j < d.n;
+    const bool valid = j < d.nv;
     const uint32_t src = valid ? d.perm[j] : 0u;
     const uint32_t cid = valid ? d.perm_cell[j] : NONE;  // physical block id * 64 + cell in block
     uint32_t myblock = cid == NONE ? NONE : (cid >> 6);

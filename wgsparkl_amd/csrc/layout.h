@@ -94,7 +94,10 @@ enum { ERRBIT_OVERFLOW = 1u, ERRBIT_KEYRANGE = 2u };
 
 // Everything a kernel needs, passed by value.
 struct Dev {
-    uint32_t n;          // particles
+    uint32_t n;          // particle slots in the current buffer (valid + vacated)
+    uint32_t nv;         // valid particles = sorted slots (== n unless sharded and particles migrated)
+    uint32_t sharded;    // 1: x-slab decomposition (kernels_shard.h)
+    int shard_lo, shard_hi;  // owned block range along x
     uint32_t npad;       // plane stride (floats)
     float *buf[2];       // ping-pong particle buffers
     uint32_t *perm;      // sorted slot -> index in the current buffer

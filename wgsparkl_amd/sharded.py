@@ -1,0 +1,299 @@
+"""Multi-GPU driver: x-slab domain decomposition of the MLS-MPM substep, one process per GPU.
+
+NEW DESIGN — the reference is single-GPU (one wgpu::Device, src/pipeline.rs:176-193).
+The protocol is written against a small backend interface so that the very same code drives
+  * `GpuShard` (this file): a sharded `wgs_data` behind the C ABI, torch tensors as exchange buffers,
+    `torch.distributed` (backend "nccl" = RCCL over xGMI) as transport;
+  * a CPU checker backend in tests/ (world_size-2 gloo test, no GPU needed).
+
+Why x slabs and what crosses a face (see wgsparkl_amd/csrc/kernels_shard.h): a particle with associated cell c
+touches nodes c..c+2 only, so a rank's particles reach the first two node layers of the block layer owned by
+the NEXT rank and nothing on the lower side. Per substep:
+  1. after P2G both neighbours swap the partial (momentum, mass) sums of those two node layers and add
+     them (a + b == b + a bitwise, so both hold identical totals and update them redundantly);
+  2. after the particle update, particles whose associated block left the rank's range move (full state).
+Bytes per face and substep: 528 B per active interface block (3D) + ~200 B per migrating particle —
+two point-to-point messages per neighbour, no collective on the data path.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+from typing import List, Optional, Sequence
+
+import numpy as np
+
+from . import _ffi
+from .models import MODEL_COROTATED
+from .pipeline import MpmPipeline, _fill_collider, _pack_particles
+from .solver import ParticleSet, SimulationParams
+
+INT_MIN, INT_MAX = -(2 ** 31), 2 ** 31 - 1
+
+
+@dataclass
+class SlabPartition:
+    """Contiguous block ranges along x: rank r owns bx in [cuts[r], cuts[r+1]); the two ends are open."""
+    cuts: Sequence[int]          # world + 1 entries, in BLOCK units (4 cells in 3D, 8 in 2D)
+
+    @property
+    def world(self) -> int:
+        return len(self.cuts) - 1
+
+    def block_range(self, rank: int):
+        lo = INT_MIN if rank == 0 else int(self.cuts[rank])
+        hi = INT_MAX if rank == self.world - 1 else int(self.cuts[rank + 1])
+        return lo, hi
+
+    def owner_of_blocks(self, bx: np.ndarray) -> np.ndarray:
+        inner = np.asarray(self.cuts[1:-1], np.int64)
+        return np.searchsorted(inner, np.asarray(bx, np.int64), side="right")
+
+    @staticmethod
+    def balanced(block_x: np.ndarray, world: int) -> "SlabPartition":
+        """Cuts at particle-count quantiles of the associated block x coordinate (balance by particle
+        count, not by volume)."""
+        bx = np.sort(np.asarray(block_x, np.int64))
+        cuts = [int(bx[0])]
+        for r in range(1, world):
+            cuts.append(int(bx[(len(bx) * r) // world]))
+        cuts.append(int(bx[-1]) + 1)
+        for i in range(1, len(cuts)):          # strictly increasing
+            cuts[i] = max(cuts[i], cuts[i - 1] + 1)
+        return SlabPartition(cuts)
+
+
+def associated_block_x(pos: np.ndarray, cell_width: float, dim: int) -> np.ndarray:
+    """floor((round(x / h) - 1) / BW) with the reference's fp32 rule (particle3d.wgsl:41-49, grid.wgsl:284-292)."""
+    bw = 4 if dim == 3 else 8
+    c = np.rint(pos[:, 0].astype(np.float32) / np.float32(cell_width)) - np.float32(1.0)
+    return np.floor(c / np.float32(bw)).astype(np.int64)
+
+
+# ------------------------------------------------------------------------------------------------
+# protocol (backend-agnostic)
+# ------------------------------------------------------------------------------------------------
+def substep_phases(backend, exchange):
+    """One substep of one rank. `exchange(to_lower, to_upper) -> (from_lower, from_upper)` moves opaque
+    record arrays between neighbours (None where there is no neighbour)."""
+    lo, hi = backend.block_lo, backend.block_hi
+    backend.step_begin()
+    to_lower = backend.pack_halo(lo) if backend.has_lower else None
+    to_upper = backend.pack_halo(hi) if backend.has_upper else None
+    from_lower, from_upper = exchange(to_lower, to_upper)
+    if from_lower is not None:
+        backend.add_halo(from_lower)
+    if from_upper is not None:
+        backend.add_halo(from_upper)
+    backend.step_end()
+    out_lower, out_upper = backend.pack_migrants()
+    in_lower, in_upper = exchange(out_lower if backend.has_lower else None, out_upper if backend.has_upper else None)
+    if in_lower is not None:
+        backend.add_migrants(in_lower)
+    if in_upper is not None:
+        backend.add_migrants(in_upper)
+
+
+def lockstep_substep(backends: List):
+    """All ranks inside ONE process (tests, single-GPU emulation of the decomposition): runs the
+    phases of every rank in lockstep and routes the messages directly."""
+    n = len(backends)
+    for b in backends:
+        b.step_begin()
+    up = [b.pack_halo(b.block_hi) if b.has_upper else None for b in backends]
+    down = [b.pack_halo(b.block_lo) if b.has_lower else None for b in backends]
+    for r, b in enumerate(backends):
+        if r > 0:
+            b.add_halo(up[r - 1])
+        if r < n - 1:
+            b.add_halo(down[r + 1])
+    for b in backends:
+        b.step_end()
+    mig = [b.pack_migrants() for b in backends]
+    for r, b in enumerate(backends):
+        if r > 0:
+            b.add_migrants(mig[r - 1][1])
+        if r < n - 1:
+            b.add_migrants(mig[r + 1][0])
+
+
+class DistExchange:
+    """Neighbour exchange over torch.distributed point-to-point ops (nccl = RCCL on ROCm, gloo on CPU).
+    Message = [count] then `count` records; neighbours are distinct peers, one xGMI link each."""
+
+    def __init__(self, dist, rank: int, world: int, device):
+        import torch
+        self.torch, self.dist, self.rank, self.world, self.device = torch, dist, rank, world, device
+
+    def __call__(self, to_lower, to_upper):
+        torch, dist = self.torch, self.dist
+        lower = self.rank - 1 if self.rank > 0 else None
+        upper = self.rank + 1 if self.rank < self.world - 1 else None
+        sends = {lower: to_lower, upper: to_upper}
+        # 1. sizes
+        ops, rsize = [], {}
+        for peer in (lower, upper):
+            if peer is None:
+                continue
+            t = sends[peer]
+            n_out = torch.tensor([0 if t is None else int(t.numel())], dtype=torch.int64, device=self.device)
+            rsize[peer] = torch.zeros(1, dtype=torch.int64, device=self.device)
+            ops += [dist.P2POp(dist.isend, n_out, peer), dist.P2POp(dist.irecv, rsize[peer], peer)]
+        if ops:
+            for w in dist.batch_isend_irecv(ops):
+                w.wait()
+        # 2. payloads
+        ops, recv = [], {}
+        for peer in (lower, upper):
+            if peer is None:
+                continue
+            t = sends[peer]
+            n_in = int(rsize[peer].item())
+            recv[peer] = torch.empty(n_in, dtype=torch.float32 if t is None else t.dtype, device=self.device)
+            if t is not None and t.numel() > 0:
+                ops.append(dist.P2POp(dist.isend, t.contiguous(), peer))
+            if n_in > 0:
+                ops.append(dist.P2POp(dist.irecv, recv[peer], peer))
+        if ops:
+            for w in dist.batch_isend_irecv(ops):
+                w.wait()
+        return recv.get(lower), recv.get(upper)
+
+
+# ------------------------------------------------------------------------------------------------
+# GPU backend
+# ------------------------------------------------------------------------------------------------
+class GpuShard:
+    """One rank's slab on one MI355X: a sharded `wgs_data` + torch device buffers for the exchanges."""
+
+    def __init__(self, pipeline: MpmPipeline, params: SimulationParams, particles: ParticleSet, global_ids: np.ndarray,
+                 colliders, cell_width: float, grid_capacity: int, block_lo: int, block_hi: int, has_lower: bool,
+                 has_upper: bool, particle_capacity: int, model: int = MODEL_COROTATED, force_plastic: bool = False,
+                 halo_capacity_blocks: int = 0, migrant_capacity: int = 0):
+        import torch
+        self.torch = torch
+        self.pipeline, self.lib, self.T = pipeline, pipeline.lib, pipeline.T
+        T, D = self.T, pipeline.dim
+        self.dim = D
+        self.block_lo, self.block_hi = int(block_lo), int(block_hi)
+        self.has_lower, self.has_upper = has_lower, has_upper
+        sp = T.SimParams()
+        sp.gravity = (C.c_float * D)(*params.gravity)
+        sp.dt = params.dt
+        raw = _pack_particles(T, particles)
+        gids = np.ascontiguousarray(global_ids, np.uint32)
+        cols = (T.Collider * max(1, len(colliders)))()
+        for i, c in enumerate(colliders):
+            _fill_collider(T, cols[i], c, D)
+        h = C.c_void_p()
+        cap = max(int(particle_capacity), particles.n)
+        _ffi.check(self.lib, self.lib.wgs_data_create_sharded(
+            pipeline._h, C.byref(sp), raw.ctypes.data_as(C.POINTER(T.Particle)), particles.n,
+            gids.ctypes.data_as(C.POINTER(C.c_uint32)), cols, len(colliders), float(cell_width), int(grid_capacity),
+            cap, max(self.block_lo, INT_MIN), min(self.block_hi, INT_MAX), 1 if force_plastic else 0, C.byref(h)))
+        self._h = h
+        if model != MODEL_COROTATED:
+            _ffi.check(self.lib, self.lib.wgs_set_constitutive_model(self._h, int(model)))
+        self.halo_rec = self.lib.wgs_shard_halo_record_bytes() // 4
+        self.part_rec = self.lib.wgs_shard_particle_record_bytes() // 4
+        self.capacity = cap
+        dev = torch.device("cuda", pipeline.device)
+        self.device = dev
+        self.halo_cap = int(halo_capacity_blocks) or int(grid_capacity)
+        self.mig_cap = int(migrant_capacity) or max(4096, cap // 16)
+        f32 = torch.float32
+        self._halo_out = [torch.empty(self.halo_cap * self.halo_rec, dtype=f32, device=dev) for _ in range(2)]
+        self._mig_out = [torch.empty(self.mig_cap * self.part_rec, dtype=f32, device=dev) for _ in range(2)]
+        self._keep = []   # received tensors stay alive until the stream has consumed them
+
+    # -- protocol
+    def step_begin(self):
+        self._keep.clear()
+        _ffi.check(self.lib, self.lib.wgs_shard_step_begin(self.pipeline._h, self._h))
+
+    def pack_halo(self, layer_bx: int):
+        buf = self._halo_out[0 if layer_bx == self.block_lo else 1]
+        cnt = C.c_uint32(0)
+        _ffi.check(self.lib, self.lib.wgs_shard_pack_halo(self._h, int(layer_bx), C.c_void_p(buf.data_ptr()), self.halo_cap,
+                                                           C.byref(cnt)))
+        return buf[: cnt.value * self.halo_rec]
+
+    def add_halo(self, recs):
+        if recs is None or recs.numel() == 0:
+            return
+        recs = recs.to(self.device).contiguous()
+        self._keep.append(recs)
+        _ffi.check(self.lib, self.lib.wgs_shard_add_halo(self._h, C.c_void_p(recs.data_ptr()), recs.numel() // self.halo_rec))
+
+    def step_end(self):
+        _ffi.check(self.lib, self.lib.wgs_shard_step_end(self.pipeline._h, self._h))
+
+    def pack_migrants(self):
+        counts = (C.c_uint32 * 2)()
+        _ffi.check(self.lib, self.lib.wgs_shard_pack_migrants(self._h, C.c_void_p(self._mig_out[0].data_ptr()),
+                                                               C.c_void_p(self._mig_out[1].data_ptr()), self.mig_cap, counts))
+        return (self._mig_out[0][: counts[0] * self.part_rec], self._mig_out[1][: counts[1] * self.part_rec])
+
+    def add_migrants(self, recs):
+        if recs is None or recs.numel() == 0:
+            return
+        recs = recs.to(self.device).contiguous()
+        self._keep.append(recs)
+        _ffi.check(self.lib, self.lib.wgs_shard_add_migrants(self._h, C.c_void_p(recs.data_ptr()), recs.numel() // self.part_rec))
+
+    # -- host side
+    def sync(self):
+        _ffi.check(self.lib, self.lib.wgs_sync(self._h))
+
+    def num_particles(self) -> int:
+        s = self.T.Stats()
+        _ffi.check(self.lib, self.lib.wgs_get_stats(self._h, C.byref(s)))
+        return int(s.num_particles)
+
+    def export(self):
+        """(global ids, pos, vel, def_grad, affine, mass) of the particles this rank owns now."""
+        torch = self.torch
+        buf = torch.empty(self.capacity * self.part_rec, dtype=torch.float32, device=self.device)
+        cnt = C.c_uint32(0)
+        _ffi.check(self.lib, self.lib.wgs_shard_export(self._h, C.c_void_p(buf.data_ptr()), self.capacity, C.byref(cnt)))
+        rec = buf[: cnt.value * self.part_rec].cpu().numpy().reshape(cnt.value, self.part_rec)
+        return unpack_records(rec, self.dim)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self.lib.wgs_data_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def unpack_records(rec: np.ndarray, dim: int):
+    """Particle records (quad layout of csrc/layout.h) -> dict of arrays."""
+    ids = rec[:, -1].copy().view(np.uint32)
+    if dim == 3:
+        q = lambda k: rec[:, 4 * k:4 * k + 4]
+        pos, mass = q(0)[:, :3], q(0)[:, 3]
+        C_ = np.concatenate([q(1), q(2), q(3)[:, :1]], 1)
+        vel = q(3)[:, 1:4]
+        F = np.concatenate([q(4), q(5), q(6)[:, :1]], 1)
+    else:
+        q = lambda k: rec[:, 4 * k:4 * k + 4]
+        pos, mass = q(0)[:, :2], q(0)[:, 2]
+        C_, vel, F = q(1), q(2)[:, :2], q(3)
+    return dict(ids=ids, pos=pos.copy(), vel=vel.copy(), def_grad=F.copy(), affine=C_.copy(), mass=mass.copy())
+
+
+def split_scene(particles: ParticleSet, partition: SlabPartition, cell_width: float):
+    """Assign every particle to the rank owning its associated block; returns per-rank (ParticleSet, global ids)."""
+    bx = associated_block_x(particles.pos, cell_width, particles.dim)
+    owner = partition.owner_of_blocks(bx)
+    out = []
+    for r in range(partition.world):
+        idx = np.nonzero(owner == r)[0]
+        sub = ParticleSet(**{k: (v[idx] if isinstance(v, np.ndarray) else v) for k, v in particles.__dict__.items()})
+        out.append((sub, idx.astype(np.uint32)))
+    return out
