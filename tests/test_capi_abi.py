@@ -10,7 +10,7 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 HEADER = open(os.path.join(ROOT, "include", "wgsparkl_hip.h")).read()
 # function declarations: "<ret> wgs_name(" at the start of a statement (skips the "wgs_status (0 = ok)" prose)
-DECLARED = sorted(set(re.findall(r"^(?:const char \*|int32_t |void |wgs_status )(wgs_[a-z_]+)\(", HEADER, re.M)))
+DECLARED = sorted(set(re.findall(r"^(?:const char \*|int32_t |uint32_t |void |wgs_status )(wgs_[a-z_]+)\(", HEADER, re.M)))
 
 
 def test_header_declares_the_expected_surface():

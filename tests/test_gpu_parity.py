@@ -254,8 +254,9 @@ def test_set_sim_params_and_colliders(hip_libs, oracle_libs):
 
 # ---------------------------------------------------------------------------------------------
 # Multi-GPU decomposition, emulated on ONE GPU: R sharded wgs_data advanced in lockstep must
-# reproduce the single-domain run (the summation order is canonical by global id, so the
-# interface sums are bitwise identical and the rest follows).
+# reproduce the single-domain run. Inside a cell the summation order is canonical by global id;
+# only the interface node sums associate differently ((own) + (neighbour's) instead of one
+# 8-slab chain), so the two runs agree to fp32 round-off, not bitwise.
 # ---------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("world,dim", [(2, 3), (3, 3), (2, 2)])
 def test_sharded_lockstep_matches_single_domain(hip_libs, world, dim):
@@ -291,7 +292,10 @@ def test_sharded_lockstep_matches_single_domain(hip_libs, world, dim):
     for f in ("pos", "vel", "def_grad", "affine"):
         got = np.concatenate([o[f] for o in outs])[order]
         want = getattr(ref, f)
-        assert np.array_equal(got, want), f"{f}: sharded run differs from the single-domain run (max abs {np.abs(got - want).max():.3e})"
+        err = rel_rms(got, want)
+        # C' holds the stress term (E * strain): round-off there is amplified like in the single-domain parity tests
+        tol = 2e-4 if f == "affine" else 1e-5
+        assert err < tol, f"{f}: sharded run differs from the single-domain run (rel rms {err:.3e})"
     # ownership: every particle sits on the rank that owns its associated block
     for r, o in enumerate(outs):
         lo, hi = part.block_range(r)

@@ -112,6 +112,13 @@ def load(dim: int):
     if not os.path.exists(path):
         raise ImportError(f"{path} is missing — run `python -c 'import __graft_entry__ as g; g.build()'` "
                           "(hipcc, gfx950). There is no CPU fallback for the MPM step.")
+    # PyTorch-ROCm ships its own libamdhip64; if this library pulled in /opt/rocm's copy first, a later
+    # torch.cuda init would find a second HIP runtime and report "No HIP GPUs are available". Loading torch
+    # first makes both resolve to one runtime (torch is only plumbing here: streams, torch.distributed).
+    try:
+        import torch  # noqa: F401
+    except Exception:  # torch is optional for the single-GPU path
+        pass
     lib = C.CDLL(path)
     T = make_types(dim)
     vp = C.c_void_p

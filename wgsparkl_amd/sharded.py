@@ -121,9 +121,10 @@ class DistExchange:
     """Neighbour exchange over torch.distributed point-to-point ops (nccl = RCCL on ROCm, gloo on CPU).
     Message = [count] then `count` records; neighbours are distinct peers, one xGMI link each."""
 
-    def __init__(self, dist, rank: int, world: int, device):
+    def __init__(self, dist, rank: int, world: int, device, dtype=None):
         import torch
         self.torch, self.dist, self.rank, self.world, self.device = torch, dist, rank, world, device
+        self.dtype = dtype or torch.float32
 
     def __call__(self, to_lower, to_upper):
         torch, dist = self.torch, self.dist
@@ -149,7 +150,7 @@ class DistExchange:
                 continue
             t = sends[peer]
             n_in = int(rsize[peer].item())
-            recv[peer] = torch.empty(n_in, dtype=torch.float32 if t is None else t.dtype, device=self.device)
+            recv[peer] = torch.empty(n_in, dtype=self.dtype, device=self.device)
             if t is not None and t.numel() > 0:
                 ops.append(dist.P2POp(dist.isend, t.contiguous(), peer))
             if n_in > 0:
