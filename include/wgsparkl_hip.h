@@ -216,7 +216,7 @@ wgs_status wgs_get_stats(wgs_data *data, wgs_stats *out);
  * associated block has bx in [block_lo, block_hi). The host (wgsparkl_amd/sharded.py, or any MPI-like
  * driver) moves the packed device buffers between neighbours (RCCL send/recv over xGMI).
  * One substep:  step_begin -> pack_halo(both faces) -> exchange -> add_halo -> step_end ->
- *               pack_migrants -> exchange -> add_migrants.
+ *               pack_migrants -> exchange -> add_migrants   (no host synchronisation anywhere).
  * `global_ids` are the particles' ids in the global scene (the canonical summation order is by id, so a
  * sharded run reproduces the single-GPU sums). All ranks must pass the same `force_plastic`. */
 wgs_status wgs_data_create_sharded(wgs_pipeline *pipeline, const wgs_sim_params *params,
@@ -226,19 +226,28 @@ wgs_status wgs_data_create_sharded(wgs_pipeline *pipeline, const wgs_sim_params 
                                    int32_t block_hi, int32_t force_plastic, wgs_data **out);
 uint32_t wgs_shard_halo_record_bytes(void);      /* key + partial sums of the two interface node layers of a block */
 uint32_t wgs_shard_particle_record_bytes(void);  /* full particle state */
-/* sort, CDF, P2G, gather of the partial node sums (asynchronous) */
+uint32_t wgs_shard_buffer_header_bytes(void);    /* every exchange buffer = header ([count,-,-,-]) + capacity records */
+/* Run this wgs_data on the caller's HIP stream (e.g. the stream RCCL work is ordered on), so that kernels
+ * and neighbour messages need no host synchronisation between them. The handle does not take ownership. */
+wgs_status wgs_set_stream(wgs_data *data, void *hip_stream);
+/* All of the following are ASYNCHRONOUS (stream-ordered) and fixed-capacity: buffers are device memory of
+ * header + capacity_records * record bytes; the record count travels in the header. Overflowing a buffer or
+ * the particle capacity is reported by the next wgs_sync(). */
+/* sort, CDF, P2G, gather of the partial node sums */
 wgs_status wgs_shard_step_begin(wgs_pipeline *pipeline, wgs_data *data);
-/* partial sums of the active blocks of layer `layer_bx` (= this rank's block_hi, or its block_lo) into a device
- * buffer of capacity_records records; *count is valid on return (blocking) */
-wgs_status wgs_shard_pack_halo(wgs_data *data, int32_t layer_bx, void *device_buf, uint32_t capacity_records, uint32_t *count);
-/* add a neighbour's partial sums (stream-ordered) */
-wgs_status wgs_shard_add_halo(wgs_data *data, const void *device_buf, uint32_t count);
-/* grid update + fused G2P / particle update (asynchronous) */
+/* partial sums of the active blocks of layer `layer_bx` (= this rank's block_hi, or its block_lo) */
+wgs_status wgs_shard_pack_halo(wgs_data *data, int32_t layer_bx, void *device_buf, uint32_t capacity_records);
+/* add a neighbour's partial sums */
+wgs_status wgs_shard_add_halo(wgs_data *data, const void *device_buf, uint32_t capacity_records);
+/* grid update + fused G2P / particle update */
 wgs_status wgs_shard_step_end(wgs_pipeline *pipeline, wgs_data *data);
-/* particles that left [block_lo, block_hi): counts[0] crossed the lower face (-> dev_lo), counts[1] the upper one (blocking) */
-wgs_status wgs_shard_pack_migrants(wgs_data *data, void *dev_lo, void *dev_hi, uint32_t capacity_records, uint32_t counts[2]);
-wgs_status wgs_shard_add_migrants(wgs_data *data, const void *device_buf, uint32_t count);
-/* full records of every particle currently owned (read-back of a sharded run; blocking) */
+/* particles that left [block_lo, block_hi): those that crossed the lower face -> dev_lo, the upper face -> dev_hi */
+wgs_status wgs_shard_pack_migrants(wgs_data *data, void *dev_lo, void *dev_hi, uint32_t capacity_records);
+/* append the particles received from the lower / upper neighbour (either may be NULL) and update the device-side
+ * counts; out_lo / out_hi are the buffers this rank packed in the same round (NULL where there is no neighbour) */
+wgs_status wgs_shard_add_migrants(wgs_data *data, const void *in_lo, const void *in_hi, const void *out_lo,
+                                  const void *out_hi, uint32_t capacity_records);
+/* full records of every particle currently owned (read-back of a sharded run; BLOCKING) */
 wgs_status wgs_shard_export(wgs_data *data, void *device_buf, uint32_t capacity_records, uint32_t *count);
 
 #ifdef __cplusplus

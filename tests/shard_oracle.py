@@ -86,7 +86,11 @@ class OracleShard:
         self._make_state(arrs, aff)
         return tuple(torch.from_numpy(np.ascontiguousarray(o.reshape(-1))) for o in out)
 
-    def add_migrants(self, recs):
+    def add_migrants(self, in_lower, in_upper):
+        for recs in (in_lower, in_upper):
+            self._add_migrants(recs)
+
+    def _add_migrants(self, recs):
         if recs is None or recs.numel() == 0:
             return
         a = self.st.arr

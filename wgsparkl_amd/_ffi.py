@@ -22,6 +22,7 @@ EXPORTS = (
     "wgs_read_grid", "wgs_read_blocks", "wgs_read_timings", "wgs_get_stats",
     # multi-GPU (x-slab decomposition; new design, no reference counterpart)
     "wgs_data_create_sharded", "wgs_shard_halo_record_bytes", "wgs_shard_particle_record_bytes",
+    "wgs_shard_buffer_header_bytes", "wgs_set_stream",
     "wgs_shard_step_begin", "wgs_shard_pack_halo", "wgs_shard_add_halo", "wgs_shard_step_end",
     "wgs_shard_pack_migrants", "wgs_shard_add_migrants", "wgs_shard_export",
 )
@@ -152,10 +153,12 @@ def load(dim: int):
     lib.wgs_shard_particle_record_bytes.restype = C.c_uint32
     lib.wgs_shard_step_begin.argtypes = [vp, vp]
     lib.wgs_shard_step_end.argtypes = [vp, vp]
-    lib.wgs_shard_pack_halo.argtypes = [vp, C.c_int32, vp, C.c_uint32, u32p]
+    lib.wgs_shard_buffer_header_bytes.restype = C.c_uint32
+    lib.wgs_set_stream.argtypes = [vp, vp]
+    lib.wgs_shard_pack_halo.argtypes = [vp, C.c_int32, vp, C.c_uint32]
     lib.wgs_shard_add_halo.argtypes = [vp, vp, C.c_uint32]
-    lib.wgs_shard_pack_migrants.argtypes = [vp, vp, vp, C.c_uint32, u32p]
-    lib.wgs_shard_add_migrants.argtypes = [vp, vp, C.c_uint32]
+    lib.wgs_shard_pack_migrants.argtypes = [vp, vp, vp, C.c_uint32]
+    lib.wgs_shard_add_migrants.argtypes = [vp, vp, vp, vp, vp, C.c_uint32]
     lib.wgs_shard_export.argtypes = [vp, vp, C.c_uint32, u32p]
     for name in EXPORTS:
         fn = getattr(lib, name)

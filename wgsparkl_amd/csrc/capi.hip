@@ -65,6 +65,7 @@ struct wgs_pipeline {
 struct wgs_data {
     wgs_pipeline *pipeline = nullptr;
     hipStream_t stream = nullptr;
+    bool owns_stream = true;
     Dev dev{};
     int side = 0;
     bool plastic = false;
@@ -272,6 +273,8 @@ wgs_status fetch_counters(wgs_data *d) {
 wgs_status sticky_status(wgs_data *d) {
     if (d->sticky_errors & ERRBIT_OVERFLOW)
         return fail(WGS_ERR_GRID_OVERFLOW, "sparse grid overflow: more active blocks than grid_capacity");
+    if (d->sticky_errors & ERRBIT_SHARD)
+        return fail(WGS_ERR_INVALID_ARGUMENT, "sharded run: a halo / migration buffer or the particle capacity overflowed");
     if (d->sticky_errors & ERRBIT_KEYRANGE)
         return fail(WGS_ERR_KEY_RANGE, "a particle left the packed block-key range (grid.wgsl:88-95)");
     return WGS_OK;
@@ -575,6 +578,12 @@ static wgs_status create_impl(wgs_pipeline *pipeline, const wgs_sim_params *para
     for (int k = 0; k < D; k++) d->host_sp.gravity[k] = params->gravity[k];
     d->host_sp.dt = params->dt;
     H2D(d->sp, &d->host_sp, sizeof(SimParamsDev));
+    if (sharded) {
+        // counts live on the device; the host-side n / nv become the launch bound (allocated capacity)
+        uint32_t cnt[2] = {n, n};
+        H2D(dev.counters + CTR_N, cnt, sizeof(cnt));
+        dev.n = dev.nv = (uint32_t)particle_capacity;
+    }
     d->host_colliders.resize(WGS_MAX_COLLIDERS);
     memset(d->host_colliders.data(), 0, sizeof(ColliderDev) * WGS_MAX_COLLIDERS);
     for (size_t i = 0; i < num_colliders; i++) fill_collider(d->host_colliders[i], colliders[i]);
@@ -604,6 +613,17 @@ wgs_status wgs_data_create_sharded(wgs_pipeline *pipeline, const wgs_sim_params 
 
 uint32_t wgs_shard_halo_record_bytes(void) { return (uint32_t)(HaloCfg<D>::REC_F4 * sizeof(float4)); }
 uint32_t wgs_shard_particle_record_bytes(void) { return (uint32_t)(particle_record_floats<D>() * sizeof(float)); }
+uint32_t wgs_shard_buffer_header_bytes(void) { return 16u; }
+
+wgs_status wgs_set_stream(wgs_data *d, void *hip_stream) {
+    if (!d) return fail(WGS_ERR_INVALID_ARGUMENT, "data is NULL");
+    HIP_TRY(hipSetDevice(d->pipeline->device));
+    HIP_TRY(hipStreamSynchronize(d->stream));
+    if (d->owns_stream && d->stream) HIP_TRY(hipStreamDestroy(d->stream));
+    d->stream = static_cast<hipStream_t>(hip_stream);
+    d->owns_stream = false;
+    return WGS_OK;
+}
 
 wgs_status wgs_shard_step_begin(wgs_pipeline *pipeline, wgs_data *d) {
     if (!pipeline || !d) return fail(WGS_ERR_INVALID_ARGUMENT, "NULL argument");
@@ -616,71 +636,68 @@ wgs_status wgs_shard_step_end(wgs_pipeline *pipeline, wgs_data *d) {
     if (!pipeline || !d) return fail(WGS_ERR_INVALID_ARGUMENT, "NULL argument");
     if (!d->dev.sharded) return fail(WGS_ERR_INVALID_ARGUMENT, "not a sharded wgs_data");
     HIP_TRY(hipSetDevice(pipeline->device));
-    return enqueue_substep<false>(d, 0, 2);
-}
-
-wgs_status wgs_shard_pack_halo(wgs_data *d, int32_t layer_bx, void *device_buf, uint32_t capacity_records, uint32_t *count) {
-    if (!d || !device_buf || !count) return fail(WGS_ERR_INVALID_ARGUMENT, "NULL argument");
-    HIP_TRY(hipSetDevice(d->pipeline->device));
-    HIP_TRY(hipMemsetAsync(d->shard_counts, 0, sizeof(uint32_t) * 4, d->stream));
-    hipLaunchKernelGGL(k_pack_halo<D>, dim3(grid_for(d, 4)), dim3(64), 0, d->stream, d->dev, layer_bx,
-                       static_cast<float4 *>(device_buf), capacity_records, d->shard_counts);
-    HIP_TRY(hipMemcpyAsync(count, d->shard_counts, sizeof(uint32_t), hipMemcpyDeviceToHost, d->stream));
-    HIP_TRY(hipStreamSynchronize(d->stream));
-    if (*count > capacity_records) return fail(WGS_ERR_INVALID_ARGUMENT, "halo buffer too small");
-    return WGS_OK;
-}
-
-wgs_status wgs_shard_add_halo(wgs_data *d, const void *device_buf, uint32_t count) {
-    if (!d || (!device_buf && count)) return fail(WGS_ERR_INVALID_ARGUMENT, "NULL argument");
-    HIP_TRY(hipSetDevice(d->pipeline->device));
-    if (count == 0) return WGS_OK;
-    const uint32_t epoch = (uint32_t)(d->substeps + 1);
-    hipLaunchKernelGGL(k_add_halo<D>, dim3(count < 4096u ? count : 4096u), dim3(64), 0, d->stream, d->dev,
-                       static_cast<const float4 *>(device_buf), count, epoch);
-    HIP_TRY(hipGetLastError());
-    return WGS_OK;
-}
-
-static wgs_status pack_particles(wgs_data *d, int mode, void *dev_lo, void *dev_hi, uint32_t capacity_records, uint32_t counts[2]) {
-    HIP_TRY(hipSetDevice(d->pipeline->device));
-    HIP_TRY(hipMemsetAsync(d->shard_counts, 0, sizeof(uint32_t) * 4, d->stream));
-    if (d->dev.n > 0)
-        hipLaunchKernelGGL(k_pack_migrants<D>, dim3(grid_for(d, 4)), dim3(256), 0, d->stream, d->dev, d->side, mode,
-                           static_cast<float *>(dev_lo), static_cast<float *>(dev_hi), capacity_records, d->shard_counts);
-    HIP_TRY(hipMemcpyAsync(counts, d->shard_counts, sizeof(uint32_t) * 2, hipMemcpyDeviceToHost, d->stream));
-    HIP_TRY(hipStreamSynchronize(d->stream));
-    if (counts[0] > capacity_records || counts[1] > capacity_records) return fail(WGS_ERR_INVALID_ARGUMENT, "particle buffer too small");
-    return WGS_OK;
-}
-
-wgs_status wgs_shard_pack_migrants(wgs_data *d, void *dev_lo, void *dev_hi, uint32_t capacity_records, uint32_t counts[2]) {
-    if (!d || !dev_lo || !dev_hi || !counts) return fail(WGS_ERR_INVALID_ARGUMENT, "NULL argument");
-    wgs_status st = pack_particles(d, 0, dev_lo, dev_hi, capacity_records, counts);
+    wgs_status st = enqueue_substep<false>(d, 0, 2);
     if (st != WGS_OK) return st;
-    d->dev.nv -= counts[0] + counts[1];  // their slots stay (vacated) until the next substep compacts them away
+    hipLaunchKernelGGL(k_shard_compacted, dim3(1), dim3(64), 0, d->stream, d->dev);
+    HIP_TRY(hipGetLastError());
     return WGS_OK;
 }
 
-wgs_status wgs_shard_add_migrants(wgs_data *d, const void *device_buf, uint32_t count) {
-    if (!d || (!device_buf && count)) return fail(WGS_ERR_INVALID_ARGUMENT, "NULL argument");
+wgs_status wgs_shard_pack_halo(wgs_data *d, int32_t layer_bx, void *device_buf, uint32_t capacity_records) {
+    if (!d || !device_buf) return fail(WGS_ERR_INVALID_ARGUMENT, "NULL argument");
     HIP_TRY(hipSetDevice(d->pipeline->device));
-    if (count == 0) return WGS_OK;
-    if ((uint64_t)d->dev.n + count > d->capacity) return fail(WGS_ERR_INVALID_ARGUMENT, "particle_capacity exceeded by incoming particles");
-    hipLaunchKernelGGL(k_append_migrants<D>, dim3((count + 255) / 256), dim3(256), 0, d->stream, d->dev, d->side,
-                       static_cast<const float *>(device_buf), count, d->dev.n);
+    hipLaunchKernelGGL(k_clear_headers, dim3(1), dim3(64), 0, d->stream, static_cast<uint32_t *>(device_buf), (uint32_t *)nullptr);
+    hipLaunchKernelGGL(k_pack_halo<D>, dim3(grid_for(d, 4)), dim3(64), 0, d->stream, d->dev, layer_bx,
+                       static_cast<float4 *>(device_buf), capacity_records);
     HIP_TRY(hipGetLastError());
-    d->dev.n += count;
-    d->dev.nv += count;
+    return WGS_OK;
+}
+
+wgs_status wgs_shard_add_halo(wgs_data *d, const void *device_buf, uint32_t capacity_records) {
+    if (!d || !device_buf) return fail(WGS_ERR_INVALID_ARGUMENT, "NULL argument");
+    HIP_TRY(hipSetDevice(d->pipeline->device));
+    const uint32_t epoch = (uint32_t)(d->substeps + 1);
+    const uint32_t g = capacity_records < 2048u ? (capacity_records ? capacity_records : 1u) : 2048u;
+    hipLaunchKernelGGL(k_add_halo<D>, dim3(g), dim3(64), 0, d->stream, d->dev, static_cast<const float4 *>(device_buf),
+                       capacity_records, epoch);
+    HIP_TRY(hipGetLastError());
+    return WGS_OK;
+}
+
+wgs_status wgs_shard_pack_migrants(wgs_data *d, void *dev_lo, void *dev_hi, uint32_t capacity_records) {
+    if (!d || !dev_lo || !dev_hi) return fail(WGS_ERR_INVALID_ARGUMENT, "NULL argument");
+    HIP_TRY(hipSetDevice(d->pipeline->device));
+    hipLaunchKernelGGL(k_clear_headers, dim3(1), dim3(64), 0, d->stream, static_cast<uint32_t *>(dev_lo), static_cast<uint32_t *>(dev_hi));
+    hipLaunchKernelGGL(k_pack_migrants<D>, dim3(grid_for(d, 4)), dim3(256), 0, d->stream, d->dev, d->side, 0,
+                       static_cast<float *>(dev_lo), static_cast<float *>(dev_hi), capacity_records);
+    HIP_TRY(hipGetLastError());
+    return WGS_OK;
+}
+
+wgs_status wgs_shard_add_migrants(wgs_data *d, const void *in_lo, const void *in_hi, const void *out_lo, const void *out_hi,
+                                  uint32_t capacity_records) {
+    if (!d) return fail(WGS_ERR_INVALID_ARGUMENT, "NULL argument");
+    HIP_TRY(hipSetDevice(d->pipeline->device));
+    if (in_lo || in_hi)
+        hipLaunchKernelGGL(k_append_migrants<D>, dim3((2 * capacity_records + 255) / 256), dim3(256), 0, d->stream, d->dev,
+                           d->side, static_cast<const float *>(in_lo), static_cast<const float *>(in_hi), capacity_records);
+    hipLaunchKernelGGL(k_shard_counts, dim3(1), dim3(64), 0, d->stream, d->dev, static_cast<const float *>(in_lo),
+                       static_cast<const float *>(in_hi), static_cast<const float *>(out_lo), static_cast<const float *>(out_hi),
+                       capacity_records);
+    HIP_TRY(hipGetLastError());
     return WGS_OK;
 }
 
 wgs_status wgs_shard_export(wgs_data *d, void *device_buf, uint32_t capacity_records, uint32_t *count) {
     if (!d || !device_buf || !count) return fail(WGS_ERR_INVALID_ARGUMENT, "NULL argument");
-    uint32_t counts[2] = {0, 0};
-    wgs_status st = pack_particles(d, 1, device_buf, device_buf, capacity_records, counts);
-    *count = counts[0];
-    return st;
+    HIP_TRY(hipSetDevice(d->pipeline->device));
+    hipLaunchKernelGGL(k_clear_headers, dim3(1), dim3(64), 0, d->stream, static_cast<uint32_t *>(device_buf), (uint32_t *)nullptr);
+    hipLaunchKernelGGL(k_pack_migrants<D>, dim3(grid_for(d, 4)), dim3(256), 0, d->stream, d->dev, d->side, 1,
+                       static_cast<float *>(device_buf), static_cast<float *>(device_buf), capacity_records);
+    HIP_TRY(hipMemcpyAsync(count, device_buf, sizeof(uint32_t), hipMemcpyDeviceToHost, d->stream));
+    HIP_TRY(hipStreamSynchronize(d->stream));
+    if (*count > capacity_records) return fail(WGS_ERR_INVALID_ARGUMENT, "export buffer too small");
+    return WGS_OK;
 }
 
 void wgs_data_destroy(wgs_data *d) {
@@ -690,7 +707,7 @@ void wgs_data_destroy(wgs_data *d) {
         for (int s = 0; s < Events::MAX_SUBSTEPS; s++)
             for (int m = 0; m < Events::MARKS; m++) hipEventDestroy(d->events.ev[s][m]);
     for (void *p : d->allocs) hipFree(p);
-    if (d->stream) hipStreamDestroy(d->stream);
+    if (d->stream && d->owns_stream) hipStreamDestroy(d->stream);
     delete d;
 }
 
@@ -771,6 +788,7 @@ wgs_status wgs_set_body_velocities(wgs_data *d, const wgs_velocity *vels, size_t
 
 wgs_status wgs_read_positions(wgs_data *d, float *out) {
     if (!d || !out) return fail(WGS_ERR_INVALID_ARGUMENT, "NULL argument");
+    if (d->dev.sharded) return fail(WGS_ERR_UNSUPPORTED, "sharded wgs_data: use wgs_shard_export");
     HIP_TRY(hipSetDevice(d->pipeline->device));
     if (d->dev.n == 0) return WGS_OK;
     float *tmp = nullptr;
@@ -786,6 +804,7 @@ wgs_status wgs_read_positions(wgs_data *d, float *out) {
 
 wgs_status wgs_read_particles(wgs_data *d, wgs_particle *out, wgs_plastic_state *plastic_out) {
     if (!d || !out) return fail(WGS_ERR_INVALID_ARGUMENT, "NULL argument");
+    if (d->dev.sharded) return fail(WGS_ERR_UNSUPPORTED, "sharded wgs_data: use wgs_shard_export");
     HIP_TRY(hipSetDevice(d->pipeline->device));
     const uint32_t n = d->dev.n;
     if (n == 0) return WGS_OK;
@@ -879,6 +898,10 @@ wgs_status wgs_get_stats(wgs_data *d, wgs_stats *out) {
     wgs_status st = fetch_counters(d);
     if (st != WGS_OK) return st;
     out->num_particles = d->dev.n;
+    if (d->dev.sharded) {
+        HIP_TRY(hipMemcpyAsync(&out->num_particles, d->dev.counters + CTR_NV, sizeof(uint32_t), hipMemcpyDeviceToHost, d->stream));
+        HIP_TRY(hipStreamSynchronize(d->stream));
+    }
     out->num_active_blocks = d->last_nblocks;
     out->grid_capacity = d->dev.cap;
     out->overflow = d->sticky_errors;

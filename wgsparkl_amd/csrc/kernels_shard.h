@@ -9,6 +9,9 @@
 //      hold identical totals and run the grid update redundantly on those nodes;
 //   2. after the particle update: particles whose associated block left the rank's range
 //      (at most one block per substep because of the h/dt velocity clamps) move, full state.
+// Everything is stream-ordered: messages are fixed-capacity buffers whose first 16 bytes hold
+// the record count, particle counts live in device counters, so a substep needs no host
+// synchronisation (overflow of a buffer sets ERRBIT_SHARD, seen at the next wgs_sync).
 #pragma once
 #include "device_math.h"
 
@@ -29,9 +32,19 @@ template <int D> __device__ inline uint32_t halo_node(int q) {
     return (uint32_t)(lx + (ly << BS) + (D == 3 ? (lz << (2 * BS)) : 0));
 }
 
+__global__ void k_clear_headers(uint32_t *a, uint32_t *b) {
+    if (threadIdx.x == 0) {
+        if (a) a[0] = 0;
+        if (b) b[0] = 0;
+    }
+}
+
 // Pack the partial sums of the interface layer `layer_bx` (active blocks only).
-template <int D> __global__ __launch_bounds__(64) void k_pack_halo(Dev d, int layer_bx, float4 *out, uint32_t cap, uint32_t *count) {
+// buf = [count, -, -, -] + cap records of REC_F4 float4.
+template <int D> __global__ __launch_bounds__(64) void k_pack_halo(Dev d, int layer_bx, float4 *buf, uint32_t cap) {
     using H = HaloCfg<D>;
+    uint32_t *count = reinterpret_cast<uint32_t *>(buf);
+    float4 *out = buf + 1;
     const uint32_t B = min(d.counters[CTR_NBLOCKS], d.cap);
     const int lane = threadIdx.x;
     for (uint32_t a = blockIdx.x; a < B; a += gridDim.x) {
@@ -42,7 +55,10 @@ template <int D> __global__ __launch_bounds__(64) void k_pack_halo(Dev d, int la
         uint32_t slot = 0;
         if (lane == 0) slot = atomicAdd(count, 1u);
         slot = __shfl(slot, 0);
-        if (slot >= cap) continue;  // reported by the host through *count > cap
+        if (slot >= cap) {
+            if (lane == 0) atomicOr(&d.counters[CTR_ERRORS], ERRBIT_SHARD);
+            continue;
+        }
         float4 *rec = out + (size_t)slot * H::REC_F4;
         if (lane == 0) rec[0] = make_float4(__uint_as_float(d.block_key[b]), 0.f, 0.f, 0.f);
         if (lane < H::NODES) rec[1 + lane] = d.nodes[(size_t)b * NPB + halo_node<D>(lane)];
@@ -50,8 +66,10 @@ template <int D> __global__ __launch_bounds__(64) void k_pack_halo(Dev d, int la
 }
 
 // Add a neighbour's partial sums to the blocks this rank has active.
-template <int D> __global__ __launch_bounds__(64) void k_add_halo(Dev d, const float4 *in, uint32_t n_rec, uint32_t epoch) {
+template <int D> __global__ __launch_bounds__(64) void k_add_halo(Dev d, const float4 *buf, uint32_t cap, uint32_t epoch) {
     using H = HaloCfg<D>;
+    const uint32_t n_rec = min(reinterpret_cast<const uint32_t *>(buf)[0], cap);
+    const float4 *in = buf + 1;
     const int lane = threadIdx.x;
     for (uint32_t r = blockIdx.x; r < n_rec; r += gridDim.x) {
         const float4 *rec = in + (size_t)r * H::REC_F4;
@@ -66,17 +84,20 @@ template <int D> __global__ __launch_bounds__(64) void k_add_halo(Dev d, const f
     }
 }
 
-// Full-state record of one particle: NQ quads + pid.
+// Full-state record of one particle: NQ quads + pid. A particle buffer = 4 header floats
+// ([count, -, -, -]) + cap records.
 template <int D> constexpr int particle_record_floats() { return Pl<D>::NQ * 4 + 1; }
 
 // Particles whose associated block left [shard_lo, shard_hi): copy them to the outbox of the face
 // they crossed and vacate their slot. mode 1 = export every valid particle instead (read-back).
-template <int D> __global__ __launch_bounds__(256) void k_pack_migrants(Dev d, int side, int mode, float *out_lo, float *out_hi,
-                                                                        uint32_t cap, uint32_t *counts) {
+template <int D> __global__ __launch_bounds__(256) void k_pack_migrants(Dev d, int side, int mode, float *buf_lo, float *buf_hi, uint32_t cap) {
     constexpr int BS = Dim<D>::BSHIFT, NQ = Pl<D>::NQ, RF = particle_record_floats<D>();
     float *buf = d.buf[side];
     const uint32_t npad = d.npad;
-    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < d.n; i += gridDim.x * 256) {
+    // right after a substep (mode 0) the buffer holds the valid particles only; a read-back (mode 1) may come
+    // after a migration round, when vacated slots and appended particles coexist
+    const uint32_t n = mode == 1 ? num_slots(d) : num_valid(d);
+    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
         const uint32_t pid = ldpid<D>(buf, npad, i);
         if (pid == PID_DEAD) continue;
         int face = -1;
@@ -89,31 +110,56 @@ template <int D> __global__ __launch_bounds__(256) void k_pack_migrants(Dev d, i
             else if (bx >= d.shard_hi) face = 1;
         }
         if (face < 0) continue;
-        const uint32_t slot = atomicAdd(&counts[face], 1u);  // a handful of particles per substep
+        float *ob = face ? buf_hi : buf_lo;
+        const uint32_t slot = atomicAdd(reinterpret_cast<uint32_t *>(ob), 1u);  // a handful of particles per substep
         if (slot < cap) {
-            float *rec = (face ? out_hi : out_lo) + (size_t)slot * RF;
+            float *rec = ob + 4 + (size_t)slot * RF;
 #pragma unroll
             for (int q = 0; q < NQ; q++) {
                 const float4 v = ldq(buf, npad, q, i);
                 rec[q * 4 + 0] = v.x; rec[q * 4 + 1] = v.y; rec[q * 4 + 2] = v.z; rec[q * 4 + 3] = v.w;
             }
             rec[NQ * 4] = __uint_as_float(pid);
+            if (mode == 0) stpid<D>(buf, npad, i, PID_DEAD);
+        } else {
+            atomicOr(&d.counters[CTR_ERRORS], ERRBIT_SHARD);  // the particle stays here: wrong physics, reported
         }
-        if (mode == 0) stpid<D>(buf, npad, i, PID_DEAD);
     }
 }
 
-// Append received particles after the current ones.
-template <int D> __global__ __launch_bounds__(256) void k_append_migrants(Dev d, int side, const float *in, uint32_t n_rec, uint32_t first_slot) {
+// Append the particles received from both neighbours after the current ones.
+template <int D> __global__ __launch_bounds__(256) void k_append_migrants(Dev d, int side, const float *in_lo, const float *in_hi, uint32_t cap) {
     constexpr int NQ = Pl<D>::NQ, RF = particle_record_floats<D>();
     float *buf = d.buf[side];
-    for (uint32_t r = blockIdx.x * 256 + threadIdx.x; r < n_rec; r += gridDim.x * 256) {
-        const float *rec = in + (size_t)r * RF;
-        const uint32_t i = first_slot + r;
+    const uint32_t n_lo = in_lo ? min(reinterpret_cast<const uint32_t *>(in_lo)[0], cap) : 0u;
+    const uint32_t n_hi = in_hi ? min(reinterpret_cast<const uint32_t *>(in_hi)[0], cap) : 0u;
+    const uint32_t first = num_valid(d);  // == slots right after a substep
+    for (uint32_t r = blockIdx.x * 256 + threadIdx.x; r < n_lo + n_hi; r += gridDim.x * 256) {
+        const float *rec = r < n_lo ? in_lo + 4 + (size_t)r * RF : in_hi + 4 + (size_t)(r - n_lo) * RF;
+        const uint32_t i = first + r;
+        if (i >= d.n) {  // d.n = allocated capacity in sharded mode
+            atomicOr(&d.counters[CTR_ERRORS], ERRBIT_SHARD);
+            continue;
+        }
 #pragma unroll
         for (int q = 0; q < NQ; q++) stq(buf, d.npad, q, i, make_float4(rec[q * 4], rec[q * 4 + 1], rec[q * 4 + 2], rec[q * 4 + 3]));
         stpid<D>(buf, d.npad, i, __float_as_uint(rec[NQ * 4]));
     }
+}
+
+// Bookkeeping after a migration round (one thread): slots = old valid + arrivals, valid = old valid - departures + arrivals.
+__global__ void k_shard_counts(Dev d, const float *in_lo, const float *in_hi, const float *out_lo, const float *out_hi, uint32_t cap) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    auto cnt = [&](const float *b) { return b ? min(reinterpret_cast<const uint32_t *>(b)[0], cap) : 0u; };
+    const uint32_t nv = d.counters[CTR_NV];
+    const uint32_t arrivals = min(cnt(in_lo) + cnt(in_hi), d.n - nv);
+    d.counters[CTR_N] = nv + arrivals;
+    d.counters[CTR_NV] = nv - cnt(out_lo) - cnt(out_hi) + arrivals;
+}
+
+// After the fused G2P kernel the other buffer holds exactly the valid particles, in sorted order.
+__global__ void k_shard_compacted(Dev d) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) d.counters[CTR_N] = d.counters[CTR_NV];
 }
 
 }  // namespace wgs

@@ -42,7 +42,7 @@ template <int D> __global__ __launch_bounds__(SORT_THREADS) void k_bin(Dev d, in
     if (tid < TOUCH_SET) s_keys[tid] = NONE;
     __syncthreads();
     const uint32_t i = blockIdx.x * SORT_THREADS + tid;
-    bool valid = i < d.n;
+    bool valid = i < num_slots(d);
     if (d.sharded && valid) valid = ldpid<D>(in, d.npad, i) != 0xffffffffu;  // slot vacated by a migrated particle
     int b[3] = {0, 0, 0};
     uint32_t key = NONE, local = 0;
@@ -149,7 +149,7 @@ template <int D> __global__ __launch_bounds__(SORT_THREADS) void k_bin(Dev d, in
             rank = __hip_atomic_load(&hist[local], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT) + r;
         }
     }
-    if (i < d.n) {
+    if (i < num_slots(d)) {
         d.cellid[i] = cid;
         d.rank[i] = rank;
     }
@@ -259,7 +259,7 @@ template <int D> __global__ __launch_bounds__(SORT_THREADS) void k_block_setup(D
 // pass reads them contiguously instead of gathering through `perm`.
 template <int D> __global__ __launch_bounds__(SORT_THREADS) void k_scatter(Dev d, int side) {
     uint32_t i = blockIdx.x * SORT_THREADS + threadIdx.x;
-    if (i >= d.n) return;
+    if (i >= num_slots(d)) return;
     uint32_t cid = d.cellid[i];
     if (cid == NONE) return;
     const uint32_t r = d.cell_start[cid] + d.rank[i];

@@ -330,7 +330,7 @@ __global__ __launch_bounds__(G2P_THREADS, G2P_WAVES_PER_EU) void k_g2p_update(De
     const uint32_t per_xcd = gridDim.x >> 3;
     const uint32_t chunk = (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
     const uint32_t j = chunk * G2P_THREADS + tid;  // slot in sorted order = output index
-    const bool valid = j < d.nv;
+    const bool valid = j < num_valid(d);
     const uint32_t src = valid ? d.perm[j] : 0u;
     const uint32_t cid = valid ? d.perm_cell[j] : NONE;  // physical block id * 64 + cell in block
     uint32_t myblock = cid == NONE ? NONE : (cid >> 6);

@@ -89,11 +89,14 @@ struct NodeCdf {        // grid.wgsl:233-240
 };
 
 // Counter slots in Dev::counters
-enum { CTR_NBLOCKS = 0, CTR_ERRORS = 1, CTR_NPHYS = 2, CTR_NCPIC = 3, CTR_COUNT = 8 };
-enum { ERRBIT_OVERFLOW = 1u, ERRBIT_KEYRANGE = 2u };
+enum { CTR_NBLOCKS = 0, CTR_ERRORS = 1, CTR_NPHYS = 2, CTR_NCPIC = 3, CTR_N = 4, CTR_NV = 5, CTR_COUNT = 8 };
+enum { ERRBIT_OVERFLOW = 1u, ERRBIT_KEYRANGE = 2u, ERRBIT_SHARD = 4u };
 
 // Everything a kernel needs, passed by value.
 struct Dev {
+    // Particle counts. Single GPU: fixed, passed by value. Sharded: they change every substep with the
+    // migrating particles and live in counters[CTR_N / CTR_NV] so that nothing on the step path needs the
+    // host; n / nv then hold the allocated capacity (launch bound). Use num_slots() / num_valid().
     uint32_t n;          // particle slots in the current buffer (valid + vacated)
     uint32_t nv;         // valid particles = sorted slots (== n unless sharded and particles migrated)
     uint32_t sharded;    // 1: x-slab decomposition (kernels_shard.h)
@@ -137,6 +140,9 @@ struct Dev {
     int model;           // WGS_MODEL_*
     uint32_t dbg;        // debug/ablation switches (env WGS_DEBUG), 0 in production
 };
+
+__device__ inline uint32_t num_slots(const Dev &d) { return d.sharded ? d.counters[CTR_N] : d.n; }
+__device__ inline uint32_t num_valid(const Dev &d) { return d.sharded ? d.counters[CTR_NV] : d.nv; }
 
 // Quad access = (one uniform 64-bit buffer base in SGPRs) + (32-bit per-lane byte offset):
 // `global_load_dwordx4 v[..], v_off, s[base:base+1]`. Valid while one ping-pong buffer is

@@ -75,7 +75,7 @@ def associated_block_x(pos: np.ndarray, cell_width: float, dim: int) -> np.ndarr
 # ------------------------------------------------------------------------------------------------
 def substep_phases(backend, exchange):
     """One substep of one rank. `exchange(to_lower, to_upper) -> (from_lower, from_upper)` moves opaque
-    record arrays between neighbours (None where there is no neighbour)."""
+    record buffers between neighbours (None where there is no neighbour)."""
     lo, hi = backend.block_lo, backend.block_hi
     backend.step_begin()
     to_lower = backend.pack_halo(lo) if backend.has_lower else None
@@ -88,10 +88,7 @@ def substep_phases(backend, exchange):
     backend.step_end()
     out_lower, out_upper = backend.pack_migrants()
     in_lower, in_upper = exchange(out_lower if backend.has_lower else None, out_upper if backend.has_upper else None)
-    if in_lower is not None:
-        backend.add_migrants(in_lower)
-    if in_upper is not None:
-        backend.add_migrants(in_upper)
+    backend.add_migrants(in_lower, in_upper)
 
 
 def lockstep_substep(backends: List):
@@ -111,10 +108,34 @@ def lockstep_substep(backends: List):
         b.step_end()
     mig = [b.pack_migrants() for b in backends]
     for r, b in enumerate(backends):
-        if r > 0:
-            b.add_migrants(mig[r - 1][1])
-        if r < n - 1:
-            b.add_migrants(mig[r + 1][0])
+        b.add_migrants(mig[r - 1][1] if r > 0 else None, mig[r + 1][0] if r < n - 1 else None)
+
+
+class FixedExchange:
+    """Neighbour exchange of FIXED-SIZE device buffers (the record count travels inside the buffer), one
+    send + one receive per neighbour, no size handshake and no host synchronisation: the point-to-point
+    ops are ordered on the current stream like the kernels. torch.distributed "nccl" = RCCL on ROCm; the
+    two neighbours are distinct peers, so each message rides its own xGMI link."""
+
+    def __init__(self, dist, rank: int, world: int):
+        import torch
+        self.torch, self.dist, self.rank, self.world = torch, dist, rank, world
+
+    def __call__(self, to_lower, to_upper):
+        torch, dist = self.torch, self.dist
+        lower = self.rank - 1 if self.rank > 0 else None
+        upper = self.rank + 1 if self.rank < self.world - 1 else None
+        ops, from_lower, from_upper = [], None, None
+        if lower is not None and to_lower is not None:
+            from_lower = torch.empty_like(to_lower)
+            ops += [dist.P2POp(dist.isend, to_lower, lower), dist.P2POp(dist.irecv, from_lower, lower)]
+        if upper is not None and to_upper is not None:
+            from_upper = torch.empty_like(to_upper)
+            ops += [dist.P2POp(dist.isend, to_upper, upper), dist.P2POp(dist.irecv, from_upper, upper)]
+        if ops:
+            for w in dist.batch_isend_irecv(ops):
+                w.wait()     # stream-level wait on NCCL/RCCL (does not block the host)
+        return from_lower, from_upper
 
 
 class DistExchange:
@@ -197,50 +218,50 @@ class GpuShard:
             _ffi.check(self.lib, self.lib.wgs_set_constitutive_model(self._h, int(model)))
         self.halo_rec = self.lib.wgs_shard_halo_record_bytes() // 4
         self.part_rec = self.lib.wgs_shard_particle_record_bytes() // 4
+        self.hdr = self.lib.wgs_shard_buffer_header_bytes() // 4
         self.capacity = cap
         dev = torch.device("cuda", pipeline.device)
         self.device = dev
-        self.halo_cap = int(halo_capacity_blocks) or int(grid_capacity)
-        self.mig_cap = int(migrant_capacity) or max(4096, cap // 16)
+        # Same capacities on every rank: the messages are fixed-size (count in the header).
+        self.halo_cap = int(halo_capacity_blocks) or 4096
+        self.mig_cap = int(migrant_capacity) or 4096
         f32 = torch.float32
-        self._halo_out = [torch.empty(self.halo_cap * self.halo_rec, dtype=f32, device=dev) for _ in range(2)]
-        self._mig_out = [torch.empty(self.mig_cap * self.part_rec, dtype=f32, device=dev) for _ in range(2)]
+        self._halo_out = [torch.zeros(self.hdr + self.halo_cap * self.halo_rec, dtype=f32, device=dev) for _ in range(2)]
+        self._mig_out = [torch.zeros(self.hdr + self.mig_cap * self.part_rec, dtype=f32, device=dev) for _ in range(2)]
         self._keep = []   # received tensors stay alive until the stream has consumed them
+        # kernels and RCCL messages are ordered on torch's current stream: no host sync inside a substep
+        _ffi.check(self.lib, self.lib.wgs_set_stream(self._h, C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)))
 
-    # -- protocol
+    # -- protocol (all asynchronous)
     def step_begin(self):
-        self._keep.clear()
+        self._keep = self._keep[-8:]
         _ffi.check(self.lib, self.lib.wgs_shard_step_begin(self.pipeline._h, self._h))
 
     def pack_halo(self, layer_bx: int):
         buf = self._halo_out[0 if layer_bx == self.block_lo else 1]
-        cnt = C.c_uint32(0)
-        _ffi.check(self.lib, self.lib.wgs_shard_pack_halo(self._h, int(layer_bx), C.c_void_p(buf.data_ptr()), self.halo_cap,
-                                                           C.byref(cnt)))
-        return buf[: cnt.value * self.halo_rec]
+        _ffi.check(self.lib, self.lib.wgs_shard_pack_halo(self._h, int(layer_bx), C.c_void_p(buf.data_ptr()), self.halo_cap))
+        return buf
 
-    def add_halo(self, recs):
-        if recs is None or recs.numel() == 0:
+    def add_halo(self, buf):
+        if buf is None:
             return
-        recs = recs.to(self.device).contiguous()
-        self._keep.append(recs)
-        _ffi.check(self.lib, self.lib.wgs_shard_add_halo(self._h, C.c_void_p(recs.data_ptr()), recs.numel() // self.halo_rec))
+        self._keep.append(buf)
+        _ffi.check(self.lib, self.lib.wgs_shard_add_halo(self._h, C.c_void_p(buf.data_ptr()), self.halo_cap))
 
     def step_end(self):
         _ffi.check(self.lib, self.lib.wgs_shard_step_end(self.pipeline._h, self._h))
 
     def pack_migrants(self):
-        counts = (C.c_uint32 * 2)()
         _ffi.check(self.lib, self.lib.wgs_shard_pack_migrants(self._h, C.c_void_p(self._mig_out[0].data_ptr()),
-                                                               C.c_void_p(self._mig_out[1].data_ptr()), self.mig_cap, counts))
-        return (self._mig_out[0][: counts[0] * self.part_rec], self._mig_out[1][: counts[1] * self.part_rec])
+                                                               C.c_void_p(self._mig_out[1].data_ptr()), self.mig_cap))
+        return self._mig_out[0], self._mig_out[1]
 
-    def add_migrants(self, recs):
-        if recs is None or recs.numel() == 0:
-            return
-        recs = recs.to(self.device).contiguous()
-        self._keep.append(recs)
-        _ffi.check(self.lib, self.lib.wgs_shard_add_migrants(self._h, C.c_void_p(recs.data_ptr()), recs.numel() // self.part_rec))
+    def add_migrants(self, in_lower, in_upper):
+        ptr = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
+        self._keep += [t for t in (in_lower, in_upper) if t is not None]
+        _ffi.check(self.lib, self.lib.wgs_shard_add_migrants(
+            self._h, ptr(in_lower), ptr(in_upper), ptr(self._mig_out[0]) if self.has_lower else None,
+            ptr(self._mig_out[1]) if self.has_upper else None, self.mig_cap))
 
     # -- host side
     def sync(self):
@@ -252,12 +273,12 @@ class GpuShard:
         return int(s.num_particles)
 
     def export(self):
-        """(global ids, pos, vel, def_grad, affine, mass) of the particles this rank owns now."""
+        """(global ids, pos, vel, def_grad, affine, mass) of the particles this rank owns now (blocking)."""
         torch = self.torch
-        buf = torch.empty(self.capacity * self.part_rec, dtype=torch.float32, device=self.device)
+        buf = torch.zeros(self.hdr + self.capacity * self.part_rec, dtype=torch.float32, device=self.device)
         cnt = C.c_uint32(0)
         _ffi.check(self.lib, self.lib.wgs_shard_export(self._h, C.c_void_p(buf.data_ptr()), self.capacity, C.byref(cnt)))
-        rec = buf[: cnt.value * self.part_rec].cpu().numpy().reshape(cnt.value, self.part_rec)
+        rec = buf[self.hdr: self.hdr + cnt.value * self.part_rec].cpu().numpy().reshape(cnt.value, self.part_rec)
         return unpack_records(rec, self.dim)
 
     def close(self):
