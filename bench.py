@@ -8,9 +8,10 @@ lattice + jitter. One "step" = one substep of MpmPipeline::queue_step
 
   python bench.py --gpus N --steps K --warmup W
 
-N > 1: one process per GPU (torch.distributed / RCCL for the barrier + max over
-ranks). Round 1 runs one independent slab per rank (weak scaling, no exchange yet;
-DESIGN.md §7 has the halo design).
+N > 1: one process per GPU (torch.distributed, backend nccl = RCCL). Weak scaling: N cubes side
+by side form one bar, cut into x-slabs; per substep each rank swaps the partial node sums of
+the interface layers and the migrating particles with its two neighbours (point-to-point over
+xGMI, no collective on the data path; wgsparkl_amd/sharded.py).
 """
 import argparse
 import json
@@ -55,19 +56,19 @@ def main():
     dist = None
     if world > 1:
         import torch.distributed as dist
+        # WGS_BENCH_ONE_GPU=1: functional test of the N > 1 path on a 1-GPU box (all ranks on cuda:0, gloo)
+        one_gpu = os.environ.get("WGS_BENCH_ONE_GPU") == "1"
+        if one_gpu:
+            local_rank = 0
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if one_gpu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     dev_index = local_rank if world > 1 else 0
 
     import numpy as np
     from wgsparkl_amd import MpmData, MpmPipeline, scenes
-
-    scene = scenes.neo_hookean_cube(n_side=args.n_side, with_floor=not args.no_floor)
-    ps = scene["particles"]
-    n = ps.n
-    pipe = MpmPipeline(dev_index, 3)
-    data = MpmData.new(pipe, scene["params"], ps, scene["colliders"], scene["cell_width"],
-                       scene["grid_capacity"], scene["model"])
 
     def barrier():
         torch.cuda.synchronize()
@@ -75,29 +76,78 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    pipe.step(data, args.warmup)
-    data.sync()
+    pipe = MpmPipeline(dev_index, 3)
+    if world == 1:
+        scene = scenes.neo_hookean_cube(n_side=args.n_side, with_floor=not args.no_floor)
+        ps = scene["particles"]
+        n = ps.n
+        n_total = n
+        data = MpmData.new(pipe, scene["params"], ps, scene["colliders"], scene["cell_width"],
+                           scene["grid_capacity"], scene["model"])
+        run = lambda k: pipe.step(data, k)          # K substeps enqueued asynchronously
+        sync = data.sync
+        parallelism = "1 GPU"
+    else:
+        # Weak scaling: `world` C2 cubes side by side along x form one elastic bar; x-slab domain
+        # decomposition, one slab per GPU, halo + migration exchanges over RCCL point-to-point (sharded.py).
+        from wgsparkl_amd.sharded import FixedExchange, GpuShard, substep_phases
+        scene = scenes.neo_hookean_bar(n_side=args.n_side, world=world, rank=rank)
+        if args.no_floor:
+            scene["colliders"] = []
+        ps = scene["particles"]
+        n = ps.n
+        n_total = scene["global_particles"]
+        lo, hi = scene["partition"].block_range(rank)
+        data = GpuShard(pipe, scene["params"], ps, scene["global_ids"], scene["colliders"], scene["cell_width"],
+                        scene["grid_capacity"], lo, hi, rank > 0, rank < world - 1,
+                        particle_capacity=int(n * 1.25) + 4096, model=scene["model"],
+                        halo_capacity_blocks=2048, migrant_capacity=4096)
+        exch = FixedExchange(dist, rank, world)
+
+        def run(k):
+            for _ in range(k):
+                substep_phases(data, exch)
+        sync = data.sync
+        parallelism = f"{world} x-slabs, halo + migration over RCCL p2p"
+
+    run(args.warmup)
+    sync()
     barrier()
     t0 = time.perf_counter()
-    pipe.step(data, args.steps)          # exactly K substeps, enqueued asynchronously
-    data.sync()
+    run(args.steps)                      # exactly K substeps
+    sync()
     barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
         t = torch.tensor([elapsed], device=f"cuda:{local_rank}", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+        cnt = torch.tensor([data.num_particles()], device=f"cuda:{local_rank}", dtype=torch.int64)
+        dist.all_reduce(cnt)
+        assert int(cnt.item()) == n_total, f"particles lost in the exchange: {int(cnt.item())} != {n_total}"
 
-    # Per-pass device times of the same K substeps, HIP events on the data's own stream.
+    # Per-pass device times (HIP events on the data's own stream) of K more substeps of the local slab.
     k_ts = min(args.steps, 64)
-    pipe.step(data, k_ts, timestamps=True)
-    data.sync()
-    timings = data.read_timings()
-    stats = data.stats()
+    if world == 1:
+        pipe.step(data, k_ts, timestamps=True)
+        data.sync()
+        timings = data.read_timings()
+        stats = data.stats()
+    else:
+        from wgsparkl_amd import _ffi
+        import ctypes as C
+        _ffi.check(pipe.lib, pipe.lib.wgs_step(pipe._h, data._h, k_ts, 1))   # local slab only (no halo): kernel timing
+        data.sync()
+        ms = (C.c_float * _ffi.WGS_NUM_PASSES)()
+        _ffi.check(pipe.lib, pipe.lib.wgs_read_timings(data._h, ms))
+        timings = dict(zip(_ffi.PASS_NAMES, [float(x) for x in ms]))
+        st = pipe.T.Stats()
+        _ffi.check(pipe.lib, pipe.lib.wgs_get_stats(data._h, C.byref(st)))
+        stats = {"num_active_blocks": int(st.num_active_blocks)}
     n_nodes = stats["num_active_blocks"] * 64
 
     if rank == 0:
-        value = n * world * args.steps / elapsed
+        value = n_total * args.steps / elapsed
         g2p_ms = timings["g2p"] / k_ts
         # fused G2P + particle update, elastic: 160 B per particle + 16 B per active node
         algo_bytes = 160.0 * n + 16.0 * n_nodes
@@ -105,7 +155,7 @@ def main():
         traffic = None
         prof = sorted(__import__("glob").glob(os.path.join(ROOT, "profiles", "r*_pmc_g2p.json")))[-1:] or [""]
         prof = prof[0]
-        if os.path.exists(prof):
+        if os.path.exists(prof) and args.n_side == 100:
             try:
                 traffic = json.load(open(prof)).get("hbm_bytes_per_launch")
             except Exception:
@@ -117,15 +167,15 @@ def main():
             "data": "synthetic",
             "config": {"workload": f"wgsparkl3d neo-Hookean elastic cube, {n} particles/GPU, 128^3-cell domain, "
                                    f"h=1, dt=1/1200, 8 particles/cell, " + ("no collider" if args.no_floor else "floor cuboid (CPIC passes on)"),
-                       "particles_per_gpu": n, "active_blocks": stats["num_active_blocks"],
-                       "parallelism": "1 GPU" if world == 1 else f"{world} independent slabs (no halo exchange yet)"},
+                       "particles_per_gpu": n_total // world, "global_particles": n_total,
+                       "active_blocks_rank0": stats["num_active_blocks"], "parallelism": parallelism},
             "roofline": {"bound": "hbm", "kernel": "k_g2p_update (fused G2P + particle update)",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "algorithmic_bytes_per_launch": algo_bytes, "avg_launch_ms": g2p_ms},
             "pass_ms_per_step": {k: v / k_ts for k, v in timings.items()},
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:
             sub = 2
             v, secs = cpu_baseline(scene, sub)
             out["cpu_baseline"] = {"value": v, "unit": "particle-steps/s", "cores": 1, "kind": "port",

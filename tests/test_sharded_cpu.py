@@ -51,3 +51,12 @@ def test_gloo_world2_matches_single_domain(oracle_libs, tmp_path, dim, k):
         scale = max(np.sqrt(np.mean(ref * ref)), 1e-300)
         err = np.sqrt(np.mean((got - ref) ** 2)) / scale
         assert err < 1e-9, (f, err)
+
+
+def test_fixed_exchange_routing_gloo_world3():
+    """FixedExchange (the transport bench.py uses over RCCL) routes lower/upper messages correctly; gloo, 3 ranks."""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29631", WORLD_SIZE="3", OMP_NUM_THREADS="1")
+    procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "fixed_exchange_worker.py")], env=dict(env, RANK=str(r)),
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(3)]
+    logs = [p.communicate(timeout=120)[0].decode() for p in procs]
+    assert all(p.returncode == 0 for p in procs), "\n".join(logs)

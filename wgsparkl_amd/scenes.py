@@ -104,3 +104,54 @@ def random_cloud(n, dim=3, extent=12.0, cell_width=1.0, seed=7, vel_scale=1.0,
     ps.affine[:] = (rng.normal(0.0, perturb_C, size=(n, dim * dim)) * ps.mass[:, None]).astype(F32)
     ps.mass[:] = (ps.mass * rng.uniform(0.5, 1.5, size=n)).astype(F32)
     return ps
+
+
+def _hash_jitter(ids: np.ndarray, dim: int, amplitude: float) -> np.ndarray:
+    """Deterministic per-particle jitter from the GLOBAL particle id (so that every rank of a sharded run
+    generates exactly the particles a single-domain run would): splitmix64 -> uniform in [-a, a)."""
+    out = np.empty((len(ids), dim), np.float64)
+    for k in range(dim):
+        z = (ids.astype(np.uint64) * np.uint64(dim) + np.uint64(k) + np.uint64(0x9E3779B97F4A7C15)) & np.uint64(0xFFFFFFFFFFFFFFFF)
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        z = z ^ (z >> np.uint64(31))
+        out[:, k] = (z >> np.uint64(11)).astype(np.float64) / float(1 << 53)
+    return (out * 2.0 - 1.0) * amplitude
+
+
+def neo_hookean_bar(n_side=100, world=1, rank=None, jitter=0.05, cell_width=1.0):
+    """Weak-scaling workload: `world` C2 cubes side by side along x = one elastic bar of
+    (n_side * world) x n_side x n_side particles. With `rank` given, only the particles of that rank's
+    x-slab are generated (global ids = index in the full lattice); returns the slab partition too."""
+    from .sharded import SlabPartition, associated_block_x
+    h = cell_width
+    ox, oy, oz = 20.0 * h, 8.0 * h, 20.0 * h
+    nx = n_side * world
+    # slab cuts in blocks (4 cells): the block containing the first lattice plane of each rank
+    cuts = [int(np.floor((ox / h - 1.0) / 4.0))]
+    for r in range(1, world):
+        cuts.append(int(np.round((ox / h + n_side * r / 2.0 - 1.0) / 4.0)))
+    cuts.append(int(np.floor((ox / h + nx / 2.0) / 4.0)) + 2)
+    part = SlabPartition(cuts)
+    if rank is None:
+        i0, i1 = 0, nx
+    else:
+        i0, i1 = max(0, n_side * rank - 12), min(nx, n_side * (rank + 1) + 12)
+    i, j, k = np.meshgrid(np.arange(i0, i1), np.arange(n_side), np.arange(n_side), indexing="ij")
+    idx = np.stack([i.ravel(), j.ravel(), k.ravel()], 1)
+    gid = ((idx[:, 0].astype(np.int64) * n_side + idx[:, 1]) * n_side + idx[:, 2])
+    pos = (idx + 0.5) * (h / 2.0) + np.array([ox, oy, oz])
+    if jitter:
+        pos = pos + _hash_jitter(gid, 3, jitter * h)
+    pos = pos.astype(F32)
+    if rank is not None:
+        own = part.owner_of_blocks(associated_block_x(pos, h, 3)) == rank
+        pos, gid = pos[own], gid[own]
+    ps = ParticleSet.uniform(pos, h / 4.0, 2700.0, ElasticCoefficients.from_young_modulus(1.0e7, 0.2),
+                             phase=ParticlePhase(1.0, FLT_MAX))
+    nb = (n_side // 8 + 4) ** 2 * (n_side // 8 + 8)
+    return dict(particles=ps, global_ids=gid.astype(np.uint32), partition=part,
+                params=SimulationParams(gravity=(0.0, -9.81, 0.0), dt=1.0 / 1200.0),
+                colliders=[Collider.cuboid((100000.0 * h, 2.0 * h, 1000.0 * h), (0.0, 0.0, 0.0))],
+                cell_width=h, grid_capacity=max(1024, 1 << int(np.ceil(np.log2(nb * 1.5)))), model=MODEL_NEO_HOOKEAN,
+                global_particles=nx * n_side * n_side)

@@ -126,6 +126,7 @@ class FixedExchange:
         lower = self.rank - 1 if self.rank > 0 else None
         upper = self.rank + 1 if self.rank < self.world - 1 else None
         ops, from_lower, from_upper = [], None, None
+        # every rank uses the same buffer capacities, so both directions of a face carry same-sized messages
         if lower is not None and to_lower is not None:
             from_lower = torch.empty_like(to_lower)
             ops += [dist.P2POp(dist.isend, to_lower, lower), dist.P2POp(dist.irecv, from_lower, lower)]
