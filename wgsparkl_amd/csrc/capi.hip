@@ -137,7 +137,9 @@ struct Unpacked {
     float dp[6], st[3], phase[2];
 };
 
-template <int DIM> __device__ inline void unpack_slot(const float *in, uint32_t npad, uint32_t j, bool plastic, bool cpic, Unpacked &u) {
+template <int DIM> __device__ inline void unpack_slot(const float *in, uint32_t npad, uint32_t j, bool plastic, bool cpic_in, uint32_t cdf_epoch, Unpacked &u) {
+    // cdf quads are valid only if stamped with the epoch of the last substep (0 = echo the input)
+    const bool cpic = cpic_in && (cdf_epoch == 0u || ldstamp<DIM>(in, npad, j) == cdf_epoch);
     using P = Pl<DIM>;
     if constexpr (DIM == 3) {
         const float4 xm = ldq(in, npad, P::XM, j), c0 = ldq(in, npad, P::CV0, j), c1 = ldq(in, npad, P::CV1, j),
@@ -174,7 +176,7 @@ template <int DIM> __device__ inline void unpack_slot(const float *in, uint32_t 
     }
 }
 
-__global__ void k_export_particles(Dev d, int side, ParticleOffsets o, bool plastic, bool cpic, const float *s_radius,
+__global__ void k_export_particles(Dev d, int side, ParticleOffsets o, bool plastic, bool cpic, uint32_t cdf_epoch, const float *s_radius,
                                    const float *s_dp, const float *s_phase, const uint32_t *s_flags, float *out,
                                    float *plastic_out) {
     const float *in = d.buf[side];
@@ -182,7 +184,7 @@ __global__ void k_export_particles(Dev d, int side, ParticleOffsets o, bool plas
     for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < d.n; j += gridDim.x * blockDim.x) {
         const uint32_t pid = ldpid<D>(in, npad, j);
         Unpacked u;
-        unpack_slot<D>(in, npad, j, plastic, cpic, u);
+        unpack_slot<D>(in, npad, j, plastic, cpic, cdf_epoch, u);
         float *r = out + (size_t)pid * o.stride;
         for (int k = 0; k < D; k++) {
             r[o.pos + k] = u.x[k];
@@ -333,7 +335,7 @@ template <bool TS> wgs_status enqueue_substep(wgs_data *d, int ts_slot, int part
             hipLaunchKernelGGL(k_node_cdf<D>, dim3(grid_for(d, 4)), dim3(256), 0, s, dev);
             hipLaunchKernelGGL(k_block_class<D>, dim3(grid_for(d, 1)), dim3(256), 0, s, dev);
             mark(2);
-            hipLaunchKernelGGL(k_particle_cdf<D>, dim3(grid_for(d, 4)), dim3(256), 0, s, dev, side);
+            hipLaunchKernelGGL(k_particle_cdf<D>, dim3(grid_for(d, 4)), dim3(256), 0, s, dev, side, epoch);
             mark(3);
         } else {
             mark(2);
@@ -363,7 +365,7 @@ template <bool TS> wgs_status enqueue_substep(wgs_data *d, int ts_slot, int part
             // ---- "g2p" + "particles_update", fused
             const int g = (int)(((dev.nv + G2P_THREADS - 1) / G2P_THREADS + 7) / 8) * 8;  // multiple of 8: XCD-aware mapping
 #define WGS_LAUNCH_G2P(MODEL, PL, CM) \
-    hipLaunchKernelGGL((k_g2p_update<D, MODEL, PL, CM>), dim3(g), dim3(G2P_THREADS), 0, s, dev, side)
+    hipLaunchKernelGGL((k_g2p_update<D, MODEL, PL, CM>), dim3(g), dim3(G2P_THREADS), 0, s, dev, side, epoch)
 #define WGS_LAUNCH_G2P_MP(MODEL, PL)        \
     do {                                    \
         if (d->cpic) {                      \
@@ -829,7 +831,7 @@ wgs_status wgs_read_particles(wgs_data *d, wgs_particle *out, wgs_plastic_state 
     // (g2p_cdf.wgsl:246-249 runs unconditionally); before any step the input is echoed.
     const bool cdf_live = d->cpic || d->substeps == 0;
     hipLaunchKernelGGL(k_export_particles, dim3(grid_for(d, 4)), dim3(256), 0, d->stream, d->dev, d->side, o, d->plastic,
-                       cdf_live, d->static_radius, d->static_dp, d->static_phase, d->static_flags, tmp, ptmp);
+                       cdf_live, (uint32_t)d->substeps, d->static_radius, d->static_dp, d->static_phase, d->static_flags, tmp, ptmp);
     hipError_t e = hipMemcpyAsync(out, tmp, bytes, hipMemcpyDeviceToHost, d->stream);
     if (e == hipSuccess && plastic_out)
         e = hipMemcpyAsync(plastic_out, ptmp, sizeof(float) * 3 * (size_t)n, hipMemcpyDeviceToHost, d->stream);

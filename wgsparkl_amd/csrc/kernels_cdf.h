@@ -220,7 +220,7 @@ template <int D> __global__ __launch_bounds__(256) void k_block_class(Dev d) {
     }
 }
 
-template <int D> __global__ __launch_bounds__(256) void k_particle_cdf(Dev d, int side) {
+template <int D> __global__ __launch_bounds__(256) void k_particle_cdf(Dev d, int side, uint32_t epoch) {
     constexpr int BW = Dim<D>::BW, BS = Dim<D>::BSHIFT, TW = Dim<D>::TW, TILE = Dim<D>::TILE, NN = Dim<D>::NNBR;
     constexpr int N = D + 1;
     using P = Pl<D>;
@@ -259,7 +259,8 @@ template <int D> __global__ __launch_bounds__(256) void k_particle_cdf(Dev d, in
             if (any) {
                 const float4 xm = ldq(buf, npad, P::XM, src);
                 const float4 cprev = ldq(buf, npad, D == 3 ? (int)P::CDF1 : (int)P::CDF0, src);
-                const uint32_t prev = __float_as_uint(cprev.w);
+                // previous affinity (sign persistence, g2p_cdf.wgsl:183-190): only if computed last substep
+                const uint32_t prev = ldstamp<D>(buf, npad, src) == epoch - 1u ? __float_as_uint(cprev.w) : 0u;
                 float x[D], ref[D], w[D][3];
                 x[0] = xm.x; x[1] = xm.y;
                 if constexpr (D == 3) x[2] = xm.z;
@@ -349,6 +350,7 @@ template <int D> __global__ __launch_bounds__(256) void k_particle_cdf(Dev d, in
                 stq(buf, npad, P::CDF0, src, make_float4(nrm[0], nrm[1], dist, __uint_as_float(aff)));
                 stq(buf, npad, P::CDF1, src, make_float4(0.f, 0.f, 0.f, 0.f));
             }
+            ststamp<D>(buf, npad, src, epoch);
         }
     }
 }

@@ -86,7 +86,7 @@ template <int D> __global__ __launch_bounds__(64) void k_add_halo(Dev d, const f
 
 // Full-state record of one particle: NQ quads + pid. A particle buffer = 4 header floats
 // ([count, -, -, -]) + cap records.
-template <int D> constexpr int particle_record_floats() { return Pl<D>::NQ * 4 + 1; }
+template <int D> constexpr int particle_record_floats() { return Pl<D>::NQ * 4 + 2; }  // quads, pid, cdf epoch
 
 // Particles whose associated block left [shard_lo, shard_hi): copy them to the outbox of the face
 // they crossed and vacate their slot. mode 1 = export every valid particle instead (read-back).
@@ -120,6 +120,7 @@ template <int D> __global__ __launch_bounds__(256) void k_pack_migrants(Dev d, i
                 rec[q * 4 + 0] = v.x; rec[q * 4 + 1] = v.y; rec[q * 4 + 2] = v.z; rec[q * 4 + 3] = v.w;
             }
             rec[NQ * 4] = __uint_as_float(pid);
+            rec[NQ * 4 + 1] = __uint_as_float(ldstamp<D>(buf, npad, i));
             if (mode == 0) stpid<D>(buf, npad, i, PID_DEAD);
         } else {
             atomicOr(&d.counters[CTR_ERRORS], ERRBIT_SHARD);  // the particle stays here: wrong physics, reported
@@ -144,6 +145,7 @@ template <int D> __global__ __launch_bounds__(256) void k_append_migrants(Dev d,
 #pragma unroll
         for (int q = 0; q < NQ; q++) stq(buf, d.npad, q, i, make_float4(rec[q * 4], rec[q * 4 + 1], rec[q * 4 + 2], rec[q * 4 + 3]));
         stpid<D>(buf, d.npad, i, __float_as_uint(rec[NQ * 4]));
+        ststamp<D>(buf, d.npad, i, __float_as_uint(rec[NQ * 4 + 1]));
     }
 }
 

@@ -124,22 +124,14 @@ template <int D> __global__ __launch_bounds__(SORT_THREADS) void k_bin(Dev d, in
         const unsigned long long same = __ballot(mine);
         todo &= ~same;
         if (lane == leader) atomicAdd(&d.block_acc[id0], (uint32_t)__popcll(same));
-        // Rank inside the group = number of lower lanes with the same cell (buffer order, hence
-        // deterministic and already canonical for particles that did not change cell); an LDS
-        // atomic would hand out ranks in hardware arbitration order.
+        // Rank inside the group from an LDS atomic (hardware arbitration order: k_canonical_order sorts
+        // each cell by particle id afterwards anyway; a ballot loop over the distinct cells of the group
+        // would give buffer-order ranks but costs ~5 us more per substep at 1 M particles).
         // Cross-lane traffic through LDS inside one wave uses (relaxed, wavefront-scope) atomic
         // accesses so the compiler may not forward this lane's own stores to its loads.
         __hip_atomic_store(&hist[lane], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
         uint32_t r = 0;
-        unsigned long long cells_todo = same;
-        while (cells_todo) {  // one iteration per distinct cell of the group (~8 on sorted input)
-            const int l1 = __ffsll((long long)cells_todo) - 1;
-            const uint32_t c0 = __shfl(local, l1);
-            const unsigned long long m = __ballot(mine && local == c0);
-            cells_todo &= ~m;
-            if (mine && local == c0) r = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-            if (lane == l1) __hip_atomic_store(&hist[c0], (uint32_t)__popcll(m), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-        }
+        if (mine) r = __hip_atomic_fetch_add(&hist[local], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
         const uint32_t cnt = __hip_atomic_load(&hist[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
         uint32_t base = 0;
         if (cnt) base = atomicAdd(&d.cell_count[id0 * NPB + lane], cnt);

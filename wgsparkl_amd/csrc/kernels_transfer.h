@@ -45,8 +45,11 @@ __global__ __launch_bounds__(P2GCfg<D>::NW * 64) void k_p2g(Dev d, int side, int
     constexpr int BW = Dim<D>::BW, BS = Dim<D>::BSHIFT, TW = Dim<D>::TW, TILE = Dim<D>::TILE;
     constexpr int NT = Cfg::NW * 64;
     constexpr int SLOTS = P2G_J * NPB;
-    __shared__ float4 s_q[Cfg::NQ][SLOTS];
-    __shared__ uint32_t s_aff[CPIC ? SLOTS : 1];
+    constexpr int ROW = NPB + 4;                 // padded [rank] row: the J float4 a (cell) group writes land on distinct banks
+    constexpr int KS = (SLOTS + NT - 1) / NT;    // staging slots per thread and round
+    constexpr int NQ = Cfg::NQ;
+    __shared__ float4 s_q[NQ][P2G_J * ROW];
+    __shared__ uint32_t s_aff[CPIC ? P2G_J * ROW : 1];
     __shared__ float4 s_tile[Cfg::NW][TILE];
     __shared__ uint32_t s_cs[NPB], s_cn[NPB];
 
@@ -102,40 +105,70 @@ __global__ __launch_bounds__(P2GCfg<D>::NW * 64) void k_p2g(Dev d, int side, int
 #pragma unroll
             for (int k = 0; k <= D; k++) acc[s][k] = 0.f;
 
-        for (uint32_t r0 = 0; r0 < maxc; r0 += P2G_J) {
-            __syncthreads();  // s_cs/s_cn visible; previous round consumed
-            // stage ranks [r0, r0 + J) of every cell; thread -> (cell, j) with j fastest so that a
-            // cell's J particles are one contiguous 64-byte run of each quad
-            for (int sl = tid; sl < SLOTS; sl += NT) {
-                const int c = sl / P2G_J, j = sl % P2G_J;
-                const uint32_t rank = r0 + j;
-                if (rank < s_cn[c]) {
-                    const uint32_t src = d.perm[s_cs[c] + rank];
-                    const int dst = j * NPB + c;
-                    if constexpr (D == 3) {
-                        const float4 xm = ldq(in, npad, Pl<3>::XM, src);
-                        const float4 c0 = ldq(in, npad, Pl<3>::CV0, src);
-                        const float4 c1 = ldq(in, npad, Pl<3>::CV1, src);
-                        float4 c2 = ldq(in, npad, Pl<3>::CV2, src);
-                        c2.y *= xm.w; c2.z *= xm.w; c2.w *= xm.w;  // momentum m v
-                        s_q[0][dst] = xm; s_q[1][dst] = c0; s_q[2][dst] = c1; s_q[3][dst] = c2;
-                    } else {
-                        const float4 xm = ldq(in, npad, Pl<2>::XM, src);   // x, y, m, V0
-                        const float4 c0 = ldq(in, npad, Pl<2>::CV0, src);
-                        float4 vl = ldq(in, npad, Pl<2>::CV2, src);        // vx, vy, lambda, mu
-                        vl.x *= xm.z; vl.y *= xm.z;
-                        s_q[0][dst] = xm; s_q[1][dst] = c0; s_q[2][dst] = vl;
-                    }
-                    if constexpr (CPIC) {
-                        const float4 cd = ldq(in, npad, D == 3 ? (int)Pl<D>::CDF1 : (int)Pl<D>::CDF0, src);
-                        s_aff[dst] = __float_as_uint(cd.w);
+        // Software-pipelined staging: the particle quads of round r+1 are fetched into registers while
+        // round r is being accumulated from LDS, so the HBM latency of a round hides behind the
+        // previous round's arithmetic instead of being paid at every barrier.
+        // Staging slot sl -> (cell c = sl / J, rank j = sl % J): a cell's J particles are one contiguous
+        // 64-byte run of each quad in HBM; in LDS they go to [j][c] (row padded to ROW).
+        float4 pre[KS][NQ];
+        uint32_t pre_aff[KS];
+        bool pre_ok[KS];
+        __syncthreads();  // s_cs / s_cn visible
+        auto fetch_round = [&](uint32_t r0) {
+#pragma unroll
+            for (int k = 0; k < KS; k++) {
+                const int sl = tid + k * NT;
+                pre_ok[k] = false;
+                if (sl < SLOTS) {
+                    const int c = sl / P2G_J;
+                    const uint32_t rank = r0 + (uint32_t)(sl % P2G_J);
+                    if (rank < s_cn[c]) {
+                        const uint32_t src = d.perm[s_cs[c] + rank];
+                        pre_ok[k] = true;
+                        if constexpr (D == 3) {
+                            pre[k][0] = ldq(in, npad, Pl<3>::XM, src);
+                            pre[k][1] = ldq(in, npad, Pl<3>::CV0, src);
+                            pre[k][2] = ldq(in, npad, Pl<3>::CV1, src);
+                            pre[k][3] = ldq(in, npad, Pl<3>::CV2, src);
+                        } else {
+                            pre[k][0] = ldq(in, npad, Pl<2>::XM, src);   // x, y, m, V0
+                            pre[k][1] = ldq(in, npad, Pl<2>::CV0, src);
+                            pre[k][2] = ldq(in, npad, Pl<2>::CV2, src);  // vx, vy, lambda, mu
+                        }
+                        if constexpr (CPIC) {
+                            const float4 cd = ldq(in, npad, D == 3 ? (int)Pl<D>::CDF1 : (int)Pl<D>::CDF0, src);
+                            pre_aff[k] = __float_as_uint(cd.w);
+                        }
                     }
                 }
             }
+        };
+        fetch_round(0);
+        for (uint32_t r0 = 0; r0 < maxc; r0 += P2G_J) {
+            __syncthreads();  // previous round consumed
+#pragma unroll
+            for (int k = 0; k < KS; k++) {
+                if (pre_ok[k]) {
+                    const int sl = tid + k * NT;
+                    const int dst = (sl % P2G_J) * ROW + sl / P2G_J;
+                    if constexpr (D == 3) {
+                        float4 c2 = pre[k][3];
+                        const float m = pre[k][0].w;
+                        c2.y *= m; c2.z *= m; c2.w *= m;  // momentum m v
+                        s_q[0][dst] = pre[k][0]; s_q[1][dst] = pre[k][1]; s_q[2][dst] = pre[k][2]; s_q[3][dst] = c2;
+                    } else {
+                        float4 vl = pre[k][2];
+                        vl.x *= pre[k][0].z; vl.y *= pre[k][0].z;
+                        s_q[0][dst] = pre[k][0]; s_q[1][dst] = pre[k][1]; s_q[2][dst] = vl;
+                    }
+                    if constexpr (CPIC) s_aff[dst] = pre_aff[k];
+                }
+            }
             __syncthreads();
+            if (r0 + P2G_J < maxc) fetch_round(r0 + P2G_J);  // in flight during the accumulation below
             const uint32_t jn = cn > r0 ? min((uint32_t)P2G_J, cn - r0) : 0u;
             for (uint32_t j = 0; j < jn; j++) {
-                const int sl = j * NPB + cell;
+                const int sl = j * ROW + cell;
                 float x[D], mv[D], c[D * D], mass;
                 if constexpr (D == 3) {
                     const float4 xm = s_q[0][sl], c0 = s_q[1][sl], c1 = s_q[2][sl], c2 = s_q[3][sl];
@@ -194,21 +227,19 @@ __global__ __launch_bounds__(P2GCfg<D>::NW * 64) void k_p2g(Dev d, int side, int
                 }
             }
         }
-        // Per-wave tile: in phase (sx, sy) every lane (cell) owns a distinct node, so a plain
-        // read-add-write is race-free inside the wave; phases run in program order. The accesses
-        // are (relaxed, wavefront-scope) atomics only to stop the compiler from forwarding a
-        // lane's own stores past another lane's update.
+        // Per-wave tile: in phase (sx, sy) every lane (cell) owns a distinct node, so a plain float4
+        // read-add-write is race-free inside the wave and the LDS executes a wave's accesses in order.
+        // The asm memory clobbers stop hipcc from hoisting a later phase's load above an earlier phase's
+        // store (legal for one thread, wrong across lanes).
         {
-            float *tile = reinterpret_cast<float *>(&s_tile[sz][0]);
 #pragma unroll
             for (int s = 0; s < 9; s++) {
-                const int node = tnode0 + (s % 3) + TW * (s / 3);
-#pragma unroll
-                for (int k = 0; k <= D; k++) {
-                    float *p = &tile[node * 4 + k];
-                    float old = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-                    __hip_atomic_store(p, old + acc[s][k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-                }
+                float4 *p = &s_tile[sz][tnode0 + (s % 3) + TW * (s / 3)];
+                float4 v = *p;
+                v.x += acc[s][0]; v.y += acc[s][1]; v.z += acc[s][2];
+                if constexpr (D == 3) v.w += acc[s][3];
+                *p = v;
+                asm volatile("" ::: "memory");
             }
         }
         __syncthreads();
@@ -308,7 +339,7 @@ constexpr int G2P_THREADS = 64;
 // whose tile sees no collider (plain MLS-MPM maths, writes default_cdf()); 2 = collider simulation,
 // blocks near a collider (full CPIC). Modes 1 and 2 are launched back to back and partition the blocks.
 template <int D, int MODEL, bool PLASTIC, int CMODE>
-__global__ __launch_bounds__(G2P_THREADS, G2P_WAVES_PER_EU) void k_g2p_update(Dev d, int side) {
+__global__ __launch_bounds__(G2P_THREADS, G2P_WAVES_PER_EU) void k_g2p_update(Dev d, int side, uint32_t epoch) {
     constexpr bool CPIC = CMODE == 2;
     constexpr int BW = Dim<D>::BW, BS = Dim<D>::BSHIFT, TW = Dim<D>::TW, TILE = Dim<D>::TILE, NN = Dim<D>::NNBR;
     constexpr int DD = D * D;
@@ -642,10 +673,7 @@ __global__ __launch_bounds__(G2P_THREADS, G2P_WAVES_PER_EU) void k_g2p_update(De
                 stq(out, npad, P::F0, j, make_float4(Fm[0], Fm[1], Fm[2], Fm[3]));
             }
             stpid<D>(out, npad, j, pid);
-            if constexpr (CMODE == 1) {  // g2p_cdf.wgsl:246-249: no collider in reach -> default_cdf()
-                stq(out, npad, P::CDF0, j, make_float4(0.f, 0.f, 0.f, 0.f));
-                stq(out, npad, P::CDF1, j, make_float4(0.f, 0.f, 0.f, 0.f));
-            }
+            // CMODE 1 (no collider in reach): default_cdf() is implied by a stale stamp, nothing to store (layout.h)
             if constexpr (CPIC) {
                 if constexpr (D == 3) {
                     stq(out, npad, P::CDF0, j, make_float4(nrm[0], nrm[1], nrm[2], sdist));
@@ -654,6 +682,7 @@ __global__ __launch_bounds__(G2P_THREADS, G2P_WAVES_PER_EU) void k_g2p_update(De
                     stq(out, npad, P::CDF0, j, make_float4(nrm[0], nrm[1], sdist, __uint_as_float(paff)));
                     stq(out, npad, P::CDF1, j, make_float4(rvel[0], rvel[1], 0.f, 0.f));
                 }
+                ststamp<D>(out, npad, j, epoch);
             }
         }  // mine
     }  // distinct blocks

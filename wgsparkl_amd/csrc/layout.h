@@ -62,8 +62,8 @@ template <> struct Pl<2> {
     static constexpr int CDF1 = 8;  // rigid_vel xy, -, -
     static constexpr int NQ = 9;
 };
-// floats per particle slot of one buffer (NQ quads + the pid plane)
-template <int D> constexpr size_t buffer_floats(uint32_t npad) { return ((size_t)Pl<D>::NQ * 4 + 1) * npad; }
+// floats per particle slot of one buffer (NQ quads + the pid plane + the cdf-epoch plane)
+template <int D> constexpr size_t buffer_floats(uint32_t npad) { return ((size_t)Pl<D>::NQ * 4 + 2) * npad; }
 
 struct SimParamsDev {   // solver/params.wgsl:3-10 + grid.cell_width; lives in HBM so graph replays see updates
     float gravity[3];
@@ -165,6 +165,21 @@ template <int D> __device__ inline uint32_t ldpid(const float *base, uint32_t np
     uint32_t off = ((uint32_t)Pl<D>::NQ * 4u * npad + i) * 4u;
     asm volatile("" : "+v"(off));
     return *reinterpret_cast<const uint32_t *>(reinterpret_cast<const char *>(base) + off);
+}
+// Epoch (substep number) at which the particle's CDF quads were last computed. A particle whose block is
+// out of reach of every collider has default_cdf() (g2p_cdf.wgsl:246-249); instead of storing 32 bytes of
+// zeros for ~all particles every substep, the quads are only written for particles near a collider and
+// are VALID only while this stamp equals the current (or, for "previous affinity", the previous) epoch.
+// A buffer slot that is not rewritten keeps a stamp at least two epochs old (ping-pong), never a fresh one.
+template <int D> __device__ inline uint32_t ldstamp(const float *base, uint32_t npad, uint32_t i) {
+    uint32_t off = (((uint32_t)Pl<D>::NQ * 4u + 1u) * npad + i) * 4u;
+    asm volatile("" : "+v"(off));
+    return *reinterpret_cast<const uint32_t *>(reinterpret_cast<const char *>(base) + off);
+}
+template <int D> __device__ inline void ststamp(float *base, uint32_t npad, uint32_t i, uint32_t e) {
+    uint32_t off = (((uint32_t)Pl<D>::NQ * 4u + 1u) * npad + i) * 4u;
+    asm volatile("" : "+v"(off));
+    *reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(base) + off) = e;
 }
 template <int D> __device__ inline void stpid(float *base, uint32_t npad, uint32_t i, uint32_t pid) {
     uint32_t off = ((uint32_t)Pl<D>::NQ * 4u * npad + i) * 4u;

@@ -296,7 +296,7 @@ class GpuShard:
 
 def unpack_records(rec: np.ndarray, dim: int):
     """Particle records (quad layout of csrc/layout.h) -> dict of arrays."""
-    ids = rec[:, -1].copy().view(np.uint32)
+    ids = rec[:, -2].copy().view(np.uint32)     # [..quads.., pid, cdf epoch]
     if dim == 3:
         q = lambda k: rec[:, 4 * k:4 * k + 4]
         pos, mass = q(0)[:, :3], q(0)[:, 3]
