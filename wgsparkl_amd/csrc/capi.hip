@@ -10,6 +10,7 @@
 #include "../../include/wgsparkl_hip.h"
 
 #include <cfloat>
+#include <cmath>
 #include <climits>
 #include <cstdint>
 #include <cstddef>
@@ -71,6 +72,7 @@ struct wgs_data {
     bool plastic = false;
     bool cpic = false;
     bool deterministic = true;
+    bool prev_sorted = false;   // the current buffer is the sorted output of the previous substep (perm_cell, links valid)
     uint64_t substeps = 0;
     uint64_t device_bytes = 0;
     uint32_t sticky_errors = 0;
@@ -311,16 +313,23 @@ template <bool TS> wgs_status enqueue_substep(wgs_data *d, int ts_slot, int part
         if (TS) hipEventRecord(d->events.ev[ts_slot][m], s);
     };
     const uint32_t epoch = (uint32_t)(d->substeps + 1);
+    // Steady state: the buffer is in the sorted order of the previous substep, whose block ids, cell ids
+    // (perm_cell) and neighbour links are still valid, so the particles are re-binned RELATIVE to their old
+    // block (k_rebin: no hash lookups except for the few particles that changed block). The full k_bin runs
+    // on the first substep, on table-rebuild substeps and in sharded runs (particles arrive from neighbours).
+    const bool rehash = d->substeps % REHASH_PERIOD == 0;
+    const bool use_rebin = d->prev_sorted && !rehash && !dev.sharded && !(dev.dbg & 128u);
     if (part != 2) {
         mark(0);
         // ---- "grid sort" (grid.rs:30-207)
-        if (d->substeps % REHASH_PERIOD == 0) {  // reset_hmap, amortised (device_math.h)
+        if (rehash) {  // reset_hmap, amortised (device_math.h)
             HIP_TRY(hipMemsetAsync(dev.hkeys, 0xff, sizeof(uint32_t) * ((size_t)dev.hmask + 1), s));
             HIP_TRY(hipMemsetAsync(dev.hvals, 0xff, sizeof(uint32_t) * ((size_t)dev.hmask + 1), s));
             HIP_TRY(hipMemsetAsync(dev.counters + CTR_NPHYS, 0, sizeof(uint32_t), s));
         }
         if (n > 0) {
-            hipLaunchKernelGGL(k_bin<D>, dim3(pgrid), dim3(SORT_THREADS), 0, s, dev, side, epoch);
+            if (use_rebin) hipLaunchKernelGGL(k_rebin<D>, dim3(pgrid), dim3(SORT_THREADS), 0, s, dev, side, epoch);
+            else hipLaunchKernelGGL(k_bin<D>, dim3(pgrid), dim3(SORT_THREADS), 0, s, dev, side, epoch);
             hipLaunchKernelGGL(k_scan_active, dim3(1), dim3(SCAN_THREADS), 0, s, dev, epoch);
             hipLaunchKernelGGL(k_block_setup<D>, dim3(grid_for(d, 4)), dim3(SORT_THREADS), 0, s, dev, epoch);
             hipLaunchKernelGGL(k_scatter<D>, dim3(pgrid), dim3(SORT_THREADS), 0, s, dev, side);
@@ -388,6 +397,7 @@ template <bool TS> wgs_status enqueue_substep(wgs_data *d, int ts_slot, int part
         mark(6);
         d->side ^= 1;
         d->substeps++;
+        d->prev_sorted = true;
         dev.n = dev.nv;  // the buffer just written holds the valid particles only, in sorted order
     }
     HIP_TRY(hipGetLastError());
@@ -461,6 +471,10 @@ static wgs_status create_impl(wgs_pipeline *pipeline, const wgs_sim_params *para
     dev.hmask = hcap - 1u;
     dev.h = cell_width;
     dev.inv_h = 1.0f / cell_width;
+    {
+        int e = 0;
+        dev.h_pow2 = (frexpf(cell_width, &e) == 0.5f) ? 1u : 0u;
+    }
     dev.model = WGS_MODEL_COROTATED;
     dev.dbg = getenv("WGS_DEBUG") ? (uint32_t)strtoul(getenv("WGS_DEBUG"), nullptr, 0) : 0u;
     dev.n_colliders = (uint32_t)num_colliders;
@@ -484,6 +498,7 @@ static wgs_status create_impl(wgs_pipeline *pipeline, const wgs_sim_params *para
     TRY_ALLOC(&dev.block_key, (size_t)dev.cap);
     TRY_ALLOC(&dev.block_count, (size_t)dev.cap);
     TRY_ALLOC(&dev.block_stamp, (size_t)dev.cap);
+    TRY_ALLOC(&dev.links_epoch, (size_t)dev.cap);
     TRY_ALLOC(&dev.block_acc, (size_t)dev.cap);
     TRY_ALLOC(&dev.active, (size_t)dev.cap);
     TRY_ALLOC(&dev.block_start, (size_t)dev.cap);

@@ -32,6 +32,37 @@ template <int D> __device__ inline void load_cell(const float *in, uint32_t npad
     if constexpr (D == 3) cell[2] = assoc_cell(xm.z, h);
 }
 
+// Per-cell counting of one wave's particles (sort.wgsl:89-99 extended to cells). Scattered device-scope
+// atomics run at the memory side on MI355X (~20 G/s when every lane hits its own line), so: LDS histogram
+// per (wave, block), lanes get their rank inside the wave's group from an LDS atomic, and ONE coalesced
+// returning global atomic per (wave, block) reserves the group's range inside each cell. The arrival
+// order of those atomics (and the LDS arbitration order) leaks into `rank`; k_canonical_order sorts each
+// cell by particle id afterwards. Wave-uniform control flow: call with all 64 lanes.
+__device__ inline void count_cells(const Dev &d, uint32_t *hist, int lane, uint32_t myid, uint32_t local, uint32_t &cid, uint32_t &rank) {
+    unsigned long long todo = __ballot(myid != NONE);
+    while (todo) {
+        const int leader = __ffsll((long long)todo) - 1;
+        const uint32_t id0 = __shfl(myid, leader);
+        const bool mine = myid == id0;
+        const unsigned long long same = __ballot(mine);
+        todo &= ~same;
+        if (lane == leader) atomicAdd(&d.block_acc[id0], (uint32_t)__popcll(same));
+        // Cross-lane traffic through LDS inside one wave uses (relaxed, wavefront-scope) atomic
+        // accesses so the compiler may not forward this lane's own stores to its loads.
+        __hip_atomic_store(&hist[lane], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+        uint32_t r = 0;
+        if (mine) r = __hip_atomic_fetch_add(&hist[local], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+        const uint32_t cnt = __hip_atomic_load(&hist[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+        uint32_t base = 0;
+        if (cnt) base = atomicAdd(&d.cell_count[id0 * NPB + lane], cnt);
+        __hip_atomic_store(&hist[lane], base, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+        if (mine) {
+            cid = id0 * NPB + local;
+            rank = __hip_atomic_load(&hist[local], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT) + r;
+        }
+    }
+}
+
 // sort.wgsl:26-36 touch_particle_blocks + sort.wgsl:89-99 update_block_particle_count, fused.
 template <int D> __global__ __launch_bounds__(SORT_THREADS) void k_bin(Dev d, int side, uint32_t epoch) {
     constexpr int BS = Dim<D>::BSHIFT, BW = Dim<D>::BW, NN = Dim<D>::NNBR;
@@ -109,39 +140,73 @@ template <int D> __global__ __launch_bounds__(SORT_THREADS) void k_bin(Dev d, in
     }
     __syncthreads();
     const uint32_t myid = !valid ? NONE : (myslot != NONE ? s_ids[myslot] : mydirect);
-    // ---- 3. count per cell. Scattered device-scope atomics run at the memory side on MI355X
-    // (~20 G/s when every lane hits its own line), so: LDS histogram per (wave, block), lanes get
-    // their rank inside the wave's group from an LDS atomic, and ONE coalesced returning global
-    // atomic per (wave, block) reserves the group's range inside each cell. The arrival order
-    // of those atomics leaks into `rank`; k_canonical_order removes that dependence.
-    uint32_t *hist = s_hist[wave];
+    // ---- 3. count per cell
     uint32_t cid = NONE, rank = 0;
-    todo = __ballot(myid != NONE);
-    while (todo) {
-        const int leader = __ffsll((long long)todo) - 1;
-        const uint32_t id0 = __shfl(myid, leader);
-        const bool mine = myid == id0;
-        const unsigned long long same = __ballot(mine);
-        todo &= ~same;
-        if (lane == leader) atomicAdd(&d.block_acc[id0], (uint32_t)__popcll(same));
-        // Rank inside the group from an LDS atomic (hardware arbitration order: k_canonical_order sorts
-        // each cell by particle id afterwards anyway; a ballot loop over the distinct cells of the group
-        // would give buffer-order ranks but costs ~5 us more per substep at 1 M particles).
-        // Cross-lane traffic through LDS inside one wave uses (relaxed, wavefront-scope) atomic
-        // accesses so the compiler may not forward this lane's own stores to its loads.
-        __hip_atomic_store(&hist[lane], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-        uint32_t r = 0;
-        if (mine) r = __hip_atomic_fetch_add(&hist[local], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-        const uint32_t cnt = __hip_atomic_load(&hist[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-        uint32_t base = 0;
-        if (cnt) base = atomicAdd(&d.cell_count[id0 * NPB + lane], cnt);
-        __hip_atomic_store(&hist[lane], base, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-        if (mine) {
-            cid = id0 * NPB + local;
-            rank = __hip_atomic_load(&hist[local], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT) + r;
+    count_cells(d, s_hist[wave], lane, myid, local, cid, rank);
+    if (i < num_slots(d)) {
+        d.cellid[i] = cid;
+        d.rank[i] = rank;
+    }
+}
+
+// Steady-state binning (sort.wgsl:26-36,89-99 for a buffer that is the sorted output of the previous
+// substep): slot i held cell perm_cell[i] of block b = perm_cell[i] >> 6 one substep ago, particles move
+// less than a cell per substep, so almost every particle is still in block b: its new cell id is
+// b * 64 + new local cell and the blocks to activate are b's neighbour links of the previous substep —
+// no hash lookup, no LDS set. Only particles that changed block go through the hash map.
+template <int D> __global__ __launch_bounds__(SORT_THREADS) void k_rebin(Dev d, int side, uint32_t epoch) {
+    constexpr int BS = Dim<D>::BSHIFT, BW = Dim<D>::BW, NN = Dim<D>::NNBR;
+    __shared__ uint32_t s_hist[SORT_THREADS / 64][NPB];
+    const float *in = d.buf[side];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t i = blockIdx.x * SORT_THREADS + tid;
+    const bool valid = i < num_slots(d);
+    uint32_t myid = NONE, local = 0;
+    if (valid) {
+        const uint32_t old = d.perm_cell[i];  // NONE only after a grid overflow: take the hash path then
+        const uint32_t ob = old >> 6;
+        const uint32_t okey = old != NONE ? d.block_key[ob] : 0u;
+        int c[D], nb[3] = {0, 0, 0};
+        load_cell<D>(in, d.npad, i, d.h, c);
+        uint32_t shift = 0;
+#pragma unroll
+        for (int k = 0; k < D; k++) {
+            nb[k] = c[k] >> BS;
+            local |= (uint32_t)(c[k] & (BW - 1)) << shift;
+            shift += BS;
+        }
+        int hi[3] = {nb[0] + 1, nb[1] + 1, nb[2] + 1};
+        if (!block_in_key_range<D>(nb) || !block_in_key_range<D>(hi)) {
+            atomicOr(&d.counters[CTR_ERRORS], ERRBIT_KEYRANGE);
+        } else {
+            const uint32_t key = pack_key<D>(nb);
+            myid = (old != NONE && key == okey) ? ob : activate_block(d, key, epoch);  // few particles change block
         }
     }
-    if (i < num_slots(d)) {
+    // activate every distinct block of the wave and its +1 neighbours (grid.wgsl:300-320)
+    unsigned long long todo = __ballot(myid != NONE);
+    while (todo) {
+        const int leader = __ffsll((long long)todo) - 1;
+        const uint32_t b1 = __shfl(myid, leader);
+        todo &= ~__ballot(myid == b1);
+        if (lane < NN) {
+            // links of the previous substep when they exist: a plain idempotent store. A block created just now,
+            // re-activated after a pause, or whose neighbour was not active (it held no particle) goes
+            // through the hash map.
+            const uint32_t t1 = d.links_epoch[b1] == epoch - 1u ? d.nbr_plus[b1 * 8u + lane] : NONE;
+            if (t1 != NONE) {
+                d.block_stamp[t1] = epoch;
+            } else {
+                int kb[3] = {0, 0, 0};
+                unpack_key<D>(d.block_key[b1], kb);
+                int nb[3] = {kb[0] + (lane & 1), kb[1] + ((lane >> 1) & 1), kb[2] + ((lane >> 2) & 1)};
+                if (block_in_key_range<D>(nb)) activate_block(d, pack_key<D>(nb), epoch);
+            }
+        }
+    }
+    uint32_t cid = NONE, rank = 0;
+    count_cells(d, s_hist[wave], lane, myid, local, cid, rank);
+    if (valid) {
         d.cellid[i] = cid;
         d.rank[i] = rank;
     }
@@ -240,6 +305,7 @@ template <int D> __global__ __launch_bounds__(SORT_THREADS) void k_block_setup(D
         d.cell_count[idx] = 0;             // accumulators are zero at rest
         if (lane == 63) {
             d.block_count[id] = inc;       // snapshot used by P2G / grid update / G2P
+            d.links_epoch[id] = epoch;     // the neighbour links written above are those of this substep
             d.block_acc[id] = 0;
             d.block_cdf_flag[id] = 0;
         }

@@ -116,6 +116,7 @@ struct Dev {
     // per physical block id (ids persist while the block stays in the hash map)
     uint32_t *block_key;   // cap: packed virtual id
     uint32_t *block_stamp; // cap: epoch of the last substep in which the block was active
+    uint32_t *links_epoch; // cap: epoch at which nbr_plus / nbr_minus of the block were last written
     uint32_t *block_acc;   // cap: particle counter being accumulated by k_bin (zero at rest)
     uint32_t *block_count; // cap: particles whose associated cell is in the block (num_particles)
     uint32_t *block_start; // cap: exclusive scan of block_count over the active list (first_particle)
@@ -137,6 +138,7 @@ struct Dev {
     uint32_t n_colliders;
     float h;             // cell width
     float inv_h;
+    uint32_t h_pow2;     // cell width is a power of two: x * inv_h == x / h bit for bit
     int model;           // WGS_MODEL_*
     uint32_t dbg;        // debug/ablation switches (env WGS_DEBUG), 0 in production
 };
