@@ -339,17 +339,12 @@ template <bool TS> wgs_status enqueue_substep(wgs_data *d, int ts_slot, int part
             HIP_TRY(hipMemsetAsync(dev.counters + CTR_NBLOCKS, 0, sizeof(uint32_t), s));
         }
         mark(1);
-        // ---- "grid_update_cdf" + "g2p_cdf" (collide.wgsl, grid_update_cdf.wgsl, g2p_cdf.wgsl)
-        if (d->cpic && n > 0) {
-            hipLaunchKernelGGL(k_node_cdf<D>, dim3(grid_for(d, 4)), dim3(256), 0, s, dev);
-            hipLaunchKernelGGL(k_block_class<D>, dim3(grid_for(d, 1)), dim3(256), 0, s, dev);
-            mark(2);
-            hipLaunchKernelGGL(k_particle_cdf<D>, dim3(grid_for(d, 4)), dim3(256), 0, s, dev, side, epoch);
-            mark(3);
-        } else {
-            mark(2);
-            mark(3);
-        }
+        // ---- "grid_update_cdf" + "g2p_cdf" (collide.wgsl, grid_update_cdf.wgsl, g2p_cdf.wgsl): one launch
+        // (kernels_cdf.h); the reference's two pass names share its time in wgs_read_timings
+        if (d->cpic && n > 0)
+            hipLaunchKernelGGL(k_cdf<D>, dim3(grid_for(d, 16)), dim3(CDF_THREADS), 0, s, dev, side, epoch);
+        mark(2);
+        mark(3);
         if (n > 0) {
             // ---- "p2g"
             const dim3 p2g_grid(grid_for(d, 5)), p2g_block(P2GCfg<D>::NW * 64);
@@ -373,8 +368,9 @@ template <bool TS> wgs_status enqueue_substep(wgs_data *d, int ts_slot, int part
         if (dev.nv > 0) {
             // ---- "g2p" + "particles_update", fused
             const int g = (int)(((dev.nv + G2P_THREADS - 1) / G2P_THREADS + 7) / 8) * 8;  // multiple of 8: XCD-aware mapping
-#define WGS_LAUNCH_G2P(MODEL, PL, CM) \
-    hipLaunchKernelGGL((k_g2p_update<D, MODEL, PL, CM>), dim3(g), dim3(G2P_THREADS), 0, s, dev, side, epoch)
+#define WGS_LAUNCH_G2P(MODEL, PL, CM)                                                                              \
+    hipLaunchKernelGGL((k_g2p_update<D, MODEL, PL, CM>), (CM) == 2 ? dim3(8, grid_for(d, 1) * 3 / 2) : dim3(g), \
+                       dim3(G2P_THREADS), 0, s, dev, side, epoch)
 #define WGS_LAUNCH_G2P_MP(MODEL, PL)        \
     do {                                    \
         if (d->cpic) {                      \

@@ -1,6 +1,6 @@
-// kernels_cdf.h — CPIC colour-distance-field passes for analytic colliders.
-//   k_node_cdf     = solver/grid_update_cdf.wgsl:16-39 + collision/collide.wgsl:23-56
-//   k_particle_cdf = solver/g2p_cdf.wgsl:39-250
+// kernels_cdf.h — CPIC colour-distance-field passes for analytic colliders (k_block_prep).
+//   node cdf     = solver/grid_update_cdf.wgsl:16-39 + collision/collide.wgsl:23-56
+//   particle cdf = solver/g2p_cdf.wgsl:39-250
 // The shape projections / pose maths are third party in the reference (wgparry
 // Shape::projectPointOnBoundary, wgebra Sim2/Sim3 — not on disk); they are
 // restated from parry's published algorithms, identically to the oracle.
@@ -121,45 +121,33 @@ template <int D> __device__ inline bool project_local_on_boundary(const Collider
     return true;
 }
 
-template <int D> __global__ __launch_bounds__(256) void k_node_cdf(Dev d) {
-    constexpr int BW = Dim<D>::BW, BS = Dim<D>::BSHIFT;
-    const uint32_t B = min(d.counters[CTR_NBLOCKS], d.cap);
-    const uint32_t total = B * NPB;
+// grid_update_cdf.wgsl:16-39 + collide.wgsl:23-56 for one node at world position pt: a pure function of
+// the node position and the collider poses.
+template <int D> __device__ inline NodeCdf node_cdf_eval(const Dev &d, const float *pt) {
     const float cap = d.h * 1.5f;
-    for (uint32_t t = blockIdx.x * 256 + threadIdx.x; t < total; t += gridDim.x * 256) {
-        const uint32_t b = d.active[t >> 6], ln = t & 63u;
-        const uint32_t node = b * NPB + ln;
-        int bc[3] = {0, 0, 0};
-        unpack_key<D>(d.block_key[b], bc);
-        int l[3] = {(int)(ln & (BW - 1)), (int)((ln >> BS) & (BW - 1)), D == 3 ? (int)(ln >> (2 * BS)) : 0};
-        float pt[D];
+    NodeCdf cdf = {1.0e10f, 0u, NONE, 0u};
+    for (uint32_t i = 0; i < d.n_colliders && i < 16u; i++) {
+        const ColliderDev &c = d.colliders[i];
+        float pl[D], projl[D], proj[D];
+        pose_to_local<D>(c, pt, pl);
+        bool inside = project_local_on_boundary<D>(c, pl, projl);
+        pose_to_world<D>(c, projl, proj);
+        float n2 = 0.f;
+        bool within = true;
 #pragma unroll
-        for (int k = 0; k < D; k++) pt[k] = (float)(bc[k] * BW + l[k]) * d.h;
-        NodeCdf cdf = {1.0e10f, 0u, NONE, 0u};
-        for (uint32_t i = 0; i < d.n_colliders && i < 16u; i++) {
-            const ColliderDev &c = d.colliders[i];
-            float pl[D], projl[D], proj[D];
-            pose_to_local<D>(c, pt, pl);
-            bool inside = project_local_on_boundary<D>(c, pl, projl);
-            pose_to_world<D>(c, projl, proj);
-            float n2 = 0.f;
-            bool within = true;
-#pragma unroll
-            for (int k = 0; k < D; k++) {
-                float dl = proj[k] - pt[k];
-                n2 += dl * dl;
-                within = within && (fabsf(dl) <= cap);
-            }
-            if (inside || within) {
-                float dist = sqrtf(n2);
-                if (dist < cdf.distance) cdf.closest_id = i;
-                cdf.distance = fminf(cdf.distance, dist);
-                cdf.affinities |= (inside ? 0x00010001u : 0x00000001u) << i;
-            }
+        for (int k = 0; k < D; k++) {
+            float dl = proj[k] - pt[k];
+            n2 += dl * dl;
+            within = within && (fabsf(dl) <= cap);
         }
-        d.node_cdf[node] = cdf;
-        if (cdf.affinities != 0u) d.block_cdf_flag[b] = 1u;  // benign race: every writer stores 1
+        if (inside || within) {
+            float dist = sqrtf(n2);
+            if (dist < cdf.distance) cdf.closest_id = i;
+            cdf.distance = fminf(cdf.distance, dist);
+            cdf.affinities |= (inside ? 0x00010001u : 0x00000001u) << i;
+        }
     }
+    return cdf;
 }
 
 // Solve the symmetric (N x N) system M x = r by LDL^T without pivoting (M is a
@@ -198,59 +186,65 @@ template <int N> __device__ inline float det_small(const float *m) {
     }
 }
 
-// Class of every active block: does any node of its (BW+2)^D tile (the block and its +1
-// neighbours) carry a collider affinity? Blocks that do not are plain MLS-MPM this substep:
-// every particle cdf is default_cdf() (g2p_cdf.wgsl:246-249), nothing reads it (P2G / G2P take the
-// plain path for the block) and the G2P launch for such blocks writes the default into the next
-// buffer. The reference runs the full CDF machinery for every block (PERF note at
-// grid_update_cdf.wgsl:34-36).
-template <int D> __global__ __launch_bounds__(256) void k_block_class(Dev d) {
-    constexpr int NN = Dim<D>::NNBR;
-    const uint32_t B = min(d.counters[CTR_NBLOCKS], d.cap);
-    for (uint32_t a = blockIdx.x * 256 + threadIdx.x; a < B; a += gridDim.x * 256) {
-        const uint32_t b = d.active[a];
-        uint32_t any = 0;
-#pragma unroll
-        for (int o = 0; o < NN; o++) {
-            const uint32_t nb = d.nbr_plus[b * 8u + o];
-            if (nb != NONE) any |= d.block_cdf_flag[nb];
-        }
-        d.block_cpic[b] = any;
-        if (any && d.block_count[b] > 0) d.cpic_list[atomicAdd(&d.counters[CTR_NCPIC], 1u)] = b;  // few blocks
-    }
-}
-
-template <int D> __global__ __launch_bounds__(256) void k_particle_cdf(Dev d, int side, uint32_t epoch) {
+// The three CDF passes of a substep in ONE launch, one single-wave workgroup per active block (every active
+// block is in flight at once; the pass costs one dependent-load chain):
+//   1. node cdf of the block's (BW+2)^D tile — its own nodes and the +1 rim. The rim belongs to the
+//      neighbour blocks; being a pure function of position it is recomputed here (3.4x redundant, a few
+//      hundred flops per node) instead of waiting for the neighbours behind a grid-wide dependency. The
+//      block's own nodes are written to node_cdf (P2G, G2P and wgs_read_grid read them).
+//   2. class of the block: does any node of the tile carry a collider affinity? Blocks that do not are
+//      plain MLS-MPM this substep: every particle cdf is default_cdf() (g2p_cdf.wgsl:246-249), nothing reads
+//      it, P2G / G2P take the plain path. The reference runs the full machinery for every block (PERF
+//      note at grid_update_cdf.wgsl:34-36).
+//   3. particle cdf (g2p_cdf.wgsl:39-250) of the particles of the blocks near a collider, from the tile in LDS.
+constexpr int CDF_THREADS = 64;
+template <int D> __global__ __launch_bounds__(CDF_THREADS) void k_cdf(Dev d, int side, uint32_t epoch) {
     constexpr int BW = Dim<D>::BW, BS = Dim<D>::BSHIFT, TW = Dim<D>::TW, TILE = Dim<D>::TILE, NN = Dim<D>::NNBR;
     constexpr int N = D + 1;
     using P = Pl<D>;
     __shared__ NodeCdf s_cdf[TILE];
+    __shared__ uint32_t s_any[2];
     float *buf = d.buf[side];
     const uint32_t npad = d.npad;
     const float h = d.h, inv_h = d.inv_h;
     const int tid = threadIdx.x;
-    const uint32_t B = min(d.counters[CTR_NCPIC], d.cap);  // only blocks near a collider (k_block_class)
-    for (uint32_t a = blockIdx.x; a < B; a += gridDim.x) {
-        const uint32_t b = d.cpic_list[a];
+    const uint32_t B = min(d.counters[CTR_NBLOCKS], d.cap);
+    uint32_t it = 0;
+    for (uint32_t a = blockIdx.x; a < B; a += gridDim.x, it ^= 1u) {
+        const uint32_t b = d.active[a];
         const uint32_t cnt = d.block_count[b];
         const uint32_t start = d.block_start[b];
         int bc[3] = {0, 0, 0};
         unpack_key<D>(d.block_key[b], bc);
-        __syncthreads();
-        const bool any = true;
-        if (any) {
-            for (int n = tid; n < TILE; n += 256) {
-                int t[3] = {n % TW, (n / TW) % TW, D == 3 ? n / (TW * TW) : 0};
-                int o = (t[0] >= BW ? 1 : 0) | (t[1] >= BW ? 2 : 0) | (t[2] >= BW ? 4 : 0);
-                int ln = (t[0] & (BW - 1)) + ((t[1] & (BW - 1)) << BS) + (D == 3 ? ((t[2] & (BW - 1)) << (2 * BS)) : 0);
-                uint32_t nb = d.nbr_plus[b * 8u + o];
-                NodeCdf c = {0.f, 0u, NONE, 0u};
-                if (nb != NONE) c = d.node_cdf[(size_t)nb * NPB + ln];
-                s_cdf[n] = c;
+        if (tid == 0) s_any[it] = 0u;
+        __syncthreads();  // previous block's tile fully consumed
+        uint32_t mine = 0u;
+        for (int n = tid; n < TILE; n += CDF_THREADS) {
+            int t[3] = {n % TW, (n / TW) % TW, D == 3 ? n / (TW * TW) : 0};
+            int o = (t[0] >= BW ? 1 : 0) | (t[1] >= BW ? 2 : 0) | (t[2] >= BW ? 4 : 0);
+            NodeCdf c = {0.f, 0u, NONE, 0u};
+            if (d.nbr_plus[b * 8u + o] != NONE) {  // nodes of blocks that are not active do not exist
+                float pt[D];
+#pragma unroll
+                for (int k = 0; k < D; k++) pt[k] = (float)(bc[k] * BW + t[k]) * h;
+                c = node_cdf_eval<D>(d, pt);
+                if (o == 0) {
+                    int ln = t[0] + (t[1] << BS) + (D == 3 ? (t[2] << (2 * BS)) : 0);
+                    d.node_cdf[(size_t)b * NPB + ln] = c;
+                }
             }
+            s_cdf[n] = c;
+            mine |= c.affinities;
         }
+        if (mine != 0u) s_any[it] = 1u;  // benign race: every writer stores 1
         __syncthreads();
-        for (uint32_t j = start + tid; j < start + cnt; j += 256) {
+        const bool any = s_any[it] != 0u;
+        if (tid == 0) {
+            d.block_cpic[b] = any ? 1u : 0u;
+            if (any && cnt > 0) d.cpic_list[atomicAdd(&d.counters[CTR_NCPIC], 1u)] = b;  // few blocks
+        }
+        if (!any) continue;
+        for (uint32_t j = start + tid; j < start + cnt; j += CDF_THREADS) {
             const uint32_t src = d.perm[j];
             float nrm[D], dist = 0.f;
             uint32_t aff = 0u;

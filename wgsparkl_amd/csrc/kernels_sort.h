@@ -193,7 +193,8 @@ template <int D> __global__ __launch_bounds__(SORT_THREADS) void k_rebin(Dev d, 
             // links of the previous substep when they exist: a plain idempotent store. A block created just now,
             // re-activated after a pause, or whose neighbour was not active (it held no particle) goes
             // through the hash map.
-            const uint32_t t1 = d.links_epoch[b1] == epoch - 1u ? d.nbr_plus[b1 * 8u + lane] : NONE;
+            const uint32_t le = d.links_epoch[b1], link = d.nbr_plus[b1 * 8u + lane];  // independent loads
+            const uint32_t t1 = le == epoch - 1u ? link : NONE;
             if (t1 != NONE) {
                 d.block_stamp[t1] = epoch;
             } else {
@@ -218,7 +219,7 @@ template <int D> __global__ __launch_bounds__(SORT_THREADS) void k_rebin(Dev d, 
 //   block_start[id] = exclusive scan of the particle counts           (sort.wgsl:101-115 + prefix_sum.wgsl)
 // One workgroup; the number of known blocks is at most a few hundred thousand.
 constexpr int SCAN_THREADS = 1024;
-constexpr int SCAN_ITEMS = 8;
+constexpr int SCAN_ITEMS = 4;
 __global__ __launch_bounds__(SCAN_THREADS) void k_scan_active(Dev d, uint32_t epoch) {
     __shared__ unsigned long long wave_sums[SCAN_THREADS / 64];
     __shared__ unsigned long long carry_s;
@@ -234,8 +235,10 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan_active(Dev d, uint32_t ep
 #pragma unroll
         for (int k = 0; k < SCAN_ITEMS; k++) {
             const uint32_t id = first + k;
-            const bool act = id < nphys && d.block_stamp[id] == epoch;
-            v[k] = act ? ((1ull << 32) | (unsigned long long)d.block_acc[id]) : 0ull;
+            const uint32_t idc = min(id, nphys - 1u);  // both loads unconditional: one round trip, not two
+            const uint32_t stamp = d.block_stamp[idc], acc = d.block_acc[idc];
+            const bool act = id < nphys && stamp == epoch;
+            v[k] = act ? ((1ull << 32) | (unsigned long long)acc) : 0ull;
             sum += v[k];
         }
         unsigned long long inc = sum;
@@ -338,7 +341,6 @@ __global__ __launch_bounds__(SORT_THREADS) void k_canonical_order(Dev d) {
         const uint32_t s = d.cell_start[c], e = d.cell_cursor[c];
         const uint32_t m = e - s;
         if (m < 2) continue;
-        if (d.dbg & 16u) { if (m > 1000000u) d.perm[s] = 0; continue; }
         if (m <= CANON_REG) {
             uint32_t k[CANON_REG];
 #pragma unroll
@@ -346,7 +348,7 @@ __global__ __launch_bounds__(SORT_THREADS) void k_canonical_order(Dev d) {
             bool sorted = true;
 #pragma unroll
             for (int q = 1; q < CANON_REG; q++) sorted = sorted && k[q - 1] <= k[q];
-            if (sorted || (d.dbg & 32u)) continue;
+            if (sorted) continue;
             // (pid << 32 | perm) packed so that one 64-bit compare-exchange moves both;
             // odd-even transposition sort: fixed network, no run-time register indexing
             unsigned long long kp[CANON_REG];
