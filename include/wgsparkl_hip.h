@@ -112,6 +112,14 @@ typedef struct {
     float com[3];          /* world-space centre of mass (wgrapier MassProperties.com) */
 } wgs_collider;
 #define WGS_MAX_COLLIDERS 16 /* src/grid/grid.wgsl:230-240: 16 affinity + 16 sign bits */
+/* Mass properties of the rigid body behind a collider (wgrapier GpuBodySet local_mprops, bound at
+ * src/solver/rigid_impulses.wgsl:81-84). All zero (the default) = kinematic or fixed body: it follows its
+ * velocity. Non-zero = dynamic: the particles push it back (two-way coupling, src/solver/p2g.wgsl:200-228,
+ * src/solver/rigid_impulses.wgsl:95-136). The centre of mass is wgs_collider.com. */
+typedef struct {
+    float inv_mass[3];           /* per-axis inverse mass */
+    float inv_inertia_local[9];  /* 3D: column-major inverse inertia tensor in the body frame; 2D: [0] = 1/I */
+} wgs_mass_properties;
 
 /* Constitutive model (the reference picks at shader-compile time,
  * src/solver/particle_update.wgsl:7-8; default = corotated like the reference). */
@@ -194,6 +202,13 @@ wgs_status wgs_set_sim_params(wgs_data *data, const wgs_sim_params *params);
 wgs_status wgs_set_collider_poses(wgs_data *data, const wgs_pose *poses, const float *coms /* n*3 or NULL */, size_t n);
 /* queue.write_buffer(bodies.vels()) (src_testbed/step.rs:98-119) */
 wgs_status wgs_set_body_velocities(wgs_data *data, const wgs_velocity *vels, size_t n);
+/* GpuBodySet::from_rapier's local mass properties (src/pipeline.rs:145, wgrapier): which bodies are dynamic.
+ * Stream-ordered like the other setters. Not available on sharded data (WGS_ERR_UNSUPPORTED). */
+wgs_status wgs_set_body_mass_properties(wgs_data *data, const wgs_mass_properties *mprops, size_t n);
+/* poses_staging read-back after the step (src_testbed/step.rs:129-132,175-198): the poses the device
+ * integrated (every substep ends with src/solver/rigid_impulses.wgsl:95-136). Blocking. `vels` and `coms`
+ * (n*3 floats, world space) may be NULL. */
+wgs_status wgs_read_body_poses(wgs_data *data, wgs_pose *poses, wgs_velocity *vels, float *coms, size_t n);
 
 /* positions is the only particle buffer the reference creates COPY_SRC (src/solver/particle3d.rs:197-201).
  * out: num_particles * WGS_DIM floats, in the caller's original particle order. Blocking. */

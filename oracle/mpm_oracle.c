@@ -943,9 +943,20 @@ void orc_g2p_cdf(orc_particles *p, const orc_params *prm, const orc_grid *g) {
 /* ------------------------------------------------------------------------ */
 /* P2G — solver/p2g.wgsl:69-236                                             */
 /* ------------------------------------------------------------------------ */
+/* rigid_impulses.wgsl:50-58: fixed-point conversion. WGSL's i32(f32) truncates toward zero and
+ * saturates (NaN -> 0). */
+static int32_t flt2int(float f) {
+    float s = f * 1e5f;
+    if (!(s == s)) return 0;
+    if (s >= 2147483648.0f) return INT32_MAX;
+    if (s <= -2147483648.0f) return INT32_MIN;
+    return (int32_t)s;
+}
+
 void orc_p2g(const orc_particles *p, const orc_params *prm, orc_grid *g) {
     const real h = prm->cell_width;
-    for (int k = 0; k < 16 * (D + ORC_ANG); k++) g->impulses[k] = 0;
+    /* the accumulators are zeroed by their consumer (rigid_impulses.wgsl:104-109); orc_step, which has
+     * no bodies, clears them itself */
     for (int32_t b = 0; b < g->n_blocks; b++) {
         for (uint32_t t = 0; t < NPB; t++) {
             int tl[3] = {0, 0, 0};
@@ -1043,9 +1054,9 @@ void orc_p2g(const orc_particles *p, const orc_params *prm, orc_grid *g) {
             if (collider_id != ORC_NONE && collider_id < 16) {
                 /* rigid_impulses.wgsl:52-54 flt2int: i32(flt * 1e5), accumulated atomically */
                 for (int k = 0; k < D; k++)
-                    g->impulses[collider_id * (D + ORC_ANG) + k] += (int32_t)((float)imp[k] * 1e5f);
+                    g->impulses[collider_id * (D + ORC_ANG) + k] += flt2int((float)imp[k]);
                 for (int k = 0; k < ORC_ANG; k++)
-                    g->impulses[collider_id * (D + ORC_ANG) + D + k] += (int32_t)((float)ang[k] * 1e5f);
+                    g->impulses[collider_id * (D + ORC_ANG) + D + k] += flt2int((float)ang[k]);
             }
         }
     }
@@ -1213,9 +1224,147 @@ void orc_step(orc_particles *p, const orc_params *prm, orc_grid *g, int n_subste
          * (then every particle cdf is reset to default_cdf()). */
         orc_grid_update_cdf(prm, g);
         orc_g2p_cdf(p, prm, g);
+        for (int k = 0; k < 16 * (D + ORC_ANG); k++) g->impulses[k] = 0;
         orc_p2g(p, prm, g);
         orc_grid_update(prm, g);
         orc_g2p(p, prm, g);
         orc_particle_update(p, prm);
+    }
+}
+
+/* ------------------------------------------------------------------------ */
+/* Rigid bodies: two-way coupling — solver/rigid_impulses.wgsl              */
+/* Body::applyImpulse / integrateVelocity / updateMprops are third party     */
+/* (wgrapier, not on disk): restated from rapier's published algorithms      */
+/* (RigidBodyVelocity::integrate, MassProperties world-space update).        */
+/* ------------------------------------------------------------------------ */
+
+/* rigid_impulses.wgsl:138-149 update_world_mass_properties: world com = pose * local com,
+ * world inverse inertia = R I^-1 R^T. */
+void orc_update_world_mass_properties(orc_collider *cols, orc_body *bodies, int n) {
+    for (int i = 0; i < n; i++) {
+        orc_collider *c = &cols[i];
+        orc_body *b = &bodies[i];
+        real com[3] = {0, 0, 0};
+        pose_to_world(c, b->local_com, com);
+        for (int k = 0; k < D; k++) c->com[k] = com[k];
+#if D == 2
+        b->inv_inertia_world[0] = b->inv_inertia_local[0];
+#else
+        /* columns of R = images of the basis vectors */
+        real rm[9], tmp[9];
+        for (int col = 0; col < 3; col++) {
+            real e[3] = {0, 0, 0}, o[3];
+            e[col] = 1;
+            quat_rotate(c->rot, e, o);
+            for (int r = 0; r < 3; r++) rm[col * 3 + r] = o[r];
+        }
+        /* tmp = R * Il ; world = tmp * R^T   (column-major, element (r,c) at [c*3+r]) */
+        for (int cc = 0; cc < 3; cc++)
+            for (int r = 0; r < 3; r++) {
+                real s = 0;
+                for (int k = 0; k < 3; k++) s += rm[k * 3 + r] * b->inv_inertia_local[cc * 3 + k];
+                tmp[cc * 3 + r] = s;
+            }
+        for (int cc = 0; cc < 3; cc++)
+            for (int r = 0; r < 3; r++) {
+                real s = 0;
+                for (int k = 0; k < 3; k++) s += tmp[k * 3 + r] * rm[k * 3 + cc];
+                b->inv_inertia_world[cc * 3 + r] = s;
+            }
+#endif
+    }
+}
+
+/* rigid_impulses.wgsl:95-136 update: apply the accumulated impulse, cap the velocities, integrate the
+ * pose, then apply gravity to bodies with a non-zero inverse mass. */
+void orc_integrate_bodies(const orc_params *prm, orc_collider *cols, const orc_body *bodies, int n, int32_t *impulses) {
+    const real dt = prm->dt, h = prm->cell_width;
+    for (int i = 0; i < n && i < 16; i++) {
+        orc_collider *c = &cols[i];
+        const orc_body *b = &bodies[i];
+        int32_t *acc = &impulses[i * (D + ORC_ANG)];
+        real lin[3] = {0, 0, 0}, ang[3] = {0, 0, 0};
+        for (int k = 0; k < D; k++) lin[k] = (real)((float)acc[k] / 1e5f);
+        for (int k = 0; k < ORC_ANG; k++) ang[k] = (real)((float)acc[D + k] / 1e5f);
+        for (int k = 0; k < D + ORC_ANG; k++) acc[k] = 0;
+        /* Body::applyImpulse */
+        real nl[3] = {0, 0, 0}, na[3] = {0, 0, 0};
+        for (int k = 0; k < D; k++) nl[k] = c->linvel[k] + b->inv_mass[k] * lin[k];
+#if D == 2
+        na[0] = c->angvel[0] + b->inv_inertia_world[0] * ang[0];
+#else
+        for (int r = 0; r < 3; r++) {
+            real s = 0;
+            for (int k = 0; k < 3; k++) s += b->inv_inertia_world[k * 3 + r] * ang[k];
+            na[r] = c->angvel[r] + s;
+        }
+#endif
+        real ln2 = 0, an2 = 0, il2 = 0, ia2 = 0;
+        for (int k = 0; k < D; k++) { ln2 += nl[k] * nl[k]; il2 += lin[k] * lin[k]; }
+        for (int k = 0; k < ORC_ANG; k++) { an2 += na[k] * na[k]; ia2 += ang[k] * ang[k]; }
+        real lnorm = r_sqrt(ln2), anorm = r_sqrt(an2);
+        real lin_limit = R(0.1) * h / dt, ang_limit = R(1.0);
+        if (r_sqrt(il2) != 0 || r_sqrt(ia2) != 0) {
+            if (lnorm > lin_limit)
+                for (int k = 0; k < D; k++) nl[k] = nl[k] * (lin_limit / lnorm);
+            if (anorm > ang_limit)
+                for (int k = 0; k < ORC_ANG; k++) na[k] = na[k] * (ang_limit / anorm);
+        }
+        /* Body::integrateVelocity (rapier RigidBodyVelocity::integrate): rotate about the world centre of
+         * mass by exp(angvel dt), translate by linvel dt, renormalise the rotation. */
+        real comw[3] = {0, 0, 0}, arm[3] = {0, 0, 0}, rarm[3] = {0, 0, 0};
+        pose_to_world(c, b->local_com, comw);
+        for (int k = 0; k < D; k++) arm[k] = c->trans[k] - comw[k];
+#if D == 2
+        real a = na[0] * dt;
+        real ca = (real)cos((double)a), sa = (real)sin((double)a);
+        rarm[0] = ca * arm[0] - sa * arm[1];
+        rarm[1] = sa * arm[0] + ca * arm[1];
+        real nc = ca * c->rot[0] - sa * c->rot[1], ns = sa * c->rot[0] + ca * c->rot[1];
+        real nn = r_sqrt(nc * nc + ns * ns);
+        c->rot[0] = nc / nn;
+        c->rot[1] = ns / nn;
+#else
+        real ax[3] = {na[0] * dt, na[1] * dt, na[2] * dt};
+        real angle = r_sqrt(ax[0] * ax[0] + ax[1] * ax[1] + ax[2] * ax[2]);
+        real dq[4] = {0, 0, 0, 1};
+        if (angle != 0) {
+            real s = (real)sin((double)angle * 0.5) / angle;
+            dq[0] = ax[0] * s; dq[1] = ax[1] * s; dq[2] = ax[2] * s;
+            dq[3] = (real)cos((double)angle * 0.5);
+        }
+        quat_rotate(dq, arm, rarm);
+        /* dq * rot (Hamilton product, (i,j,k,w) storage) */
+        const real *q = c->rot;
+        real nq[4];
+        nq[0] = dq[3] * q[0] + dq[0] * q[3] + dq[1] * q[2] - dq[2] * q[1];
+        nq[1] = dq[3] * q[1] - dq[0] * q[2] + dq[1] * q[3] + dq[2] * q[0];
+        nq[2] = dq[3] * q[2] + dq[0] * q[1] - dq[1] * q[0] + dq[2] * q[3];
+        nq[3] = dq[3] * q[3] - dq[0] * q[0] - dq[1] * q[1] - dq[2] * q[2];
+        real nn = r_sqrt(nq[0] * nq[0] + nq[1] * nq[1] + nq[2] * nq[2] + nq[3] * nq[3]);
+        for (int k = 0; k < 4; k++) c->rot[k] = nq[k] / nn;
+#endif
+        for (int k = 0; k < D; k++) c->trans[k] = comw[k] + rarm[k] + nl[k] * dt;
+        /* gravity on dynamic axes only (rigid_impulses.wgsl:130-131) */
+        for (int k = 0; k < D; k++) c->linvel[k] = nl[k] + (b->inv_mass[k] != 0 ? prm->gravity[k] * dt : 0);
+        for (int k = 0; k < ORC_ANG; k++) c->angvel[k] = na[k];
+    }
+}
+
+/* pipeline.rs:201-280 with bodies: world mass properties first, body integration last. */
+void orc_step_bodies(orc_particles *p, const orc_params *prm, orc_grid *g, orc_collider *cols, orc_body *bodies,
+                     int n_substeps) {
+    for (int k = 0; k < 16 * (D + ORC_ANG); k++) g->impulses[k] = 0;
+    for (int s = 0; s < n_substeps; s++) {
+        orc_update_world_mass_properties(cols, bodies, prm->n_colliders);
+        orc_sort(p, prm, g);
+        orc_grid_update_cdf(prm, g);
+        orc_g2p_cdf(p, prm, g);
+        orc_p2g(p, prm, g);
+        orc_grid_update(prm, g);
+        orc_g2p(p, prm, g);
+        orc_particle_update(p, prm);
+        orc_integrate_bodies(prm, cols, bodies, prm->n_colliders, g->impulses);
     }
 }

@@ -93,6 +93,16 @@ typedef struct {
     real com[3];         /* world-space centre of mass */
 } orc_collider;
 
+/* Mass properties of the rigid body a collider is attached to (wgrapier
+ * GpuBodySet local_mprops / mprops as used by rigid_impulses.wgsl:81-84).
+ * A kinematic or fixed body has inv_mass = 0 and inv_inertia_local = 0. */
+typedef struct {
+    real inv_mass[3];           /* per-axis inverse mass (rapier: effective_inv_mass) */
+    real inv_inertia_local[9];  /* 3D: column-major inverse inertia tensor in the body frame; 2D: [0] */
+    real local_com[3];          /* centre of mass in the body frame */
+    real inv_inertia_world[9];  /* out: R inv_inertia_local R^T (3D) / copy (2D), by orc_update_world_mass_properties */
+} orc_body;
+
 typedef struct {
     real gravity[3];
     real dt;
@@ -163,6 +173,14 @@ void orc_grid_update(const orc_params *prm, orc_grid *g);
 void orc_g2p(orc_particles *p, const orc_params *prm, const orc_grid *g);
 void orc_particle_update(orc_particles *p, const orc_params *prm);
 void orc_step(orc_particles *p, const orc_params *prm, orc_grid *g, int n_substeps);
+
+/* rigid bodies (two-way coupling) — rigid_impulses.wgsl:95-149, pipeline.rs:204-205,268-280.
+ * orc_step_bodies = the full pipeline.rs:201-280 order for analytic colliders: the colliders of
+ * prm (which must point at `cols`) are moved by the impulses p2g accumulated. */
+void orc_update_world_mass_properties(orc_collider *cols, orc_body *bodies, int n);
+void orc_integrate_bodies(const orc_params *prm, orc_collider *cols, const orc_body *bodies, int n, int32_t *impulses);
+void orc_step_bodies(orc_particles *p, const orc_params *prm, orc_grid *g, orc_collider *cols, orc_body *bodies,
+                     int n_substeps);
 
 #ifdef __cplusplus
 }

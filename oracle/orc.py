@@ -57,6 +57,10 @@ class Oracle:
             _fields_ = [("shape_type", C.c_int32), ("shape", R * 4), ("rot", R * 4), ("trans", R * 3),
                         ("scale", R), ("linvel", R * 3), ("angvel", R * 3), ("com", R * 3)]
 
+        class Body(C.Structure):
+            _fields_ = [("inv_mass", R * 3), ("inv_inertia_local", R * 9), ("local_com", R * 3),
+                        ("inv_inertia_world", R * 9)]
+
         class Params(C.Structure):
             _fields_ = [("gravity", R * 3), ("dt", R), ("cell_width", R), ("model", C.c_int32),
                         ("n_colliders", C.c_int32), ("colliders", C.POINTER(Collider))]
@@ -69,7 +73,7 @@ class Oracle:
                         ("particle_next", U32P), ("node_mv", RP), ("node_cdf_dist", RP),
                         ("node_cdf_aff", U32P), ("node_cdf_closest", U32P), ("impulses", I32P)]
 
-        self.Particles, self.Collider, self.Params, self.Grid = Particles, Collider, Params, Grid
+        self.Particles, self.Collider, self.Params, self.Grid, self.Body = Particles, Collider, Params, Grid, Body
         L = self.lib
         L.orc_pack_key.restype = C.c_uint32
         L.orc_pack_key.argtypes = [I32P]
@@ -162,6 +166,17 @@ class Oracle:
         return OracleState(self, particles, params, colliders, cell_width, grid_capacity, model)
 
 
+def _is_moving(c) -> bool:
+    return any(float(v) != 0.0 for k in ("linvel", "angvel", "inv_mass", "inv_inertia_local")
+               for v in getattr(c, k, ()))
+
+
+def _quat_rotate(q, v):
+    u, w = q[:3], q[3]
+    t = 2.0 * np.cross(u, v)
+    return v + w * t + np.cross(u, t)
+
+
 class OracleState:
     """Particles + grid in the oracle's precision; `step()` advances it."""
 
@@ -187,6 +202,12 @@ class OracleState:
         self.cols = (orc.Collider * max(1, len(colliders)))()
         for i, c in enumerate(colliders):
             self._fill_collider(self.cols[i], c)
+        self.bodies = (orc.Body * max(1, len(colliders)))()
+        for i, c in enumerate(colliders):
+            self._fill_body(self.bodies[i], self.cols[i], c)
+        self.n_colliders = len(colliders)
+        # like the HIP host side: bodies that cannot move skip the (identity) integration pass
+        self.moving = any(_is_moving(c) for c in colliders)
         prm = orc.Params()
         g = list(params.gravity) + [0.0] * (3 - len(params.gravity))
         prm.gravity = (orc.real * 3)(*g)
@@ -235,9 +256,43 @@ class OracleState:
         com = list(c.com) if c.com is not None else list(c.translation)
         dst.com = (R * 3)(*(com + [0.0] * (3 - len(com))))
 
+    def _fill_body(self, dst, col, c):
+        """Mass properties; the local centre of mass is the world one mapped through the inverse pose."""
+        orc, D = self.orc, self.orc.dim
+        R = orc.real
+        im = list(getattr(c, "inv_mass", (0.0,) * 3))
+        dst.inv_mass = (R * 3)(*(im + [0.0] * (3 - len(im)))[:3])
+        ii = list(getattr(c, "inv_inertia_local", (0.0,) * 9))
+        dst.inv_inertia_local = (R * 9)(*(ii + [0.0] * (9 - len(ii)))[:9])
+        d = np.array([col.com[k] - col.trans[k] for k in range(3)], np.float64)
+        if D == 2:
+            cs, sn = col.rot[0], col.rot[1]
+            loc = np.array([cs * d[0] + sn * d[1], -sn * d[0] + cs * d[1], 0.0]) / col.scale
+        else:
+            loc = _quat_rotate(np.array([-col.rot[0], -col.rot[1], -col.rot[2], col.rot[3]]), d) / col.scale
+        dst.local_com = (R * 3)(*[float(x) for x in loc])
+
     def set_colliders(self, colliders):
         for i, c in enumerate(colliders):
             self._fill_collider(self.cols[i], c)
+            self._fill_body(self.bodies[i], self.cols[i], c)
+        self.moving = any(_is_moving(c) for c in colliders)
+
+    def collider_states(self):
+        """Current (rotation, translation, linvel, angvel, com) of every collider, as float64 arrays."""
+        D = self.orc.dim
+        out = []
+        for i in range(self.n_colliders):
+            c = self.cols[i]
+            out.append(dict(rotation=np.array(list(c.rot)[:(2 if D == 2 else 4)], np.float64),
+                            translation=np.array(list(c.trans)[:D], np.float64),
+                            linvel=np.array(list(c.linvel)[:D], np.float64),
+                            angvel=np.array(list(c.angvel)[:(1 if D == 2 else 3)], np.float64),
+                            com=np.array(list(c.com)[:D], np.float64)))
+        return out
+
+    def impulses(self):
+        return self.g["impulses"].copy()
 
     def set_params(self, params):
         g = list(params.gravity) + [0.0] * (3 - len(params.gravity))
@@ -253,8 +308,18 @@ class OracleState:
     def g2p(self): self.orc.lib.orc_g2p(C.byref(self.P), C.byref(self.prm), C.byref(self.G))
     def particle_update(self): self.orc.lib.orc_particle_update(C.byref(self.P), C.byref(self.prm))
 
+    def update_world_mass_properties(self):
+        self.orc.lib.orc_update_world_mass_properties(self.cols, self.bodies, self.n_colliders)
+
+    def integrate_bodies(self):
+        self.orc.lib.orc_integrate_bodies(C.byref(self.prm), self.cols, self.bodies, self.n_colliders, self.G.impulses)
+
     def step(self, n_substeps=1):
-        self.orc.lib.orc_step(C.byref(self.P), C.byref(self.prm), C.byref(self.G), int(n_substeps))
+        if self.moving:  # pipeline.rs:201-280 with the rigid-body passes (rigid_impulses.wgsl)
+            self.orc.lib.orc_step_bodies(C.byref(self.P), C.byref(self.prm), C.byref(self.G), self.cols, self.bodies,
+                                         int(n_substeps))
+        else:
+            self.orc.lib.orc_step(C.byref(self.P), C.byref(self.prm), C.byref(self.G), int(n_substeps))
 
     @property
     def n_blocks(self): return int(self.G.n_blocks)

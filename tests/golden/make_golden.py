@@ -35,6 +35,10 @@ def main():
         out[f"{name}/grid_cells"] = cells
         out[f"{name}/grid_vm"] = np.asarray(mv, np.float64)
         out[f"{name}/grid_aff"] = aff
+        if sc["colliders"]:
+            bodies = st.collider_states()
+            for key in ("rotation", "translation", "linvel", "angvel"):
+                out[f"{name}/body_{key}"] = np.stack([b[key] for b in bodies])
     np.savez_compressed(os.path.join(HERE, "oracle_regression.npz"), **out)
     print("wrote", len(out), "arrays")
 

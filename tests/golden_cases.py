@@ -42,5 +42,22 @@ def tilted_box2d():
     return sc
 
 
+def dynamic_ball2d():
+    """Two-way coupling: a dynamic ball dropped on an elastic block next to a kinematic, spinning box."""
+    sc = scenes.elastic_block_2d(nx=16, ny=16, with_floor=False)
+    sc["colliders"] = [Collider.ball(1.5, (11.0, 16.6), linvel=(0.3, -2.0, 0.0)).with_density(500.0, 2),
+                       Collider.cuboid((1.0, 1.0), (5.5, 10.0), linvel=(0.5, 0.0, 0.0), angvel=(2.0,), com=(5.0, 10.0))]
+    return sc
+
+
+def dynamic_ball3d():
+    sc = scenes.neo_hookean_cube(n_side=8, with_floor=False)
+    sc["colliders"] = [Collider.ball(1.5, (21.8, 13.3, 22.1), linvel=(0.2, -3.0, 0.0)).with_density(500.0, 3),
+                       Collider.cuboid((1.0, 1.0, 1.0), (18.9, 10.0, 22.0), linvel=(0.5, 0.0, 0.0), angvel=(0.0, 0.0, 0.8),
+                                       com=(18.7, 10.0, 22.0))]
+    return sc
+
+
 CASES = {"cloud3d": (cloud3d, 3), "cloud2d": (cloud2d, 3), "sand3d": (sand3d, 2), "floor3d": (floor3d, 20),
-         "tilted_box2d": (tilted_box2d, 20)}
+         "tilted_box2d": (tilted_box2d, 20), "dynamic_ball2d": (dynamic_ball2d, 120),
+         "dynamic_ball3d": (dynamic_ball3d, 120)}

@@ -141,6 +141,73 @@ def test_grid_overflow_is_reported(hip_libs):
         run_gpu(sc, 1)
 
 
+def test_body_setters_and_readback(hip_libs, oracle_libs):
+    """wgs_set_body_velocities / wgs_set_collider_poses / wgs_set_body_mass_properties between steps, and the
+    pose read-back of the testbed (src_testbed/step.rs:79-132): the device-integrated poses are not rolled back
+    by a velocity write, a pose write moves the centre of mass with the body."""
+    from golden_cases import dynamic_ball3d
+    from helpers import oracle, pipeline
+    from wgsparkl_amd import MpmData
+    import dataclasses
+    sc = dynamic_ball3d()
+    args = (sc["colliders"], sc["cell_width"], sc["grid_capacity"], sc["model"])
+    pipe = pipeline(3)
+    data = MpmData.new(pipe, sc["params"], sc["particles"], *args)
+    st = oracle(3, np.float64).new_state(sc["particles"], sc["params"], *args)
+    pipe.step(data, 30); st.step(30)
+    # velocity write only: poses keep what the device integrated
+    cur = st.collider_states()
+    data.lib.wgs_sync(data._h)
+    vel = (data.T.Velocity * 2)()
+    vel[0].linear = (0.1, -1.0, 0.0); vel[0].angular = (0.0, 0.5, 0.0)
+    vel[1].linear = (0.0, 0.2, 0.0); vel[1].angular = (0.0, 0.0, -0.3)
+    from wgsparkl_amd import _ffi
+    _ffi.check(data.lib, data.lib.wgs_set_body_velocities(data._h, vel, 2))
+    for i in range(2):
+        for k in range(3):
+            st.cols[i].linvel[k] = vel[i].linear[k]
+            st.cols[i].angvel[k] = vel[i].angular[k]
+    pipe.step(data, 30); st.step(30)
+    st.update_world_mass_properties()
+    got, ref = data.read_body_poses(), st.collider_states()
+    for i in range(2):
+        for key in ("rotation", "translation", "linvel", "angvel", "com"):
+            assert np.allclose(got[i][key], ref[i][key], rtol=0.0, atol=3e-4), (i, key, got[i][key], ref[i][key])
+    assert np.abs(got[0]["translation"] - cur[0]["translation"]).max() < 0.2   # not rolled back to the initial pose
+    # full refresh through the host mirror (poses + velocities + mass properties), body 0 made kinematic
+    cols = [dataclasses.replace(sc["colliders"][0], translation=(21.5, 13.4, 22.0), linvel=(0.0, -0.5, 0.0),
+                                inv_mass=(0.0,) * 3, inv_inertia_local=(0.0,) * 9), sc["colliders"][1]]
+    data.set_colliders(cols); st.set_colliders(cols)
+    pipe.step(data, 20); st.step(20)
+    st.update_world_mass_properties()
+    got, ref = data.read_body_poses(), st.collider_states()
+    for i in range(2):
+        for key in ("rotation", "translation", "linvel", "angvel", "com"):
+            assert np.allclose(got[i][key], ref[i][key], rtol=0.0, atol=3e-4), (i, key, got[i][key], ref[i][key])
+    assert abs(got[0]["linvel"][1] + 0.5) < 1e-6   # kinematic now: keeps its velocity, no gravity
+    gp = data.read_particles()
+    same = gp.cdf_affinity == st.arr["cdf_affinity"]
+    assert same.mean() > 0.99
+    assert rel_rms(gp.pos[same], st.arr["pos"][same]) < 1e-5
+
+
+def test_dynamic_bodies_refused_on_sharded_data(hip_libs):
+    """Two-way coupling needs the impulses of every rank: reported as unsupported, not silently wrong."""
+    from wgsparkl_amd import sharded
+    from golden_cases import dynamic_ball3d
+    from helpers import pipeline
+    sc = dynamic_ball3d()
+    ps = sc["particles"]
+    sh = sharded.GpuShard(pipeline(3), sc["params"], ps, np.arange(ps.n, dtype=np.uint32), sc["colliders"],
+                          sc["cell_width"], sc["grid_capacity"], sharded.INT_MIN, sharded.INT_MAX, False, False, ps.n,
+                          sc["model"])
+    mp = (sh.T.MassProperties * 2)()
+    mp[0].inv_mass = (1.0, 1.0, 1.0)
+    assert sh.lib.wgs_set_body_mass_properties(sh._h, mp, 2) != 0
+    mp[0].inv_mass = (0.0, 0.0, 0.0)   # kinematic bodies are fine: every rank integrates the same poses
+    assert sh.lib.wgs_set_body_mass_properties(sh._h, mp, 2) == 0
+
+
 # ---------------------------------------------------------------------------------------------
 # Committed golden vectors (tests/golden/oracle_regression.npz) incl. the CPIC collider paths
 # ---------------------------------------------------------------------------------------------
@@ -176,6 +243,14 @@ def test_against_committed_golden_vectors(hip_libs, oracle_libs, name):
     o32 = grid_of(st32)[1]
     assert_close_to_truth("grid velocity", vm[:, :dim], o32[:, :dim], _GOLD[f"{name}/grid_vm"][:, :dim],
                           5e-4 if cpic else GRID_V_TOL)
+    if cpic:
+        # rigid bodies, integrated on the device every substep (rigid_impulses.wgsl:95-136); the dynamic ones
+        # are pushed by the particles (two-way coupling, p2g.wgsl:200-228). Absolute tolerance: positions are
+        # O(10), velocities O(1), fixed-point impulses have a 1e-5 resolution.
+        bodies = data.read_body_poses()
+        for key in ("rotation", "translation", "linvel", "angvel"):
+            got_b = np.stack([b[key] for b in bodies])
+            assert np.allclose(got_b, _GOLD[f"{name}/body_{key}"], rtol=0.0, atol=3e-4), (key, got_b, _GOLD[f"{name}/body_{key}"])
 
 
 def test_cpic_node_cdf_bit_exact(hip_libs, oracle_libs):

@@ -26,3 +26,7 @@ def test_oracle_matches_committed_vectors(oracle_libs, name):
         ref = GOLD[f"{name}/{f}"]
         assert np.allclose(st.arr[f], ref, rtol=1e-9, atol=1e-9 * max(1.0, np.abs(ref).max())), f
     assert np.allclose(mv, GOLD[f"{name}/grid_vm"], rtol=1e-9, atol=1e-9 * np.abs(GOLD[f"{name}/grid_vm"]).max())
+    if sc["colliders"]:
+        bodies = st.collider_states()
+        for key in ("rotation", "translation", "linvel", "angvel"):
+            assert np.allclose(np.stack([b[key] for b in bodies]), GOLD[f"{name}/body_{key}"], rtol=0.0, atol=1e-9), key

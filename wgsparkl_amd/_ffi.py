@@ -18,7 +18,7 @@ PASS_NAMES = ("update rigid particles", "grid sort", "grid_update_cdf", "p2g_cdf
 EXPORTS = (
     "wgs_last_error", "wgs_dim", "wgs_pipeline_create", "wgs_pipeline_destroy", "wgs_data_create",
     "wgs_data_destroy", "wgs_set_constitutive_model", "wgs_step", "wgs_sync", "wgs_set_sim_params",
-    "wgs_set_collider_poses", "wgs_set_body_velocities", "wgs_read_positions", "wgs_read_particles",
+    "wgs_set_collider_poses", "wgs_set_body_velocities", "wgs_set_body_mass_properties", "wgs_read_body_poses", "wgs_read_positions", "wgs_read_particles",
     "wgs_read_grid", "wgs_read_blocks", "wgs_read_timings", "wgs_get_stats",
     # multi-GPU (x-slab decomposition; new design, no reference counterpart)
     "wgs_data_create_sharded", "wgs_shard_halo_record_bytes", "wgs_shard_particle_record_bytes",
@@ -85,6 +85,9 @@ def make_types(D: int):
     class Collider(C.Structure):
         _fields_ = [("shape_type", u), ("shape", f * 4), ("pose", Pose), ("velocity", Velocity), ("com", f * 3)]
 
+    class MassProperties(C.Structure):
+        _fields_ = [("inv_mass", f * 3), ("inv_inertia_local", f * 9)]
+
     class NodeRecord(C.Structure):
         _fields_ = [("cell", C.c_int32 * D), ("velocity", f * D), ("mass", f), ("cdf_distance", f),
                     ("cdf_affinities", u), ("cdf_closest_id", u)]
@@ -98,7 +101,7 @@ def make_types(D: int):
 
     ns = dict(SimParams=SimParams, Elastic=Elastic, DruckerPrager=DruckerPrager, PlasticState=PlasticState,
               Phase=Phase, Cdf=Cdf, Dynamics=Dynamics, Particle=Particle, Pose=Pose, Velocity=Velocity,
-              Collider=Collider, NodeRecord=NodeRecord, BlockRecord=BlockRecord, Stats=Stats)
+              Collider=Collider, MassProperties=MassProperties, NodeRecord=NodeRecord, BlockRecord=BlockRecord, Stats=Stats)
     return type("Types", (), ns)
 
 
@@ -138,6 +141,8 @@ def load(dim: int):
     lib.wgs_set_sim_params.argtypes = [vp, C.POINTER(T.SimParams)]
     lib.wgs_set_collider_poses.argtypes = [vp, C.POINTER(T.Pose), C.POINTER(C.c_float), C.c_size_t]
     lib.wgs_set_body_velocities.argtypes = [vp, C.POINTER(T.Velocity), C.c_size_t]
+    lib.wgs_set_body_mass_properties.argtypes = [vp, C.POINTER(T.MassProperties), C.c_size_t]
+    lib.wgs_read_body_poses.argtypes = [vp, C.POINTER(T.Pose), C.POINTER(T.Velocity), C.POINTER(C.c_float), C.c_size_t]
     lib.wgs_read_positions.argtypes = [vp, C.POINTER(C.c_float)]
     lib.wgs_read_particles.argtypes = [vp, C.POINTER(T.Particle), C.POINTER(T.PlasticState)]
     lib.wgs_read_grid.argtypes = [vp, C.POINTER(T.NodeRecord), C.c_size_t, C.POINTER(C.c_size_t)]

@@ -20,6 +20,7 @@
 #include <string>
 #include <vector>
 
+#include "kernels_bodies.h"
 #include "kernels_cdf.h"
 #include "kernels_shard.h"
 #include "kernels_sort.h"
@@ -49,7 +50,7 @@ wgs_status fail(wgs_status code, const std::string &msg) {
 
 struct Events {
     static constexpr int MAX_SUBSTEPS = 64;
-    static constexpr int MARKS = 8;  // boundaries: start, sort, cdf_nodes, cdf_particles, p2g, grid, g2p(end)
+    static constexpr int MARKS = 8;  // boundaries: start, sort, cdf_nodes, cdf_particles, p2g, grid, g2p, bodies(end)
     hipEvent_t ev[MAX_SUBSTEPS][MARKS];
     int used = 0;
     bool created = false;
@@ -87,7 +88,10 @@ struct wgs_data {
     uint32_t *static_flags = nullptr;  // bit0 has_plasticity, bit1 has_phase
     SimParamsDev *sp = nullptr;
     ColliderDev *colliders = nullptr;
-    std::vector<ColliderDev> host_colliders;
+    std::vector<ColliderDev> host_colliders;  // what the host last wrote (poses / velocities move on the device)
+    std::vector<BodyDev> host_bodies;
+    bool bodies_move = false;   // some body has a velocity or a mass: integrate_bodies runs every substep
+    bool two_way = false;       // some body is dynamic: P2G accumulates impulses
     SimParamsDev host_sp{};
     Events events;
     float timings[WGS_NUM_PASSES] = {0};
@@ -288,11 +292,12 @@ void resolve_timings(wgs_data *d) {
     if (!d->timings_pending) return;
     hipStreamSynchronize(d->stream);
     for (int p = 0; p < WGS_NUM_PASSES; p++) d->timings[p] = 0.f;
-    // marks: 0 start | 1 after sort | 2 after node cdf | 3 after particle cdf | 4 after p2g | 5 after grid update | 6 after fused g2p
-    const int pass_of_mark[6] = {WGS_PASS_GRID_SORT, WGS_PASS_GRID_UPDATE_CDF, WGS_PASS_G2P_CDF,
-                                 WGS_PASS_P2G,       WGS_PASS_GRID_UPDATE,     WGS_PASS_G2P};
+    // marks: 0 start | 1 after sort | 2 after node cdf | 3 after particle cdf | 4 after p2g | 5 after grid update |
+    //        6 after fused g2p | 7 after integrate_bodies
+    const int pass_of_mark[7] = {WGS_PASS_GRID_SORT, WGS_PASS_GRID_UPDATE_CDF, WGS_PASS_G2P_CDF,   WGS_PASS_P2G,
+                                 WGS_PASS_GRID_UPDATE, WGS_PASS_G2P,           WGS_PASS_INTEGRATE_BODIES};
     for (int s = 0; s < d->events.used; s++)
-        for (int m = 0; m < 6; m++) {
+        for (int m = 0; m < 7; m++) {
             float ms = 0.f;
             if (hipEventElapsedTime(&ms, d->events.ev[s][m], d->events.ev[s][m + 1]) == hipSuccess)
                 d->timings[pass_of_mark[m]] += ms;
@@ -350,7 +355,8 @@ template <bool TS> wgs_status enqueue_substep(wgs_data *d, int ts_slot, int part
             const dim3 p2g_grid(grid_for(d, 5)), p2g_block(P2GCfg<D>::NW * 64);
             if (d->cpic) {
                 hipLaunchKernelGGL((k_p2g<D, false>), p2g_grid, p2g_block, 0, s, dev, side, 1);
-                hipLaunchKernelGGL((k_p2g<D, true>), p2g_grid, p2g_block, 0, s, dev, side, 2);
+                if (d->two_way) hipLaunchKernelGGL((k_p2g<D, true, true>), p2g_grid, p2g_block, 0, s, dev, side, 2);
+                else hipLaunchKernelGGL((k_p2g<D, true>), p2g_grid, p2g_block, 0, s, dev, side, 2);
             } else {
                 hipLaunchKernelGGL((k_p2g<D, false>), p2g_grid, p2g_block, 0, s, dev, side, 0);
             }
@@ -361,7 +367,9 @@ template <bool TS> wgs_status enqueue_substep(wgs_data *d, int ts_slot, int part
     if (part != 1) {
         if (n > 0) {
             // ---- "grid_update"
-            if (part == 0) hipLaunchKernelGGL((k_grid_update<D, 0>), dim3(grid_for(d, 4)), dim3(256), 0, s, dev);
+            if (part == 0 && d->two_way)
+                hipLaunchKernelGGL((k_grid_update<D, 0, true>), dim3(grid_for(d, 4)), dim3(256), 0, s, dev);
+            else if (part == 0) hipLaunchKernelGGL((k_grid_update<D, 0>), dim3(grid_for(d, 4)), dim3(256), 0, s, dev);
             else hipLaunchKernelGGL((k_grid_update<D, 2>), dim3(grid_for(d, 4)), dim3(256), 0, s, dev);
         }
         mark(5);
@@ -391,6 +399,11 @@ template <bool TS> wgs_status enqueue_substep(wgs_data *d, int ts_slot, int part
 #undef WGS_LAUNCH_G2P
         }
         mark(6);
+        // ---- "integrate_bodies" (rigid_impulses.wgsl:95-136) + the world mass properties of the next substep
+        // (pipeline.rs:204-205). Skipped while no body has a velocity or a mass: it would be the identity.
+        if (d->bodies_move && dev.n_colliders > 0)
+            hipLaunchKernelGGL(k_bodies_integrate<D>, dim3(1), dim3(16), 0, s, dev);
+        mark(7);
         d->side ^= 1;
         d->substeps++;
         d->prev_sorted = true;
@@ -512,6 +525,8 @@ static wgs_status create_impl(wgs_pipeline *pipeline, const wgs_sim_params *para
     TRY_ALLOC(&dev.counters, (size_t)CTR_COUNT);
     TRY_ALLOC(&d->sp, (size_t)1);
     TRY_ALLOC(&d->colliders, (size_t)WGS_MAX_COLLIDERS);
+    TRY_ALLOC(&dev.bodies, (size_t)WGS_MAX_COLLIDERS);
+    TRY_ALLOC(&dev.impulses, (size_t)WGS_MAX_COLLIDERS * 8);
     TRY_ALLOC(&d->static_radius, (size_t)dev.npad);
     TRY_ALLOC(&d->static_dp, (size_t)dev.npad * 6);
     TRY_ALLOC(&d->static_phase, (size_t)dev.npad * 2);
@@ -601,6 +616,13 @@ static wgs_status create_impl(wgs_pipeline *pipeline, const wgs_sim_params *para
     memset(d->host_colliders.data(), 0, sizeof(ColliderDev) * WGS_MAX_COLLIDERS);
     for (size_t i = 0; i < num_colliders; i++) fill_collider(d->host_colliders[i], colliders[i]);
     H2D(d->colliders, d->host_colliders.data(), sizeof(ColliderDev) * WGS_MAX_COLLIDERS);
+    d->host_bodies.assign(WGS_MAX_COLLIDERS, BodyDev{});
+    d->bodies_move = false;
+    for (size_t i = 0; i < num_colliders; i++)
+        for (int k = 0; k < 3; k++)
+            d->bodies_move = d->bodies_move || colliders[i].velocity.linear[k] != 0.f || colliders[i].velocity.angular[k] != 0.f;
+    if (num_colliders)  // local centres of mass from the world ones (update_world_mass_properties' inverse)
+        hipLaunchKernelGGL(k_bodies_refresh<D>, dim3(1), dim3(16), 0, d->stream, dev, 0xffffu);
 #undef H2D
     if (hipStreamSynchronize(d->stream) != hipSuccess) return bail(fail(WGS_ERR_HIP, "initial upload failed"));
     *out = d;
@@ -773,6 +795,18 @@ wgs_status wgs_set_sim_params(wgs_data *d, const wgs_sim_params *params) {
     return WGS_OK;
 }
 
+// The setters write single fields of the device-side ColliderDev records (strided copies): poses and
+// velocities are integrated on the device, so a whole-record upload would roll them back.
+namespace {
+wgs_status upload_collider_field(wgs_data *d, size_t field_offset, size_t field_bytes, size_t n) {
+    if (n == 0) return WGS_OK;
+    HIP_TRY(hipMemcpy2DAsync(reinterpret_cast<char *>(d->colliders) + field_offset, sizeof(ColliderDev),
+                             reinterpret_cast<const char *>(d->host_colliders.data()) + field_offset, sizeof(ColliderDev),
+                             field_bytes, n, hipMemcpyHostToDevice, d->stream));
+    return WGS_OK;
+}
+}  // namespace
+
 wgs_status wgs_set_collider_poses(wgs_data *d, const wgs_pose *poses, const float *coms, size_t n) {
     if (!d || (!poses && n)) return fail(WGS_ERR_INVALID_ARGUMENT, "NULL argument");
     if (n > d->dev.n_colliders) return fail(WGS_ERR_INVALID_ARGUMENT, "more poses than colliders");
@@ -783,7 +817,14 @@ wgs_status wgs_set_collider_poses(wgs_data *d, const wgs_pose *poses, const floa
         c.scale = poses[i].scale;
         if (coms) for (int k = 0; k < 3; k++) c.com[k] = coms[i * 3 + k];
     }
-    HIP_TRY(hipMemcpyAsync(d->colliders, d->host_colliders.data(), sizeof(ColliderDev) * WGS_MAX_COLLIDERS, hipMemcpyHostToDevice, d->stream));
+    static_assert(offsetof(ColliderDev, scale) + sizeof(float) - offsetof(ColliderDev, rot) == 32, "rot|trans|scale contiguous");
+    wgs_status st = upload_collider_field(d, offsetof(ColliderDev, rot), 32, n);
+    if (st != WGS_OK) return st;
+    if (coms && (st = upload_collider_field(d, offsetof(ColliderDev, com), sizeof(float) * 3, n)) != WGS_OK) return st;
+    // update_world_mass_properties (rigid_impulses.wgsl:138-149) for the new poses; with explicit world
+    // centres of mass the local ones are re-derived instead
+    if (n) hipLaunchKernelGGL(k_bodies_refresh<D>, dim3(1), dim3(16), 0, d->stream, d->dev, coms ? (uint32_t)((1u << n) - 1u) : 0u);
+    HIP_TRY(hipGetLastError());
     return WGS_OK;
 }
 
@@ -794,8 +835,62 @@ wgs_status wgs_set_body_velocities(wgs_data *d, const wgs_velocity *vels, size_t
         ColliderDev &c = d->host_colliders[i];
         for (int k = 0; k < 3; k++) c.linvel[k] = vels[i].linear[k];
         for (int k = 0; k < 3; k++) c.angvel[k] = vels[i].angular[k];
+        for (int k = 0; k < 3; k++) d->bodies_move = d->bodies_move || c.linvel[k] != 0.f || c.angvel[k] != 0.f;
     }
-    HIP_TRY(hipMemcpyAsync(d->colliders, d->host_colliders.data(), sizeof(ColliderDev) * WGS_MAX_COLLIDERS, hipMemcpyHostToDevice, d->stream));
+    static_assert(offsetof(ColliderDev, angvel) - offsetof(ColliderDev, linvel) == 12, "linvel|angvel contiguous");
+    return upload_collider_field(d, offsetof(ColliderDev, linvel), sizeof(float) * 6, n);
+}
+
+wgs_status wgs_set_body_mass_properties(wgs_data *d, const wgs_mass_properties *mp, size_t n) {
+    if (!d || (!mp && n)) return fail(WGS_ERR_INVALID_ARGUMENT, "NULL argument");
+    if (n > d->dev.n_colliders) return fail(WGS_ERR_INVALID_ARGUMENT, "more mass properties than colliders");
+    bool dynamic = false;
+    for (size_t i = 0; i < n; i++) {
+        BodyDev &b = d->host_bodies[i];
+        for (int k = 0; k < 3; k++) b.inv_mass[k] = mp[i].inv_mass[k];
+        for (int k = 0; k < 9; k++) b.inv_inertia_local[k] = mp[i].inv_inertia_local[k];
+    }
+    for (size_t i = 0; i < d->dev.n_colliders; i++) {
+        const BodyDev &b = d->host_bodies[i];
+        for (int k = 0; k < 3; k++) dynamic = dynamic || b.inv_mass[k] != 0.f;
+        for (int k = 0; k < 9; k++) dynamic = dynamic || b.inv_inertia_local[k] != 0.f;
+    }
+    if (dynamic && d->dev.sharded)
+        return fail(WGS_ERR_UNSUPPORTED, "dynamic bodies on sharded data: the impulses would need a reduction over ranks");
+    if (dynamic && !d->dev.imp_slab) {  // per-block partial node impulses, only ever needed with dynamic bodies
+        const size_t count = (size_t)d->dev.cap * Dim<D>::TILE * (D == 3 ? 2 : 1);
+        wgs_status st = dev_alloc(d, &d->dev.imp_slab, count);
+        if (st != WGS_OK) return st;
+    }
+    d->two_way = dynamic;
+    d->bodies_move = d->bodies_move || dynamic;
+    // inv_mass | inv_inertia_local are the first 12 floats of BodyDev; local_com / world inertia stay device-owned
+    static_assert(offsetof(BodyDev, local_com) == sizeof(float) * 12, "BodyDev layout");
+    if (n)
+        HIP_TRY(hipMemcpy2DAsync(d->dev.bodies, sizeof(BodyDev), d->host_bodies.data(), sizeof(BodyDev), sizeof(float) * 12, n,
+                                 hipMemcpyHostToDevice, d->stream));
+    if (n) hipLaunchKernelGGL(k_bodies_refresh<D>, dim3(1), dim3(16), 0, d->stream, d->dev, 0u);
+    HIP_TRY(hipGetLastError());
+    return WGS_OK;
+}
+
+wgs_status wgs_read_body_poses(wgs_data *d, wgs_pose *poses, wgs_velocity *vels, float *coms, size_t n) {
+    if (!d || (!poses && n)) return fail(WGS_ERR_INVALID_ARGUMENT, "NULL argument");
+    if (n > d->dev.n_colliders) return fail(WGS_ERR_INVALID_ARGUMENT, "more poses than colliders");
+    std::vector<ColliderDev> tmp(WGS_MAX_COLLIDERS);
+    HIP_TRY(hipMemcpyAsync(tmp.data(), d->colliders, sizeof(ColliderDev) * WGS_MAX_COLLIDERS, hipMemcpyDeviceToHost, d->stream));
+    HIP_TRY(hipStreamSynchronize(d->stream));
+    for (size_t i = 0; i < n; i++) {
+        const ColliderDev &c = tmp[i];
+        for (int k = 0; k < 4; k++) poses[i].rotation[k] = c.rot[k];
+        for (int k = 0; k < 3; k++) poses[i].translation[k] = c.trans[k];
+        poses[i].scale = c.scale;
+        if (vels) {
+            for (int k = 0; k < 3; k++) vels[i].linear[k] = c.linvel[k];
+            for (int k = 0; k < 3; k++) vels[i].angular[k] = c.angvel[k];
+        }
+        if (coms) for (int k = 0; k < 3; k++) coms[i * 3 + k] = c.com[k];
+    }
     return WGS_OK;
 }
 

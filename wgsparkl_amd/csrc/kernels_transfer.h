@@ -11,7 +11,7 @@
 // pass (the reference keeps P2G and grid update apart only because of WebGPU's
 // binding limit, p2g.wgsl:129-133).
 #pragma once
-#include "device_math.h"
+#include "kernels_bodies.h"
 
 namespace wgs {
 
@@ -39,7 +39,11 @@ template <> struct P2GCfg<2> {
 // `filter`: 0 = every block; in collider simulations the pass is launched twice, CPIC = false with
 // filter 1 (blocks whose tile sees no collider: every affinity is 0, plain MLS-MPM) and CPIC = true
 // with filter 2 (blocks near a collider).
-template <int D, bool CPIC>
+// TWOWAY (with CPIC): the momentum an incompatible (particle, node) pair does not transfer is accumulated
+// as an impulse on the node's closest body (p2g.wgsl:200-228), per node, in a second LDS tile; the
+// per-block partial node sums go to imp_slab and are gathered, converted to fixed point and added to the
+// bodies by the grid update (p2g.wgsl:142-155).
+template <int D, bool CPIC, bool TWOWAY = false>
 __global__ __launch_bounds__(P2GCfg<D>::NW * 64) void k_p2g(Dev d, int side, int filter) {
     using Cfg = P2GCfg<D>;
     constexpr int BW = Dim<D>::BW, BS = Dim<D>::BSHIFT, TW = Dim<D>::TW, TILE = Dim<D>::TILE;
@@ -52,6 +56,9 @@ __global__ __launch_bounds__(P2GCfg<D>::NW * 64) void k_p2g(Dev d, int side, int
     __shared__ uint32_t s_aff[CPIC ? P2G_J * ROW : 1];
     __shared__ float4 s_tile[Cfg::NW][TILE];
     __shared__ uint32_t s_cs[NPB], s_cn[NPB];
+    constexpr int IMPQ = D == 3 ? 2 : 1;  // impulse quads per node: (lin, 0), (ang, 0) | (lin.xy, ang, 0)
+    __shared__ float4 s_nrm[TWOWAY ? P2G_J * ROW : 1];
+    __shared__ float4 s_imp[TWOWAY ? Cfg::NW : 1][TWOWAY ? IMPQ : 1][TWOWAY ? TILE : 1];
 
     const float *in = d.buf[side];
     const uint32_t npad = d.npad;
@@ -82,6 +89,10 @@ __global__ __launch_bounds__(P2GCfg<D>::NW * 64) void k_p2g(Dev d, int side, int
             s_cn[cell] = cn;
         }
         for (int n = cell; n < TILE; n += 64) s_tile[sz][n] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if constexpr (TWOWAY) {
+            for (int n = cell; n < TILE; n += 64)
+                for (int q = 0; q < IMPQ; q++) s_imp[sz][q][n] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
         uint32_t maxc = cn;
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) maxc = max(maxc, (uint32_t)__shfl_xor((int)maxc, off));
@@ -89,6 +100,7 @@ __global__ __launch_bounds__(P2GCfg<D>::NW * 64) void k_p2g(Dev d, int side, int
 #pragma unroll
         for (int k = 0; k < D; k++) cpos[k] = (float)(bc[k] * BW + lc[k]) * h;
         uint32_t naff[Cfg::NSXY];
+        unsigned long long ncol = 0ull;  // closest collider of the nine nodes: 4 bits each + valid bit at 36 + s
         if constexpr (CPIC) {  // affinities of this thread's nine target nodes (p2g.wgsl:100-103)
 #pragma unroll
             for (int s = 0; s < 9; s++) {
@@ -97,6 +109,10 @@ __global__ __launch_bounds__(P2GCfg<D>::NW * 64) void k_p2g(Dev d, int side, int
                 int ln = (t[0] & (BW - 1)) + ((t[1] & (BW - 1)) << BS) + (D == 3 ? ((t[2] & (BW - 1)) << (2 * BS)) : 0);
                 uint32_t nb = d.nbr_plus[b * 8u + o];
                 naff[s] = nb != NONE ? d.node_cdf[(size_t)nb * NPB + ln].affinities : 0u;
+                if constexpr (TWOWAY) {
+                    const uint32_t cl = nb != NONE ? d.node_cdf[(size_t)nb * NPB + ln].closest_id : NONE;
+                    if (cl < 16u) ncol |= ((unsigned long long)cl << (4 * s)) | (1ull << (36 + s));
+                }
             }
         }
         float acc[Cfg::NSXY][D + 1];
@@ -111,6 +127,7 @@ __global__ __launch_bounds__(P2GCfg<D>::NW * 64) void k_p2g(Dev d, int side, int
         // Staging slot sl -> (cell c = sl / J, rank j = sl % J): a cell's J particles are one contiguous
         // 64-byte run of each quad in HBM; in LDS they go to [j][c] (row padded to ROW).
         float4 pre[KS][NQ];
+        float4 pre_nrm[TWOWAY ? KS : 1];
         uint32_t pre_aff[KS];
         bool pre_ok[KS];
         __syncthreads();  // s_cs / s_cn visible
@@ -138,6 +155,7 @@ __global__ __launch_bounds__(P2GCfg<D>::NW * 64) void k_p2g(Dev d, int side, int
                         if constexpr (CPIC) {
                             const float4 cd = ldq(in, npad, D == 3 ? (int)Pl<D>::CDF1 : (int)Pl<D>::CDF0, src);
                             pre_aff[k] = __float_as_uint(cd.w);
+                            if constexpr (TWOWAY) pre_nrm[k] = D == 3 ? ldq(in, npad, Pl<D>::CDF0, src) : cd;  // cdf normal
                         }
                     }
                 }
@@ -153,15 +171,17 @@ __global__ __launch_bounds__(P2GCfg<D>::NW * 64) void k_p2g(Dev d, int side, int
                     const int dst = (sl % P2G_J) * ROW + sl / P2G_J;
                     if constexpr (D == 3) {
                         float4 c2 = pre[k][3];
-                        const float m = pre[k][0].w;
+                        const float m = TWOWAY ? 1.f : pre[k][0].w;  // (the two-way path needs the raw velocity too)
                         c2.y *= m; c2.z *= m; c2.w *= m;  // momentum m v
                         s_q[0][dst] = pre[k][0]; s_q[1][dst] = pre[k][1]; s_q[2][dst] = pre[k][2]; s_q[3][dst] = c2;
                     } else {
                         float4 vl = pre[k][2];
-                        vl.x *= pre[k][0].z; vl.y *= pre[k][0].z;
+                        const float m = TWOWAY ? 1.f : pre[k][0].z;
+                        vl.x *= m; vl.y *= m;
                         s_q[0][dst] = pre[k][0]; s_q[1][dst] = pre[k][1]; s_q[2][dst] = vl;
                     }
                     if constexpr (CPIC) s_aff[dst] = pre_aff[k];
+                    if constexpr (TWOWAY) s_nrm[dst] = pre_nrm[k];
                 }
             }
             __syncthreads();
@@ -184,6 +204,17 @@ __global__ __launch_bounds__(P2GCfg<D>::NW * 64) void k_p2g(Dev d, int side, int
                 }
                 uint32_t paff = 0u;
                 if constexpr (CPIC) paff = s_aff[sl];
+                float pv[D], pn[D];  // raw particle velocity and cdf normal (two-way coupling)
+                if constexpr (TWOWAY) {
+                    const float4 nq = s_nrm[sl];
+                    pn[0] = nq.x; pn[1] = nq.y;
+                    if constexpr (D == 3) pn[2] = nq.z;
+#pragma unroll
+                    for (int k = 0; k < D; k++) {
+                        pv[k] = mv[k];
+                        mv[k] = mv[k] * mass;
+                    }
+                }
                 // p2g.wgsl:176-198: ref = assoc_node - x ; w = eval_all(-ref / h) ; dpt = ref + shift * h
                 float ref[D], wx[3], wy[3];
 #pragma unroll
@@ -216,7 +247,47 @@ __global__ __launch_bounds__(P2GCfg<D>::NW * 64) void k_p2g(Dev d, int side, int
                         if constexpr (CPIC) {
                             // p2g.wgsl:200-228: incompatible pairs transfer nothing to the grid (their momentum
                             // becomes an impulse on the rigid body: two-way coupling)
-                            if (!affinities_are_compatible(naff[s], paff)) continue;
+                            if (!affinities_are_compatible(naff[s], paff)) {
+                                if constexpr (TWOWAY) {
+                                    if ((ncol >> (36 + s)) & 1ull) {  // p2g.wgsl:203-224
+                                        const ColliderDev &cl = d.colliders[(uint32_t)(ncol >> (4 * s)) & 15u];
+                                        const float wgt = wx[sx] * wyz;
+                                        float dpt[3] = {ref[0] + (float)sx * h, dy, 0.f}, cc[3] = {0.f, 0.f, 0.f};
+                                        if constexpr (D == 3) dpt[2] = ref[2] + (float)sz * h;
+#pragma unroll
+                                        for (int k = 0; k < D; k++) cc[k] = dpt[k] + x[k];  // cell_center
+                                        float bv[D], rel[D], prj[D], dimp[3] = {0.f, 0.f, 0.f}, lever[3] = {0.f, 0.f, 0.f};
+                                        velocity_at_point<D>(cl, cc, bv);
+#pragma unroll
+                                        for (int k = 0; k < D; k++) rel[k] = pv[k] - bv[k];
+                                        project_velocity<D>(rel, pn, prj);
+#pragma unroll
+                                        for (int k = 0; k < D; k++) {
+                                            const float ghost = bv[k] + prj[k];
+                                            dimp[k] = (pv[k] - ghost) * (wgt * mass);
+                                            lever[k] = cl.com[k] - cc[k];
+                                        }
+                                        const int node = tnode0 + sx + TW * sy;
+                                        if constexpr (D == 3) {
+                                            float4 a = s_imp[sz][0][node], bq = s_imp[sz][1][node];
+                                            a.x += dimp[0]; a.y += dimp[1]; a.z += dimp[2];
+                                            bq.x += dimp[1] * lever[2] - dimp[2] * lever[1];
+                                            bq.y += dimp[2] * lever[0] - dimp[0] * lever[2];
+                                            bq.z += dimp[0] * lever[1] - dimp[1] * lever[0];
+                                            s_imp[sz][0][node] = a;
+                                            s_imp[sz][1][node] = bq;
+                                        } else {
+                                            float4 a = s_imp[sz][0][node];
+                                            a.x += dimp[0]; a.y += dimp[1];
+                                            a.z += dimp[0] * lever[1] + dimp[1] * (-lever[0]);
+                                            s_imp[sz][0][node] = a;
+                                        }
+                                        // lanes own distinct nodes within one (sx, sy) phase; keep the phases in order
+                                        asm volatile("" ::: "memory");
+                                    }
+                                }
+                                continue;
+                            }
                         }
                         const float dx = ref[0] + (float)sx * h;
                         const float w = wx[sx] * wyz;
@@ -252,6 +323,18 @@ __global__ __launch_bounds__(P2GCfg<D>::NW * 64) void k_p2g(Dev d, int side, int
                 sum.x += p.x; sum.y += p.y; sum.z += p.z; sum.w += p.w;
             }
             d.slab[(size_t)b * TILE + n] = sum;
+            if constexpr (TWOWAY) {
+#pragma unroll
+                for (int q = 0; q < IMPQ; q++) {
+                    float4 is = s_imp[0][q][n];
+#pragma unroll
+                    for (int w = 1; w < Cfg::NW; w++) {
+                        const float4 p = s_imp[w][q][n];
+                        is.x += p.x; is.y += p.y; is.z += p.z;
+                    }
+                    d.imp_slab[((size_t)b * TILE + n) * IMPQ + q] = is;
+                }
+            }
         }
     }
 }
@@ -260,7 +343,7 @@ __global__ __launch_bounds__(P2GCfg<D>::NW * 64) void k_p2g(Dev d, int side, int
 // Gather of the slabs covering each node + solver/grid_update.wgsl:55-64.
 // PHASE 0: gather + update in one pass (single GPU). Sharded runs split it around the halo exchange:
 // PHASE 1 = gather only (partial momentum/mass sums into nodes[]), PHASE 2 = update from nodes[].
-template <int D, int PHASE> __global__ __launch_bounds__(256) void k_grid_update(Dev d) {
+template <int D, int PHASE, bool TWOWAY = false> __global__ __launch_bounds__(256) void k_grid_update(Dev d) {
     constexpr int BW = Dim<D>::BW, BS = Dim<D>::BSHIFT, TW = Dim<D>::TW, TILE = Dim<D>::TILE, NN = Dim<D>::NNBR;
     const uint32_t B = min(d.counters[CTR_NBLOCKS], d.cap);
     const uint32_t total = B * NPB;
@@ -275,6 +358,7 @@ template <int D, int PHASE> __global__ __launch_bounds__(256) void k_grid_update
         l[1] = (ln >> BS) & (BW - 1);
         l[2] = D == 3 ? (ln >> (2 * BS)) : 0;
         float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
+        float isum[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};  // node impulse (two-way coupling): linear, angular
         uint32_t srcs[NN];
         int tis[NN];
 #pragma unroll
@@ -291,6 +375,30 @@ template <int D, int PHASE> __global__ __launch_bounds__(256) void k_grid_update
             if constexpr (PHASE != 2) {
                 float4 p = d.slab[(size_t)src * TILE + ti];
                 sum.x += p.x; sum.y += p.y; sum.z += p.z; sum.w += p.w;
+                if constexpr (TWOWAY) {
+                    if (d.block_cpic[src] != 0u) {  // only the CPIC launch of P2G writes impulse partials
+                        constexpr int IMPQ = D == 3 ? 2 : 1;
+                        const float4 a = d.imp_slab[((size_t)src * TILE + ti) * IMPQ];
+                        isum[0] += a.x; isum[1] += a.y; isum[2] += a.z;
+                        if constexpr (D == 3) {
+                            const float4 bq = d.imp_slab[((size_t)src * TILE + ti) * IMPQ + 1];
+                            isum[3] += bq.x; isum[4] += bq.y; isum[5] += bq.z;
+                        }
+                    }
+                }
+            }
+        }
+        if constexpr (TWOWAY) {
+            // p2g.wgsl:142-155: the node's total impulse goes to its closest body, in fixed point (integer
+            // atomics: order-independent, like the reference)
+            const uint32_t cl = d.node_cdf[node].closest_id;
+            if (cl < 16u) {
+                constexpr int NI = D == 3 ? 6 : 3;
+#pragma unroll
+                for (int k = 0; k < NI; k++) {
+                    const int32_t v = flt2int(isum[k]);
+                    if (v != 0) atomicAdd(&d.impulses[cl * 8u + k], v);
+                }
             }
         }
         if constexpr (PHASE == 1) {

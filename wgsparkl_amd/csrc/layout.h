@@ -81,6 +81,13 @@ struct ColliderDev {    // wgs_collider, device copy
     float com[3];
 };
 
+struct BodyDev {        // mass properties of the body behind a collider (rigid_impulses.wgsl:81-84)
+    float inv_mass[3];
+    float inv_inertia_local[9];   // 3D: column-major, body frame; 2D: [0]
+    float local_com[3];
+    float inv_inertia_world[9];   // refreshed from the pose every substep
+};
+
 struct NodeCdf {        // grid.wgsl:233-240
     float distance;
     uint32_t affinities;
@@ -134,8 +141,11 @@ struct Dev {
     uint32_t *cpic_list;      // cap: particle-bearing blocks with block_cpic set, [0, counters[CTR_NCPIC])
     uint32_t *counters;    // CTR_COUNT
     const SimParamsDev *sp;
-    const ColliderDev *colliders;
+    ColliderDev *colliders;  // poses / velocities are integrated on the device (kernels_bodies.h)
     uint32_t n_colliders;
+    BodyDev *bodies;         // 16: mass properties
+    int32_t *impulses;       // 16 * 8: fixed-point (x 1e5) linear[D] + angular impulses accumulated by P2G
+    float4 *imp_slab;        // cap*TILE*IMPQ per-block partial node impulses (two-way coupling only), or null
     float h;             // cell width
     float inv_h;
     uint32_t h_pow2;     // cell width is a power of two: x * inv_h == x / h bit for bit

@@ -136,6 +136,10 @@ def _unpack_particles(T, raw: np.ndarray, D: int, plastic: Optional[np.ndarray])
         phase=sl("phase", 2), has_plasticity=u[:, off("has_plasticity")] != 0, has_phase=u[:, off("has_phase")] != 0)
 
 
+def _is_dynamic(c: Collider) -> bool:
+    return any(float(v) != 0.0 for v in list(c.inv_mass) + list(c.inv_inertia_local))
+
+
 def _fill_collider(T, dst, c: Collider, D: int):
     dst.shape_type = int(c.shape_type)
     sh = list(c.shape) + [0.0] * (4 - len(c.shape))
@@ -182,6 +186,8 @@ class MpmData:
         self.n_colliders = len(colliders)
         if model != MODEL_COROTATED:
             self.set_constitutive_model(model)
+        if any(_is_dynamic(c) for c in colliders):
+            self.set_body_mass_properties(colliders)
 
     @classmethod
     def new(cls, pipeline, params, particles, colliders, cell_width, grid_capacity, model=MODEL_COROTATED):
@@ -216,6 +222,35 @@ class MpmData:
                 coms[3 * i + k] = tmp[i].com[k]
         _ffi.check(self.lib, self.lib.wgs_set_collider_poses(self._h, poses, coms, n))
         _ffi.check(self.lib, self.lib.wgs_set_body_velocities(self._h, vels, n))
+        self.set_body_mass_properties(colliders)
+
+    def set_body_mass_properties(self, colliders: Sequence[Collider]):
+        """GpuBodySet::from_rapier's local mass properties: all zero = kinematic, else two-way coupling."""
+        n = len(colliders)
+        mp = (self.T.MassProperties * max(1, n))()
+        for i, c in enumerate(colliders):
+            im = (list(c.inv_mass) + [0.0] * 3)[:3]
+            ii = (list(c.inv_inertia_local) + [0.0] * 9)[:9]
+            mp[i].inv_mass = (C.c_float * 3)(*im)
+            mp[i].inv_inertia_local = (C.c_float * 9)(*ii)
+        _ffi.check(self.lib, self.lib.wgs_set_body_mass_properties(self._h, mp, n))
+
+    def read_body_poses(self):
+        """poses_staging read-back (src_testbed/step.rs:129-132): one dict per collider with rotation
+        (3D quaternion (i,j,k,w); 2D (cos, sin)), translation, linvel, angvel, com as float64 arrays."""
+        n, D = self.n_colliders, self.dim
+        poses = (self.T.Pose * max(1, n))()
+        vels = (self.T.Velocity * max(1, n))()
+        coms = (C.c_float * (3 * max(1, n)))()
+        _ffi.check(self.lib, self.lib.wgs_read_body_poses(self._h, poses, vels, coms, n))
+        out = []
+        for i in range(n):
+            out.append(dict(rotation=np.array(list(poses[i].rotation)[:(2 if D == 2 else 4)], np.float64),
+                            translation=np.array(list(poses[i].translation)[:D], np.float64),
+                            linvel=np.array(list(vels[i].linear)[:D], np.float64),
+                            angvel=np.array(list(vels[i].angular)[:(1 if D == 2 else 3)], np.float64),
+                            com=np.array([coms[3 * i + k] for k in range(D)], np.float64)))
+        return out
 
     # -- device -> host
     def sync(self):

@@ -175,6 +175,38 @@ class Collider:
     linvel: Sequence[float] = (0.0, 0.0, 0.0)
     angvel: Sequence[float] = (0.0, 0.0, 0.0)         # 2D: (w,)
     com: Optional[Sequence[float]] = None             # world-space; defaults to translation
+    # Mass properties of the parent body (wgrapier local_mprops, rigid_impulses.wgsl:81-84). All zero =
+    # kinematic / fixed: the body follows its velocity only. Non-zero = dynamic: two-way coupling.
+    inv_mass: Sequence[float] = (0.0, 0.0, 0.0)
+    inv_inertia_local: Sequence[float] = (0.0,) * 9   # 3D: column-major, body frame; 2D: (1/I,)
+
+    def with_density(self, density: float, dim: int) -> "Collider":
+        """Dynamic body of uniform density (rapier's MassProperties::from_ball / from_cuboid / from_capsule
+        formulas): fills inv_mass and inv_inertia_local; the centre of mass is the shape origin."""
+        import math
+        s = [float(x) * self.scale for x in self.shape]
+        if self.shape_type == SHAPE_BALL:
+            r = s[0]
+            if dim == 2:
+                m = density * math.pi * r * r
+                inertia = [m * r * r / 2.0]
+            else:
+                m = density * 4.0 / 3.0 * math.pi * r ** 3
+                inertia = [2.0 / 5.0 * m * r * r] * 3
+        elif self.shape_type == SHAPE_CUBOID:
+            if dim == 2:
+                m = density * 4.0 * s[0] * s[1]
+                inertia = [m * (s[0] ** 2 + s[1] ** 2) / 3.0]
+            else:
+                m = density * 8.0 * s[0] * s[1] * s[2]
+                inertia = [m * (s[1] ** 2 + s[2] ** 2) / 3.0, m * (s[0] ** 2 + s[2] ** 2) / 3.0,
+                           m * (s[0] ** 2 + s[1] ** 2) / 3.0]
+        else:
+            raise NotImplementedError("with_density: ball and cuboid only")
+        inv = [1.0 / x for x in inertia]
+        ii = [inv[0]] + [0.0] * 8 if dim == 2 else [inv[0], 0, 0, 0, inv[1], 0, 0, 0, inv[2]]
+        import dataclasses
+        return dataclasses.replace(self, inv_mass=(1.0 / m,) * 3, inv_inertia_local=tuple(ii))
 
     @staticmethod
     def cuboid(half_extents, translation, **kw) -> "Collider":
