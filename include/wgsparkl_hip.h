@@ -215,6 +215,31 @@ wgs_status wgs_read_body_poses(wgs_data *data, wgs_pose *poses, wgs_velocity *ve
 wgs_status wgs_read_positions(wgs_data *data, float *out);
 /* Full particle state in the caller's original order (tests / checkpoint). Blocking. */
 wgs_status wgs_read_particles(wgs_data *data, wgs_particle *out, wgs_plastic_state *plastic_out /* may be NULL */);
+/* Render hand-off: src_testbed/prep_vertex_buffer{2,3}d.wgsl `main`, the compute pass the testbed
+ * queues after the substeps (src_testbed/step.rs:144-163). One InstanceData per particle in the caller's order
+ * (src_testbed/instancing3d.rs:66-74): base_color is an INPUT (set once at startup by the testbed), the rest is
+ * written. Modes = RenderMode (src_testbed/prep_vertex_buffer.rs:11-18). */
+enum {
+    WGS_RENDER_DEFAULT = 0, WGS_RENDER_VOLUME = 1, WGS_RENDER_VELOCITY = 2, WGS_RENDER_CDF_NORMALS = 3,
+    WGS_RENDER_CDF_DISTANCES = 4, WGS_RENDER_CDF_SIGNS = 5
+};
+typedef struct {
+    float deformation[3][4]; /* mat3x3 columns, padded to vec4 (2D: F in the xy block, identity elsewhere) */
+    float position[4];       /* xyz, 0 (2D: z = 0) */
+    float base_color[4];
+    float color[4];
+} wgs_instance;
+/* host buffer of n records: staged to the device, filled, copied back. Blocking. */
+wgs_status wgs_prep_vertex_buffer(wgs_data *data, uint32_t mode, wgs_instance *instances);
+/* interop form: `device_instances` is a DEVICE pointer to n records that stay resident (the testbed's vertex
+ * buffer); stream-ordered, returns immediately. */
+wgs_status wgs_prep_vertex_buffer_device(wgs_data *data, uint32_t mode, wgs_instance *device_instances);
+
+/* Checkpoint restore (the reference has no checkpointing, MpmData::new always starts from
+ * DruckerPragerPlasticState::default, src/models/drucker_prager.rs:36-53): wgs_read_particles +
+ * wgs_read_body_poses -> wgs_data_create (+ wgs_set_body_mass_properties) -> wgs_set_plastic_state continues a
+ * run bit-exactly. `states`: one record per particle in the caller's order. Blocking; single-domain data. */
+wgs_status wgs_set_plastic_state(wgs_data *data, const wgs_plastic_state *states);
 /* Sparse grid of the last substep: nodes of every active block. *count receives the number written. */
 wgs_status wgs_read_grid(wgs_data *data, wgs_node_record *out, size_t capacity, size_t *count);
 /* Active block headers + the sorted particle ids (GpuParticles.sorted_ids, src/solver/particle3d.rs:178-180)

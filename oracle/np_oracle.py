@@ -195,3 +195,45 @@ class NpState:
         vel[ok] = g["vel"][flat]
         mass[ok] = g["mass"][flat]
         return vel, mass
+
+
+# ---------------------------------------------------------------------------------------------
+# Render hand-off: src_testbed/prep_vertex_buffer{2,3}d.wgsl `main`, restated on arrays (tests only)
+# ---------------------------------------------------------------------------------------------
+RENDER_DEFAULT, RENDER_VOLUME, RENDER_VELOCITY, RENDER_CDF_NORMALS, RENDER_CDF_DISTANCES, RENDER_CDF_SIGNS = range(6)
+
+
+def prep_instances(pos, vel, def_grad, cdf_normal, cdf_dist, cdf_affinity, mode, cell_width, dt, base_color):
+    """-> [n, 24] float64: deformation (3 padded columns), position (vec4), base_color, color.
+    prep_vertex_buffer3d.wgsl:45-95 / prep_vertex_buffer2d.wgsl:40-90. Singular values in descending order."""
+    n, d = pos.shape
+    out = np.zeros((n, 24))
+    m = np.tile(np.eye(3), (n, 1, 1))                       # [n, row, col]
+    m[:, :d, :d] = _mat(np.asarray(def_grad, np.float64), d)
+    for c in range(3):
+        out[:, 4 * c:4 * c + 3] = m[:, :, c]
+    out[:, 12:12 + d] = pos
+    out[:, 16:20] = base_color
+    col = np.array(base_color, np.float64).copy().reshape(n, 4)
+    if mode == RENDER_VELOCITY:
+        col[:, :d] = np.abs(vel) * dt * 100.0 + 0.2
+    elif mode == RENDER_VOLUME:
+        S = np.linalg.svd(_mat(np.asarray(def_grad, np.float64), d), compute_uv=False)   # descending
+        col[:, :d] = (1.0 - S) / 0.005 + 0.2
+    elif mode == RENDER_CDF_NORMALS:
+        zero = np.all(cdf_normal == 0.0, axis=1)
+        col[:, :3] = 0.0
+        col[~zero, :d] = (cdf_normal[~zero] + 1.0) / 2.0
+    elif mode == RENDER_CDF_DISTANCES:
+        dd = cdf_dist / (cell_width * 1.5)
+        col[:, 0] = np.where(dd > 0, 0.0, np.abs(dd))
+        col[:, 1] = np.where(dd > 0, np.abs(dd), 0.0)
+        col[:, 2] = 0.0
+    elif mode == RENDER_CDF_SIGNS:
+        aff = np.asarray(cdf_affinity, np.uint32)
+        a = (aff >> 16) & (aff & 0xFFFF)
+        col[:, 0] = ((aff != 0) & (a != 0)).astype(np.float64)
+        col[:, 1] = ((aff != 0) & (a == 0)).astype(np.float64)
+        col[:, 2] = 0.0
+    out[:, 20:24] = col
+    return out

@@ -87,6 +87,15 @@ pub struct wgs_mass_properties {
 }
 #[repr(C)]
 #[derive(Copy, Clone)]
+pub struct wgs_instance {
+    // = src_testbed/instancing3d.rs InstanceData
+    pub deformation: [[f32; 4]; 3],
+    pub position: [f32; 4],
+    pub base_color: [f32; 4],
+    pub color: [f32; 4],
+}
+#[repr(C)]
+#[derive(Copy, Clone)]
 pub struct wgs_node_record {
     pub cell: [i32; DIM],
     pub velocity: [f32; DIM],
@@ -135,6 +144,9 @@ extern "C" {
     ) -> wgs_status;
     pub fn wgs_read_positions(d: *mut wgs_data, out: *mut f32) -> wgs_status;
     pub fn wgs_read_particles(d: *mut wgs_data, out: *mut wgs_particle, plastic: *mut wgs_plastic_state) -> wgs_status;
+    pub fn wgs_prep_vertex_buffer(d: *mut wgs_data, mode: u32, instances: *mut wgs_instance) -> wgs_status;
+    pub fn wgs_prep_vertex_buffer_device(d: *mut wgs_data, mode: u32, device_instances: *mut wgs_instance) -> wgs_status;
+    pub fn wgs_set_plastic_state(d: *mut wgs_data, states: *const wgs_plastic_state) -> wgs_status;
     pub fn wgs_read_grid(d: *mut wgs_data, out: *mut wgs_node_record, capacity: usize, count: *mut usize) -> wgs_status;
     pub fn wgs_read_blocks(
         d: *mut wgs_data, out: *mut wgs_block_record, capacity: usize, count: *mut usize, sorted_ids: *mut u32,

@@ -191,6 +191,63 @@ def test_body_setters_and_readback(hip_libs, oracle_libs):
     assert rel_rms(gp.pos[same], st.arr["pos"][same]) < 1e-5
 
 
+@pytest.mark.parametrize("name", ["tilted_box2d", "floor3d"])
+def test_prep_vertex_buffer_modes(hip_libs, name):
+    """Render hand-off: every RenderMode of src_testbed/prep_vertex_buffer{2,3}d.wgsl against its numpy
+    restatement evaluated on the particle state read back from the same run."""
+    from oracle import np_oracle
+    make, k = _CASES[name]
+    sc = make()
+    data = run_gpu(sc, k)
+    ps = data.read_particles()
+    rng = np.random.default_rng(3)
+    base = rng.uniform(0.0, 1.0, size=(ps.n, 4)).astype(np.float32)
+    assert (ps.cdf_affinity != 0).any()
+    for mode in range(6):
+        got = data.prep_vertex_buffer(mode, base)
+        ref = np_oracle.prep_instances(ps.pos, ps.vel, ps.def_grad, ps.cdf_normal, ps.cdf_dist, ps.cdf_affinity, mode,
+                                       sc["cell_width"], sc["params"].dt, base)
+        assert np.array_equal(got[:, :20], ref[:, :20].astype(np.float32)), mode       # F, position, base colour: copies
+        tol = 2e-3 if mode == np_oracle.RENDER_VOLUME else 1e-6                         # (1 - S) / 0.005 amplifies 200 x
+        assert np.allclose(got[:, 20:], ref[:, 20:], rtol=0.0, atol=tol), mode
+    with pytest.raises(Exception):
+        data.prep_vertex_buffer(17, base)
+
+
+def test_checkpoint_restart_is_bit_exact(hip_libs):
+    """read_particles (+ plastic state, + body poses) -> MpmData.new -> set_plastic_state continues the
+    run bit-for-bit (every reduction is in canonical particle order, whatever the storage order)."""
+    import dataclasses
+    from helpers import pipeline
+    from wgsparkl_amd import MpmData
+    ps = scenes.random_cloud(3000, dim=3, seed=5, extent=10.0, young=1e6, plasticity=DruckerPrager.new(1e6, 0.25), phase=None)
+    ps.pos[:, 1] += 3.0
+    cols = [Collider.cuboid((50.0, 1.0, 50.0), (8.0, 1.0, 8.0)),
+            Collider.ball(1.5, (8.0, 12.0, 8.0), linvel=(0.0, -1.0, 0.0), angvel=(0.0, 0.0, 0.5))]
+    params = SimulationParams((0.0, -9.81, 0.0), 5e-4)
+    pipe = pipeline(3)
+    args = (1.0, 4096, MODEL_COROTATED)
+    full = MpmData.new(pipe, params, ps, cols, *args)
+    pipe.step(full, 24)
+    part = MpmData.new(pipe, params, ps, cols, *args)
+    pipe.step(part, 12)
+    snap, bodies = part.read_particles(), part.read_body_poses()
+    assert (snap.dp_state != np.array([1.0, 1.0, 0.0], np.float32)).any(), "scene should have yielded by now"
+    cols2 = [dataclasses.replace(c, translation=tuple(b["translation"]), rotation=tuple(b["rotation"]),
+                                 linvel=tuple(b["linvel"]), angvel=tuple(b["angvel"]), com=tuple(b["com"]))
+             for c, b in zip(cols, bodies)]
+    rest = MpmData.new(pipe, params, snap, cols2, *args)
+    rest.set_plastic_state(snap.dp_state)
+    pipe.step(rest, 12)
+    a, b = full.read_particles(), rest.read_particles()
+    for f in ("pos", "vel", "def_grad", "affine", "dp_state", "phase", "cdf_affinity", "cdf_normal", "cdf_dist"):
+        assert np.array_equal(getattr(a, f), getattr(b, f)), f
+    pa, pb = full.read_body_poses(), rest.read_body_poses()
+    for x, y in zip(pa, pb):
+        for key in x:
+            assert np.array_equal(x[key], y[key]), key
+
+
 def test_dynamic_bodies_refused_on_sharded_data(hip_libs):
     """Two-way coupling needs the impulses of every rank: reported as unsupported, not silently wrong."""
     from wgsparkl_amd import sharded

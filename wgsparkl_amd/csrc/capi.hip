@@ -220,6 +220,80 @@ __global__ void k_export_particles(Dev d, int side, ParticleOffsets o, bool plas
     }
 }
 
+// checkpoint restore: Drucker-Prager plastic state by persistent particle id (models/drucker_prager.wgsl:18-23)
+__global__ void k_import_plastic_state(Dev d, int side, const float *states) {
+    using P = Pl<D>;
+    float *buf = d.buf[side];
+    const uint32_t npad = d.npad;
+    for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < num_slots(d); j += gridDim.x * blockDim.x) {
+        const uint32_t pid = ldpid<D>(buf, npad, j);
+        if (pid == 0xffffffffu) continue;  // vacated slot of a sharded run
+        const float *st = states + (size_t)pid * 3;
+        float4 q1 = ldq(buf, npad, P::DP1, j), q2 = ldq(buf, npad, P::DP2, j);
+        q1.z = st[0];
+        q1.w = st[1];
+        q2.x = st[2];
+        stq(buf, npad, P::DP1, j, q1);
+        stq(buf, npad, P::DP2, j, q2);
+    }
+}
+
+// Render hand-off: src_testbed/prep_vertex_buffer{2,3}d.wgsl `main`. Instance i = particle i of the
+// caller's order; base_color is read from the instance record, everything else is written.
+__global__ void k_prep_instances(Dev d, int side, uint32_t mode, bool cpic, uint32_t cdf_epoch, float *inst) {
+    const float *in = d.buf[side];
+    const uint32_t npad = d.npad;
+    const float h = d.h, dt = d.sp->dt;
+    for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < d.n; j += gridDim.x * blockDim.x) {
+        const uint32_t pid = ldpid<D>(in, npad, j);
+        Unpacked u;
+        unpack_slot<D>(in, npad, j, false, cpic, cdf_epoch, u);
+        float *r = inst + (size_t)pid * 24;
+        // deformation: mat3x3 as three padded columns (instancing3d.rs:66-74); 2D embeds F in the xy block
+        float m[9] = {1.f, 0.f, 0.f, 0.f, 1.f, 0.f, 0.f, 0.f, 1.f};
+        for (int col = 0; col < D; col++)
+            for (int row = 0; row < D; row++) m[col * 3 + row] = u.F[col * D + row];
+        for (int col = 0; col < 3; col++) {
+            for (int row = 0; row < 3; row++) r[col * 4 + row] = m[col * 3 + row];
+            r[col * 4 + 3] = 0.f;
+        }
+        r[12] = u.x[0]; r[13] = u.x[1]; r[14] = D == 3 ? u.x[D - 1] : 0.f; r[15] = 0.f;
+        const float base[4] = {r[16], r[17], r[18], r[19]};
+        float col[4] = {base[0], base[1], base[2], base[3]};
+        if (mode == WGS_RENDER_VELOCITY) {
+            for (int k = 0; k < D; k++) col[k] = fabsf(u.v[k]) * dt * 100.0f + 0.2f;
+        } else if (mode == WGS_RENDER_VOLUME) {
+            Svd<D> sv;
+            svd<D>(u.F, sv);
+            float s[3] = {sv.s[0], sv.s[1], D == 3 ? sv.s[D - 1] : 0.f};
+            // descending order, like the reference's SVD (wgebra Svd2/Svd3, third party)
+            if (s[0] < s[1]) { float t = s[0]; s[0] = s[1]; s[1] = t; }
+            if (D == 3) {
+                if (s[1] < s[2]) { float t = s[1]; s[1] = s[2]; s[2] = t; }
+                if (s[0] < s[1]) { float t = s[0]; s[0] = s[1]; s[1] = t; }
+            }
+            for (int k = 0; k < D; k++) col[k] = (1.0f - s[k]) / 0.005f + 0.2f;
+        } else if (mode == WGS_RENDER_CDF_NORMALS) {
+            bool zero = true;
+            for (int k = 0; k < D; k++) zero = zero && u.nrm[k] == 0.f;
+            col[0] = col[1] = col[2] = 0.f;
+            if (!zero)
+                for (int k = 0; k < D; k++) col[k] = (u.nrm[k] + 1.0f) / 2.0f;
+        } else if (mode == WGS_RENDER_CDF_DISTANCES) {
+            const float dd = u.dist / (h * 1.5f);
+            col[0] = dd > 0.f ? 0.f : fabsf(dd);
+            col[1] = dd > 0.f ? fabsf(dd) : 0.f;
+            col[2] = 0.f;
+        } else if (mode == WGS_RENDER_CDF_SIGNS) {
+            const uint32_t a = (u.aff >> 16) & (u.aff & 0xffffu);
+            col[0] = (u.aff != 0u && a != 0u) ? 1.f : 0.f;
+            col[1] = (u.aff != 0u && a == 0u) ? 1.f : 0.f;
+            col[2] = 0.f;
+        }
+        r[20] = col[0]; r[21] = col[1]; r[22] = col[2]; r[23] = col[3];
+    }
+}
+
 __global__ void k_export_positions(Dev d, int side, float *out) {
     const float *in = d.buf[side];
     for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < d.n; j += gridDim.x * blockDim.x) {
@@ -944,6 +1018,55 @@ wgs_status wgs_read_particles(wgs_data *d, wgs_particle *out, wgs_plastic_state 
     if (e == hipSuccess) e = hipStreamSynchronize(d->stream);
     hipFree(tmp);
     if (ptmp) hipFree(ptmp);
+    if (e != hipSuccess) return fail(WGS_ERR_HIP, hipGetErrorString(e));
+    return WGS_OK;
+}
+
+wgs_status wgs_prep_vertex_buffer_device(wgs_data *d, uint32_t mode, wgs_instance *device_instances) {
+    if (!d || !device_instances) return fail(WGS_ERR_INVALID_ARGUMENT, "NULL argument");
+    if (mode > WGS_RENDER_CDF_SIGNS) return fail(WGS_ERR_INVALID_ARGUMENT, "unknown render mode");
+    HIP_TRY(hipSetDevice(d->pipeline->device));
+    const bool cdf_live = d->cpic || d->substeps == 0;
+    if (d->dev.n)
+        hipLaunchKernelGGL(k_prep_instances, dim3(grid_for(d, 4)), dim3(256), 0, d->stream, d->dev, d->side, mode, cdf_live,
+                           (uint32_t)d->substeps, reinterpret_cast<float *>(device_instances));
+    HIP_TRY(hipGetLastError());
+    return WGS_OK;
+}
+
+wgs_status wgs_prep_vertex_buffer(wgs_data *d, uint32_t mode, wgs_instance *instances) {
+    if (!d || !instances) return fail(WGS_ERR_INVALID_ARGUMENT, "NULL argument");
+    HIP_TRY(hipSetDevice(d->pipeline->device));
+    const size_t bytes = sizeof(wgs_instance) * (size_t)d->dev.n;
+    if (bytes == 0) return WGS_OK;
+    wgs_instance *tmp = nullptr;
+    HIP_TRY(hipMalloc((void **)&tmp, bytes));
+    hipError_t e = hipMemcpyAsync(tmp, instances, bytes, hipMemcpyHostToDevice, d->stream);  // base colours
+    wgs_status st = e == hipSuccess ? wgs_prep_vertex_buffer_device(d, mode, tmp) : WGS_ERR_HIP;
+    if (st == WGS_OK) {
+        e = hipMemcpyAsync(instances, tmp, bytes, hipMemcpyDeviceToHost, d->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(d->stream);
+    }
+    hipFree(tmp);
+    if (st != WGS_OK && e == hipSuccess) return st;
+    if (e != hipSuccess) return fail(WGS_ERR_HIP, hipGetErrorString(e));
+    return WGS_OK;
+}
+
+wgs_status wgs_set_plastic_state(wgs_data *d, const wgs_plastic_state *states) {
+    if (!d || !states) return fail(WGS_ERR_INVALID_ARGUMENT, "NULL argument");
+    if (d->dev.sharded) return fail(WGS_ERR_UNSUPPORTED, "plastic-state restore addresses particles by local index: single-domain data only");
+    HIP_TRY(hipSetDevice(d->pipeline->device));
+    const size_t n = d->dev.n;
+    if (n == 0 || !d->plastic) return WGS_OK;  // no particle carries plasticity: nothing reads the state
+    float *tmp = nullptr;
+    HIP_TRY(hipMalloc((void **)&tmp, sizeof(float) * 3 * n));
+    hipError_t e = hipMemcpyAsync(tmp, states, sizeof(float) * 3 * n, hipMemcpyHostToDevice, d->stream);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(k_import_plastic_state, dim3(grid_for(d, 4)), dim3(256), 0, d->stream, d->dev, d->side, tmp);
+        e = hipStreamSynchronize(d->stream);
+    }
+    hipFree(tmp);
     if (e != hipSuccess) return fail(WGS_ERR_HIP, hipGetErrorString(e));
     return WGS_OK;
 }

@@ -270,6 +270,21 @@ class MpmData:
             self._h, raw.ctypes.data_as(C.POINTER(T.Particle)), plastic.ctypes.data_as(C.POINTER(T.PlasticState))))
         return _unpack_particles(T, raw, self.dim, plastic)
 
+    def prep_vertex_buffer(self, mode: int = 0, base_color=None) -> np.ndarray:
+        """src_testbed/prep_vertex_buffer{2,3}d.wgsl: n x 24 floats (deformation 3 x vec4, position vec4, base_color,
+        color), particle i of the caller's order in row i. `base_color`: n x 4 (default opaque white)."""
+        inst = np.zeros((self.n, 24), F32)
+        inst[:, 16:20] = 1.0 if base_color is None else np.asarray(base_color, F32).reshape(self.n, 4)
+        _ffi.check(self.lib, self.lib.wgs_prep_vertex_buffer(self._h, int(mode), inst.ctypes.data_as(C.c_void_p)))
+        return inst
+
+    def set_plastic_state(self, dp_state: np.ndarray):
+        """Checkpoint restore of the Drucker-Prager plastic state (n x 3: plastic det, hardening, log_vol_gain)
+        in the caller's particle order; together with `MpmData.new(read_particles())` it continues a run
+        bit-exactly."""
+        st = np.ascontiguousarray(dp_state, F32).reshape(self.n, 3)
+        _ffi.check(self.lib, self.lib.wgs_set_plastic_state(self._h, st.ctypes.data_as(C.POINTER(self.T.PlasticState))))
+
     def read_grid(self):
         """(cells[int32 M x D], vel_mass[M x (D+1)], cdf_dist, cdf_aff, cdf_closest), lexicographically
         sorted by cell coordinate (physical node ids are not comparable between runs)."""
