@@ -94,7 +94,9 @@ typedef struct {
  * pair (src/pipeline.rs:107-117 -> wgrapier GpuBodySet: shape, pose, velocity,
  * world mass properties). Only analytic shapes are handled, like collide()
  * (src/collision/collide.wgsl:36-38 skips polylines and trimeshes). */
-enum { WGS_SHAPE_BALL = 0, WGS_SHAPE_CUBOID = 1, WGS_SHAPE_CAPSULE = 2 };
+enum { WGS_SHAPE_BALL = 0, WGS_SHAPE_CUBOID = 1, WGS_SHAPE_CAPSULE = 2,
+       WGS_SHAPE_MESH = 3 /* trimesh / heightfield / polyline: no analytic projection, coupled through the rigid
+                             particles of wgs_set_rigid_particles */ };
 typedef struct {
     float rotation[4];     /* 3D: unit quaternion (i, j, k, w); 2D: (cos, sin, 0, 0) */
     float translation[3];
@@ -205,6 +207,16 @@ wgs_status wgs_set_body_velocities(wgs_data *data, const wgs_velocity *vels, siz
 /* GpuBodySet::from_rapier's local mass properties (src/pipeline.rs:145, wgrapier): which bodies are dynamic.
  * Stream-ordered like the other setters. Not available on sharded data (WGS_ERR_UNSUPPORTED). */
 wgs_status wgs_set_body_mass_properties(wgs_data *data, const wgs_mass_properties *mprops, size_t n);
+/* Rigid particles of the mesh colliders = the buffers GpuRigidParticles::from_rapier builds on the host
+ * (src/solver/particle3d.rs:100-150, 2D src/solver/particle2d.rs:75-125; sampling step = cell width,
+ * src/pipeline.rs:144) plus the mesh vertex buffers of wgrapier's GpuBodySet: sample points and mesh vertices in
+ * the collider's LOCAL frame, per sample the vertex ids of the triangle (2D: segment, vertex[2] unused) it was
+ * taken from and its collider. Every substep then runs `update rigid particles`, the rigid-particle block marks
+ * and `p2g_cdf` (src/solver/rigid_particle_update.wgsl, src/grid/sort.wgsl:38-86, src/solver/p2g_cdf.wgsl).
+ * Copies its inputs; n == 0 removes them. Blocking; single-domain data. */
+typedef struct { uint32_t vertex[3]; uint32_t collider; } wgs_sample_ids;   /* GpuSampleIds */
+wgs_status wgs_set_rigid_particles(wgs_data *data, const float *local_points /* n*DIM */, const wgs_sample_ids *ids, size_t n,
+                                   const float *local_vertices /* nv*DIM */, const uint32_t *vertex_collider_ids, size_t nv);
 /* poses_staging read-back after the step (src_testbed/step.rs:129-132,175-198): the poses the device
  * integrated (every substep ends with src/solver/rigid_impulses.wgsl:95-136). Blocking. `vels` and `coms`
  * (n*3 floats, world space) may be NULL. */

@@ -504,7 +504,7 @@ static void mark_block_as_active(orc_grid *g, const int32_t *block) {
 /* ------------------------------------------------------------------------ */
 /* Sort — grid/grid.rs:30-207, grid/sort.wgsl:26-36,89-137, grid.wgsl:186-203,362-379 */
 /* ------------------------------------------------------------------------ */
-void orc_sort(const orc_particles *p, const orc_params *prm, orc_grid *g) {
+static void sort_impl(const orc_particles *p, const orc_params *prm, orc_grid *g, orc_rigid *rig) {
     const float h = (float)prm->cell_width;
     /* reset_hmap */
     for (int32_t i = 0; i < g->hmap_capacity; i++) { g->hmap_state[i] = ORC_NONE; g->hmap_value[i] = 0; }
@@ -532,6 +532,41 @@ void orc_sort(const orc_particles *p, const orc_params *prm, orc_grid *g) {
                     mark_block_as_active(g, nb);
                 }
 #endif
+    }
+    if (rig) {
+        /* mark_rigid_particles_needing_block (sort.wgsl:55-86): the sample's own block is missing but one of
+         * its "+1" neighbours exists. All marks are taken before any block is added (two dispatches). */
+        for (int32_t i = 0; i < rig->n; i++) {
+            float pf[3] = {0, 0, 0};
+            int32_t b[3];
+            uint32_t l[3];
+            for (int k = 0; k < D; k++) pf[k] = (float)rig->world_pts[i * D + k];
+            orc_block_and_local(pf, h, b, l);
+            int first = 0, count = 0;
+#if D == 2
+            const int assoc[4][3] = {{0, 0, 0}, {0, 1, 0}, {1, 0, 0}, {1, 1, 0}};
+            const int nassoc = 4;
+#else
+            const int assoc[8][3] = {{0, 0, 0}, {0, 0, 1}, {0, 1, 0}, {0, 1, 1}, {1, 0, 0}, {1, 0, 1}, {1, 1, 0}, {1, 1, 1}};
+            const int nassoc = 8;
+#endif
+            for (first = 0; first < nassoc; first++) {
+                int32_t nb[3] = {b[0] + assoc[first][0], b[1] + assoc[first][1], b[2] + assoc[first][2]};
+                if (hmap_find(g, nb) != ORC_NONE) break;
+            }
+            (void)count;
+            rig->needs_block[i] = (first > 0 && first < nassoc) ? 1u : 0u;
+        }
+        /* touch_rigid_particle_blocks (sort.wgsl:38-52): only the sample's own block */
+        for (int32_t i = 0; i < rig->n; i++) {
+            if (!rig->needs_block[i]) continue;
+            float pf[3] = {0, 0, 0};
+            int32_t b[3];
+            uint32_t l[3];
+            for (int k = 0; k < D; k++) pf[k] = (float)rig->world_pts[i * D + k];
+            orc_block_and_local(pf, h, b, l);
+            mark_block_as_active(g, b);
+        }
     }
     /* update_block_particle_count */
     for (int32_t i = 0; i < p->n; i++) {
@@ -585,7 +620,29 @@ void orc_sort(const orc_particles *p, const orc_params *prm, orc_grid *g) {
         g->node_len[node]++;
     }
     free(scan);
+    if (rig) {
+        /* sort_rigid_particles (sort.wgsl:139-161): per-node lists; samples whose block does not exist are
+         * ignored. Built back to front so that heads are the smallest ids (reference: race order). */
+        for (size_t i = 0; i < nn; i++) { rig->node_head[i] = ORC_NONE; rig->node_len[i] = 0; }
+        for (int32_t i = rig->n - 1; i >= 0; i--) {
+            float pf[3] = {0, 0, 0};
+            int32_t b[3];
+            uint32_t l[3];
+            for (int k = 0; k < D; k++) pf[k] = (float)rig->world_pts[i * D + k];
+            orc_block_and_local(pf, h, b, l);
+            uint32_t id = hmap_find(g, b);
+            rig->next[i] = ORC_NONE;
+            if (id == ORC_NONE) continue;
+            uint32_t node = id * NPB + node_local_index(l);
+            rig->next[i] = rig->node_head[node];
+            rig->node_head[node] = (uint32_t)i;
+            rig->node_len[node]++;
+        }
+    }
 }
+
+void orc_sort(const orc_particles *p, const orc_params *prm, orc_grid *g) { sort_impl(p, prm, g, NULL); }
+void orc_sort_rigid(const orc_particles *p, const orc_params *prm, orc_grid *g, orc_rigid *rig) { sort_impl(p, prm, g, rig); }
 
 /* ------------------------------------------------------------------------ */
 /* Rigid-body helpers (third party in the reference: wgrapier body.wgsl,    */
@@ -762,6 +819,7 @@ void orc_grid_update_cdf(const orc_params *prm, orc_grid *g) {
             int nc = prm->n_colliders < ORC_MAX_COLLIDERS ? prm->n_colliders : ORC_MAX_COLLIDERS;
             for (int i = 0; i < nc; i++) {
                 const orc_collider *c = &prm->colliders[i];
+                if (c->shape_type >= ORC_SHAPE_MESH) continue; /* collide.wgsl:36-38 */
                 real pl[3], projl[3], proj[3];
                 pose_to_local(c, pt, pl);
                 int inside = project_local_on_boundary(c, pl, projl);
@@ -1366,5 +1424,139 @@ void orc_step_bodies(orc_particles *p, const orc_params *prm, orc_grid *g, orc_c
         orc_g2p(p, prm, g);
         orc_particle_update(p, prm);
         orc_integrate_bodies(prm, cols, bodies, prm->n_colliders, g->impulses);
+    }
+}
+
+/* ------------------------------------------------------------------------ */
+/* Rigid particles of mesh colliders                                         */
+/* ------------------------------------------------------------------------ */
+
+/* rigid_particle_update.wgsl:26-49: world = pose * local for the samples and for the mesh vertices */
+void orc_update_rigid_particles(const orc_params *prm, orc_rigid *rig) {
+    for (int32_t i = 0; i < rig->n; i++) {
+        const orc_collider *c = &prm->colliders[rig->ids[i * 4 + 3]];
+        real w[3] = {0, 0, 0}, l[3] = {0, 0, 0};
+        for (int k = 0; k < D; k++) l[k] = rig->local_pts[i * D + k];
+        pose_to_world(c, l, w);
+        for (int k = 0; k < D; k++) rig->world_pts[i * D + k] = w[k];
+    }
+    for (int32_t i = 0; i < rig->nv; i++) {
+        const orc_collider *c = &prm->colliders[rig->vtx_collider[i]];
+        real w[3] = {0, 0, 0}, l[3] = {0, 0, 0};
+        for (int k = 0; k < D; k++) l[k] = rig->local_vtx[i * D + k];
+        pose_to_world(c, l, w);
+        for (int k = 0; k < D; k++) rig->world_vtx[i * D + k] = w[k];
+    }
+}
+
+/* p2g_cdf.wgsl:52-190: every node gathers the rigid particles of the 27 (9) cells below it and projects
+ * itself on their primitive; a valid projection sets the collider's affinity bit, ORs its sign bit and competes
+ * for the closest collider. Equal distances: the smaller collider id wins (reference: list order). */
+void orc_p2g_cdf(const orc_params *prm, orc_grid *g, const orc_rigid *rig) {
+    const real h = prm->cell_width;
+    for (int32_t b = 0; b < g->n_blocks; b++)
+        for (uint32_t t = 0; t < NPB; t++) {
+            int tl[3] = {0, 0, 0};
+#if D == 2
+            tl[0] = (int)(t % 8); tl[1] = (int)(t / 8);
+#else
+            tl[0] = (int)(t % 4); tl[1] = (int)((t / 4) % 4); tl[2] = (int)(t / 16);
+#endif
+            uint32_t gid = (uint32_t)b * NPB + t;
+            real cell[3] = {0, 0, 0};
+            for (int k = 0; k < D; k++) cell[k] = (real)(g->block_vid[b * D + k] * BW + tl[k]) * h;
+            real ndist = g->node_cdf_dist[gid];
+            uint32_t naff = g->node_cdf_aff[gid], nclosest = g->node_cdf_closest[gid];
+            for (int n = 0; n < ORC_NBH; n++) {
+                int32_t cb[3];
+                uint32_t cl[3] = {0, 0, 0};
+                for (int k = 0; k < D; k++) {
+                    int rel = tl[k] + NBH_SHIFTS[n][k] - 2;
+                    int o = rel < 0 ? -1 : 0;
+                    cb[k] = g->block_vid[b * D + k] + o;
+                    cl[k] = (uint32_t)(rel - o * BW);
+                }
+                uint32_t id = hmap_find(g, cb);
+                if (id == ORC_NONE) continue;
+                uint32_t node = id * NPB + node_local_index(cl);
+                for (uint32_t rp = rig->node_head[node]; rp != ORC_NONE; rp = rig->next[rp]) {
+                    const uint32_t *ids = &rig->ids[rp * 4];
+                    uint32_t col = ids[3];
+                    const real *va = &rig->world_vtx[ids[0] * D], *vb = &rig->world_vtx[ids[1] * D];
+                    int valid = 0, sign = 0;
+                    real dist = 0;
+#if D == 2
+                    /* wgparry Segment::projectLocalPoint (third party): clamp of the orthogonal projection */
+                    real ab[2] = {vb[0] - va[0], vb[1] - va[1]}, ap[2] = {cell[0] - va[0], cell[1] - va[1]};
+                    real den = ab[0] * ab[0] + ab[1] * ab[1];
+                    real tt = den > 0 ? (ap[0] * ab[0] + ap[1] * ab[1]) / den : 0;
+                    real proj[2];
+                    if (tt <= 0) { proj[0] = va[0]; proj[1] = va[1]; }
+                    else if (tt >= 1) { proj[0] = vb[0]; proj[1] = vb[1]; }
+                    else { proj[0] = va[0] + ab[0] * tt; proj[1] = va[1] + ab[1] * tt; }
+                    if ((proj[0] != va[0] || proj[1] != va[1]) && (proj[0] != vb[0] || proj[1] != vb[1])) {
+                        real dp[2] = {cell[0] - proj[0], cell[1] - proj[1]};
+                        valid = 1;
+                        dist = r_sqrt(dp[0] * dp[0] + dp[1] * dp[1]);
+                        sign = (dp[0] * (-ab[1]) + dp[1] * ab[0]) < 0;
+                    }
+#else
+                    const real *vc = &rig->world_vtx[ids[2] * D];
+                    real ap[3], bp[3], cp[3], ab[3], ac[3], bc[3], nrm[3], t1[3];
+                    for (int k = 0; k < 3; k++) {
+                        ap[k] = cell[k] - va[k]; bp[k] = cell[k] - vb[k]; cp[k] = cell[k] - vc[k];
+                        ab[k] = vb[k] - va[k]; ac[k] = vc[k] - va[k]; bc[k] = vc[k] - vb[k];
+                    }
+#define CROSS(o, x, y) do { o[0] = x[1] * y[2] - x[2] * y[1]; o[1] = x[2] * y[0] - x[0] * y[2]; o[2] = x[0] * y[1] - x[1] * y[0]; } while (0)
+#define DOT(x, y) (x[0] * y[0] + x[1] * y[1] + x[2] * y[2])
+                    CROSS(nrm, ab, ac);
+                    real nlen = r_sqrt(DOT(nrm, nrm));
+                    if (nlen != 0) {
+                        real d1, d2, d3;
+                        CROSS(t1, ab, nrm); d1 = DOT(t1, ap);
+                        CROSS(t1, bc, nrm); d2 = DOT(t1, bp);
+                        CROSS(t1, ac, nrm); d3 = DOT(t1, cp);
+                        if (d1 <= 0 && d2 <= 0 && d3 >= 0) {
+                            real sd = DOT(nrm, ap) / nlen;
+                            valid = 1;
+                            sign = sd < 0;
+                            dist = r_abs(sd);
+                        }
+                    }
+#undef CROSS
+#undef DOT
+#endif
+                    if (!valid || col >= 16) continue;
+                    naff |= (1u << col) | ((uint32_t)sign << (col + 16));
+                    if (dist < ndist || (dist == ndist && col < nclosest)) {
+                        ndist = dist;
+                        nclosest = col;
+                    }
+                }
+            }
+            g->node_cdf_dist[gid] = ndist;
+            g->node_cdf_aff[gid] = naff;
+            g->node_cdf_closest[gid] = nclosest;
+        }
+}
+
+/* pipeline.rs:201-280, every pass */
+void orc_step_full(orc_particles *p, const orc_params *prm, orc_grid *g, orc_collider *cols, orc_body *bodies,
+                   orc_rigid *rig, int move_bodies, int n_substeps) {
+    for (int k = 0; k < 16 * (D + ORC_ANG); k++) g->impulses[k] = 0;
+    for (int s = 0; s < n_substeps; s++) {
+        if (move_bodies) orc_update_world_mass_properties(cols, bodies, prm->n_colliders);
+        if (rig) orc_update_rigid_particles(prm, rig);
+        sort_impl(p, prm, g, rig);
+        orc_grid_update_cdf(prm, g);
+        if (rig) orc_p2g_cdf(prm, g, rig);
+        orc_g2p_cdf(p, prm, g);
+        orc_p2g(p, prm, g);
+        orc_grid_update(prm, g);
+        orc_g2p(p, prm, g);
+        orc_particle_update(p, prm);
+        /* bodies that can neither move nor be pushed: the pass is the identity (the HIP path skips it too) */
+        if (move_bodies) orc_integrate_bodies(prm, cols, bodies, prm->n_colliders, g->impulses);
+        else for (int k = 0; k < 16 * (D + ORC_ANG); k++) g->impulses[k] = 0;
     }
 }

@@ -55,7 +55,8 @@ typedef ORC_REAL real;
 enum { ORC_MODEL_COROTATED = 0, ORC_MODEL_NEO_HOOKEAN = 1 };
 
 /* Analytic collider shapes handled by collide() (collision/collide.wgsl:23-56). */
-enum { ORC_SHAPE_BALL = 0, ORC_SHAPE_CUBOID = 1, ORC_SHAPE_CAPSULE = 2 };
+enum { ORC_SHAPE_BALL = 0, ORC_SHAPE_CUBOID = 1, ORC_SHAPE_CAPSULE = 2,
+       ORC_SHAPE_MESH = 3 /* trimesh / heightfield / polyline: no analytic projection (collide.wgsl:36-38), rigid particles instead */ };
 
 /* Particle state, structure-of-arrays. Matrices are column-major like WGSL
  * matNxN / nalgebra (element (r,c) at [c*D + r]).
@@ -135,6 +136,24 @@ typedef struct {
     int32_t *impulses;         /* 16*(D+ANG): fixed-point (x1e5) linear+angular impulses accumulated by p2g */
 } orc_grid;
 
+/* Rigid particles of the mesh colliders (GpuRigidParticles, src/solver/particle3d.rs:83-150, 2D
+ * particle2d.rs:60-125): sample points in the collider's local frame with the primitive (triangle / segment)
+ * they were sampled from, and the mesh vertices. Caller allocates everything. */
+typedef struct {
+    int32_t n;                 /* samples */
+    const real *local_pts;     /* n*D */
+    real *world_pts;           /* n*D, out of orc_update_rigid_particles */
+    const uint32_t *ids;       /* n*4: vertex ids of the primitive (2D: [0..1]), collider id in [3] */
+    int32_t nv;                /* mesh vertices */
+    const real *local_vtx;     /* nv*D */
+    real *world_vtx;           /* nv*D */
+    const uint32_t *vtx_collider; /* nv */
+    uint32_t *needs_block;     /* n: sort.wgsl:56-86 flag (one word per sample here) */
+    uint32_t *node_head;       /* cap*64: per-node rigid particle list (sort.wgsl:140-161) */
+    uint32_t *node_len;        /* cap*64 */
+    uint32_t *next;            /* n */
+} orc_rigid;
+
 #ifdef __cplusplus
 extern "C" {
 #endif
@@ -181,6 +200,14 @@ void orc_update_world_mass_properties(orc_collider *cols, orc_body *bodies, int 
 void orc_integrate_bodies(const orc_params *prm, orc_collider *cols, const orc_body *bodies, int n, int32_t *impulses);
 void orc_step_bodies(orc_particles *p, const orc_params *prm, orc_grid *g, orc_collider *cols, orc_body *bodies,
                      int n_substeps);
+
+/* rigid particles of mesh colliders — solver/rigid_particle_update.wgsl:26-49, grid/sort.wgsl:38-86,139-161,
+ * solver/p2g_cdf.wgsl:52-190. orc_step_full = the complete pipeline.rs:201-280 order. */
+void orc_update_rigid_particles(const orc_params *prm, orc_rigid *rig);
+void orc_sort_rigid(const orc_particles *p, const orc_params *prm, orc_grid *g, orc_rigid *rig);
+void orc_p2g_cdf(const orc_params *prm, orc_grid *g, const orc_rigid *rig);
+void orc_step_full(orc_particles *p, const orc_params *prm, orc_grid *g, orc_collider *cols, orc_body *bodies,
+                   orc_rigid *rig, int move_bodies, int n_substeps);
 
 #ifdef __cplusplus
 }

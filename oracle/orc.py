@@ -61,6 +61,11 @@ class Oracle:
             _fields_ = [("inv_mass", R * 3), ("inv_inertia_local", R * 9), ("local_com", R * 3),
                         ("inv_inertia_world", R * 9)]
 
+        class Rigid(C.Structure):
+            _fields_ = [("n", C.c_int32), ("local_pts", RP), ("world_pts", RP), ("ids", U32P), ("nv", C.c_int32),
+                        ("local_vtx", RP), ("world_vtx", RP), ("vtx_collider", U32P), ("needs_block", U32P),
+                        ("node_head", U32P), ("node_len", U32P), ("next", U32P)]
+
         class Params(C.Structure):
             _fields_ = [("gravity", R * 3), ("dt", R), ("cell_width", R), ("model", C.c_int32),
                         ("n_colliders", C.c_int32), ("colliders", C.POINTER(Collider))]
@@ -73,7 +78,7 @@ class Oracle:
                         ("particle_next", U32P), ("node_mv", RP), ("node_cdf_dist", RP),
                         ("node_cdf_aff", U32P), ("node_cdf_closest", U32P), ("impulses", I32P)]
 
-        self.Particles, self.Collider, self.Params, self.Grid, self.Body = Particles, Collider, Params, Grid, Body
+        self.Particles, self.Collider, self.Params, self.Grid, self.Body, self.Rigid = Particles, Collider, Params, Grid, Body, Rigid
         L = self.lib
         L.orc_pack_key.restype = C.c_uint32
         L.orc_pack_key.argtypes = [I32P]
@@ -231,6 +236,22 @@ class OracleState:
             "node_cdf_dist": np.zeros(nn, dt), "node_cdf_aff": np.zeros(nn, np.uint32),
             "node_cdf_closest": np.zeros(nn, np.uint32), "impulses": np.zeros(16 * (D + (1 if D == 2 else 3)), np.int32),
         }
+        # rigid particles of the mesh colliders (sampled on the host like the reference does)
+        from wgsparkl_amd.sampling import build_rigid_particles
+        rb = build_rigid_particles(colliders, D, float(cell_width))
+        self.R = None
+        if rb is not None:
+            n_r, n_v = len(rb["local_pts"]), len(rb["local_vtx"])
+            self.rig = {"local_pts": rb["local_pts"].astype(dt), "world_pts": np.zeros((n_r, D), dt),
+                        "ids": np.ascontiguousarray(rb["ids"], np.uint32), "local_vtx": rb["local_vtx"].astype(dt),
+                        "world_vtx": np.zeros((n_v, D), dt), "vtx_collider": rb["vtx_collider"],
+                        "needs_block": np.zeros(n_r, np.uint32), "node_head": np.zeros(nn, np.uint32),
+                        "node_len": np.zeros(nn, np.uint32), "next": np.zeros(n_r, np.uint32)}
+            Rg = orc.Rigid()
+            Rg.n, Rg.nv = n_r, n_v
+            for k, a in self.rig.items():
+                setattr(Rg, k, orc._p(a, C.c_uint32 if a.dtype == np.uint32 else orc.real))
+            self.R = Rg
         G = orc.Grid()
         G.cap_blocks, G.hmap_capacity = cap, hcap
         for k, a in self.g.items():
@@ -315,7 +336,10 @@ class OracleState:
         self.orc.lib.orc_integrate_bodies(C.byref(self.prm), self.cols, self.bodies, self.n_colliders, self.G.impulses)
 
     def step(self, n_substeps=1):
-        if self.moving:  # pipeline.rs:201-280 with the rigid-body passes (rigid_impulses.wgsl)
+        if self.R is not None:  # mesh colliders: the complete pipeline.rs:201-280 order
+            self.orc.lib.orc_step_full(C.byref(self.P), C.byref(self.prm), C.byref(self.G), self.cols, self.bodies,
+                                       C.byref(self.R), 1 if self.moving else 0, int(n_substeps))
+        elif self.moving:  # pipeline.rs:201-280 with the rigid-body passes (rigid_impulses.wgsl)
             self.orc.lib.orc_step_bodies(C.byref(self.P), C.byref(self.prm), C.byref(self.G), self.cols, self.bodies,
                                          int(n_substeps))
         else:

@@ -87,6 +87,13 @@ pub struct wgs_mass_properties {
 }
 #[repr(C)]
 #[derive(Copy, Clone)]
+pub struct wgs_sample_ids {
+    // = GpuSampleIds (src/solver/particle3d.rs:62-66); 2D: vertex[0..2] is the segment
+    pub vertex: [u32; 3],
+    pub collider: u32,
+}
+#[repr(C)]
+#[derive(Copy, Clone)]
 pub struct wgs_instance {
     // = src_testbed/instancing3d.rs InstanceData
     pub deformation: [[f32; 4]; 3],
@@ -147,6 +154,10 @@ extern "C" {
     pub fn wgs_prep_vertex_buffer(d: *mut wgs_data, mode: u32, instances: *mut wgs_instance) -> wgs_status;
     pub fn wgs_prep_vertex_buffer_device(d: *mut wgs_data, mode: u32, device_instances: *mut wgs_instance) -> wgs_status;
     pub fn wgs_set_plastic_state(d: *mut wgs_data, states: *const wgs_plastic_state) -> wgs_status;
+    pub fn wgs_set_rigid_particles(
+        d: *mut wgs_data, local_points: *const f32, ids: *const wgs_sample_ids, n: usize, local_vertices: *const f32,
+        vertex_collider_ids: *const u32, nv: usize,
+    ) -> wgs_status;
     pub fn wgs_read_grid(d: *mut wgs_data, out: *mut wgs_node_record, capacity: usize, count: *mut usize) -> wgs_status;
     pub fn wgs_read_blocks(
         d: *mut wgs_data, out: *mut wgs_block_record, capacity: usize, count: *mut usize, sorted_ids: *mut u32,

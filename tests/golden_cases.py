@@ -58,6 +58,34 @@ def dynamic_ball3d():
     return sc
 
 
+def mesh_floor3d():
+    """Mesh colliders (rigid particles, p2g_cdf): an elastic cube lands on an undulating heightfield while a
+    kinematic trimesh wedge pushes into its side."""
+    sc = scenes.neo_hookean_cube(n_side=8, with_floor=False)
+    sc["particles"].pos[:, 1] -= 0.4
+    sc["particles"].vel[:, 1] = -3.0
+    ii, jj = np.meshgrid(np.arange(7), np.arange(7), indexing="ij")
+    heights = (0.25 * np.sin(0.9 * ii) * np.cos(0.7 * jj)).astype(np.float32)
+    wedge_v = np.array([[0, -2, -2], [0, -2, 2], [0, 2, 2], [0, 2, -2], [-2, 0, 0]], np.float32)
+    wedge_i = np.array([[0, 1, 2], [0, 2, 3], [4, 1, 0], [4, 2, 1], [4, 3, 2], [4, 0, 3]], np.uint32)
+    sc["colliders"] = [Collider.heightfield(heights, (18.0, 1.0, 18.0), (22.13, 7.2, 21.81)),
+                       Collider.trimesh(wedge_v, wedge_i, (19.9, 9.5, 22.0), linvel=(0.6, 0.0, 0.0), angvel=(0.0, 0.3, 0.0))]
+    sc["grid_capacity"] = 1024
+    return sc
+
+
+def polyline2d():
+    """2D polyline collider: a V-shaped ground under an elastic block."""
+    sc = scenes.elastic_block_2d(nx=20, ny=16, with_floor=False)
+    sc["particles"].vel[:, 1] = -6.0
+    verts = np.array([[-14.0, 3.0], [-4.0, 0.4], [0.0, 0.0], [5.0, 0.6], [14.0, 3.5]], np.float32)
+    segs = np.array([[0, 1], [1, 2], [2, 3], [3, 4]], np.uint32)
+    x0 = float(sc["particles"].pos[:, 0].mean())
+    y0 = float(sc["particles"].pos[:, 1].min())
+    sc["colliders"] = [Collider.polyline(verts, segs, (x0, y0 - 0.9))]
+    return sc
+
+
 CASES = {"cloud3d": (cloud3d, 3), "cloud2d": (cloud2d, 3), "sand3d": (sand3d, 2), "floor3d": (floor3d, 20),
          "tilted_box2d": (tilted_box2d, 20), "dynamic_ball2d": (dynamic_ball2d, 120),
-         "dynamic_ball3d": (dynamic_ball3d, 120)}
+         "dynamic_ball3d": (dynamic_ball3d, 120), "mesh_floor3d": (mesh_floor3d, 80), "polyline2d": (polyline2d, 140)}

@@ -22,6 +22,7 @@
 
 #include "kernels_bodies.h"
 #include "kernels_cdf.h"
+#include "kernels_rigid.h"
 #include "kernels_shard.h"
 #include "kernels_sort.h"
 #include "kernels_transfer.h"
@@ -406,9 +407,16 @@ template <bool TS> wgs_status enqueue_substep(wgs_data *d, int ts_slot, int part
             HIP_TRY(hipMemsetAsync(dev.hvals, 0xff, sizeof(uint32_t) * ((size_t)dev.hmask + 1), s));
             HIP_TRY(hipMemsetAsync(dev.counters + CTR_NPHYS, 0, sizeof(uint32_t), s));
         }
+        // ---- "update rigid particles" (rigid_particle_update.wgsl): samples and vertices of the mesh colliders
+        if (dev.n_rigid > 0)
+            hipLaunchKernelGGL(k_rigid_transform<D>, dim3(grid_for(d, 1)), dim3(256), 0, s, dev);
         if (n > 0) {
             if (use_rebin) hipLaunchKernelGGL(k_rebin<D>, dim3(pgrid), dim3(SORT_THREADS), 0, s, dev, side, epoch);
             else hipLaunchKernelGGL(k_bin<D>, dim3(pgrid), dim3(SORT_THREADS), 0, s, dev, side, epoch);
+            if (dev.n_rigid > 0) {  // blocks a mesh sample reaches must exist (sort.wgsl:38-86)
+                hipLaunchKernelGGL(k_rigid_mark<D>, dim3(grid_for(d, 1)), dim3(256), 0, s, dev, epoch);
+                hipLaunchKernelGGL(k_rigid_touch<D>, dim3(grid_for(d, 1)), dim3(256), 0, s, dev, epoch);
+            }
             hipLaunchKernelGGL(k_scan_active, dim3(1), dim3(SCAN_THREADS), 0, s, dev, epoch);
             hipLaunchKernelGGL(k_block_setup<D>, dim3(grid_for(d, 4)), dim3(SORT_THREADS), 0, s, dev, epoch);
             hipLaunchKernelGGL(k_scatter<D>, dim3(pgrid), dim3(SORT_THREADS), 0, s, dev, side);
@@ -420,6 +428,8 @@ template <bool TS> wgs_status enqueue_substep(wgs_data *d, int ts_slot, int part
         mark(1);
         // ---- "grid_update_cdf" + "g2p_cdf" (collide.wgsl, grid_update_cdf.wgsl, g2p_cdf.wgsl): one launch
         // (kernels_cdf.h); the reference's two pass names share its time in wgs_read_timings
+        if (dev.n_rigid > 0 && n > 0)  // "p2g_cdf": mesh primitives -> node cdf accumulators
+            hipLaunchKernelGGL(k_p2g_cdf<D>, dim3(grid_for(d, 1)), dim3(256), 0, s, dev, epoch);
         if (d->cpic && n > 0)
             hipLaunchKernelGGL(k_cdf<D>, dim3(grid_for(d, 16)), dim3(CDF_THREADS), 0, s, dev, side, epoch);
         mark(2);
@@ -945,6 +955,53 @@ wgs_status wgs_set_body_mass_properties(wgs_data *d, const wgs_mass_properties *
                                  hipMemcpyHostToDevice, d->stream));
     if (n) hipLaunchKernelGGL(k_bodies_refresh<D>, dim3(1), dim3(16), 0, d->stream, d->dev, 0u);
     HIP_TRY(hipGetLastError());
+    return WGS_OK;
+}
+
+wgs_status wgs_set_rigid_particles(wgs_data *d, const float *local_points, const wgs_sample_ids *ids, size_t n,
+                                   const float *local_vertices, const uint32_t *vertex_collider_ids, size_t nv) {
+    if (!d) return fail(WGS_ERR_INVALID_ARGUMENT, "NULL argument");
+    if (n && (!local_points || !ids || !local_vertices || !vertex_collider_ids || !nv))
+        return fail(WGS_ERR_INVALID_ARGUMENT, "NULL argument");
+    if (d->dev.sharded) return fail(WGS_ERR_UNSUPPORTED, "mesh colliders on sharded data");
+    if (n > 0xffffffffull || nv > 0xffffffffull) return fail(WGS_ERR_INVALID_ARGUMENT, "too many samples");
+    for (size_t i = 0; i < n; i++) {
+        if (ids[i].collider >= d->dev.n_colliders) return fail(WGS_ERR_INVALID_ARGUMENT, "sample of an unknown collider");
+        for (int k = 0; k < D; k++)
+            if (ids[i].vertex[k] >= nv) return fail(WGS_ERR_INVALID_ARGUMENT, "sample refers to a vertex out of range");
+    }
+    for (size_t i = 0; i < nv; i++)
+        if (vertex_collider_ids[i] >= d->dev.n_colliders) return fail(WGS_ERR_INVALID_ARGUMENT, "vertex of an unknown collider");
+    HIP_TRY(hipSetDevice(d->pipeline->device));
+    HIP_TRY(hipStreamSynchronize(d->stream));
+    Dev &dev = d->dev;
+    dev.n_rigid = 0;  // (buffers of an earlier call stay owned by the data and are released with it)
+    if (n == 0) return WGS_OK;
+    wgs_status st;
+#define RP_ALLOC(ptr, count) \
+    if ((st = dev_alloc(d, ptr, (size_t)(count))) != WGS_OK) return st
+    RP_ALLOC(&dev.rp_local, n * D);
+    RP_ALLOC(&dev.rp_world, n * D);
+    RP_ALLOC(&dev.rp_ids, n);
+    RP_ALLOC(&dev.rv_local, nv * D);
+    RP_ALLOC(&dev.rv_world, nv * D);
+    RP_ALLOC(&dev.rv_collider, nv);
+    RP_ALLOC(&dev.rp_needs, n);
+    if (!dev.mesh_min) {
+        RP_ALLOC(&dev.mesh_min, (size_t)dev.cap * NPB);
+        RP_ALLOC(&dev.mesh_aff, (size_t)dev.cap * NPB);
+    }
+#undef RP_ALLOC
+    std::vector<uint4> packed(n);
+    for (size_t i = 0; i < n; i++)
+        packed[i] = make_uint4(ids[i].vertex[0], ids[i].vertex[1], D == 3 ? ids[i].vertex[2] : 0u, ids[i].collider);
+    HIP_TRY(hipMemcpyAsync(dev.rp_local, local_points, sizeof(float) * n * D, hipMemcpyHostToDevice, d->stream));
+    HIP_TRY(hipMemcpyAsync(dev.rp_ids, packed.data(), sizeof(uint4) * n, hipMemcpyHostToDevice, d->stream));
+    HIP_TRY(hipMemcpyAsync(dev.rv_local, local_vertices, sizeof(float) * nv * D, hipMemcpyHostToDevice, d->stream));
+    HIP_TRY(hipMemcpyAsync(dev.rv_collider, vertex_collider_ids, sizeof(uint32_t) * nv, hipMemcpyHostToDevice, d->stream));
+    HIP_TRY(hipStreamSynchronize(d->stream));
+    dev.n_rigid = (uint32_t)n;
+    dev.n_rvtx = (uint32_t)nv;
     return WGS_OK;
 }
 

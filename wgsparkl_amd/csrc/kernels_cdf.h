@@ -128,6 +128,7 @@ template <int D> __device__ inline NodeCdf node_cdf_eval(const Dev &d, const flo
     NodeCdf cdf = {1.0e10f, 0u, NONE, 0u};
     for (uint32_t i = 0; i < d.n_colliders && i < 16u; i++) {
         const ColliderDev &c = d.colliders[i];
+        if (c.shape_type >= 3u) continue;  // mesh shapes have no analytic projection (collide.wgsl:36-38)
         float pl[D], projl[D], proj[D];
         pose_to_local<D>(c, pt, pl);
         bool inside = project_local_on_boundary<D>(c, pl, projl);
@@ -228,6 +229,20 @@ template <int D> __global__ __launch_bounds__(CDF_THREADS) void k_cdf(Dev d, int
 #pragma unroll
                 for (int k = 0; k < D; k++) pt[k] = (float)(bc[k] * BW + t[k]) * h;
                 c = node_cdf_eval<D>(d, pt);
+                if (d.n_rigid != 0u) {  // mesh colliders: merge what k_p2g_cdf scattered (p2g_cdf.wgsl:103-117)
+                    int ln = (t[0] & (BW - 1)) + ((t[1] & (BW - 1)) << BS) + (D == 3 ? ((t[2] & (BW - 1)) << (2 * BS)) : 0);
+                    const size_t mn = (size_t)d.nbr_plus[b * 8u + o] * NPB + ln;
+                    const unsigned long long mm = d.mesh_min[mn];
+                    if (mm != ~0ull) {
+                        const float md = __uint_as_float((uint32_t)(mm >> 32));
+                        const uint32_t mid = (uint32_t)mm;
+                        c.affinities |= d.mesh_aff[mn];
+                        if (md < c.distance || (md == c.distance && mid < c.closest_id)) {
+                            c.distance = md;
+                            c.closest_id = mid;
+                        }
+                    }
+                }
                 if (o == 0) {
                     int ln = t[0] + (t[1] << BS) + (D == 3 ? (t[2] << (2 * BS)) : 0);
                     d.node_cdf[(size_t)b * NPB + ln] = c;

@@ -306,6 +306,10 @@ template <int D> __global__ __launch_bounds__(SORT_THREADS) void k_block_setup(D
         d.cell_start[idx] = start;
         d.cell_cursor[idx] = start + cnt;  // cell end
         d.cell_count[idx] = 0;             // accumulators are zero at rest
+        if (d.n_rigid != 0u) {             // mesh-collider cdf accumulators of this substep (k_p2g_cdf)
+            d.mesh_min[idx] = ~0ull;
+            d.mesh_aff[idx] = 0u;
+        }
         if (lane == 63) {
             d.block_count[id] = inc;       // snapshot used by P2G / grid update / G2P
             d.links_epoch[id] = epoch;     // the neighbour links written above are those of this substep

@@ -146,6 +146,15 @@ struct Dev {
     BodyDev *bodies;         // 16: mass properties
     int32_t *impulses;       // 16 * 8: fixed-point (x 1e5) linear[D] + angular impulses accumulated by P2G
     float4 *imp_slab;        // cap*TILE*IMPQ per-block partial node impulses (two-way coupling only), or null
+    // rigid particles of mesh colliders (kernels_rigid.h); n_rigid == 0 when there is none
+    uint32_t n_rigid, n_rvtx;
+    float *rp_local, *rp_world;          // n_rigid * D: sample points, body frame / world
+    uint4 *rp_ids;                       // n_rigid: vertex ids of the sample's triangle / segment, collider id in .w
+    float *rv_local, *rv_world;          // n_rvtx * D: mesh vertices
+    uint32_t *rv_collider;               // n_rvtx
+    uint32_t *rp_needs;                  // n_rigid: sort.wgsl:55-86 flag
+    unsigned long long *mesh_min;        // cap*64: (distance bits << 32 | collider id) of the closest mesh primitive, ~0 = none
+    uint32_t *mesh_aff;                  // cap*64: affinity / sign bits set by mesh primitives
     float h;             // cell width
     float inv_h;
     uint32_t h_pow2;     // cell width is a power of two: x * inv_h == x / h bit for bit

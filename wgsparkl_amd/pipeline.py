@@ -188,6 +188,11 @@ class MpmData:
             self.set_constitutive_model(model)
         if any(_is_dynamic(c) for c in colliders):
             self.set_body_mass_properties(colliders)
+        # mesh colliders: sampled on the host like GpuRigidParticles::from_rapier (sampling step = cell width)
+        from .sampling import build_rigid_particles
+        rb = build_rigid_particles(colliders, D, float(cell_width))
+        if rb is not None:
+            self.set_rigid_particles(rb)
 
     @classmethod
     def new(cls, pipeline, params, particles, colliders, cell_width, grid_capacity, model=MODEL_COROTATED):
@@ -223,6 +228,18 @@ class MpmData:
         _ffi.check(self.lib, self.lib.wgs_set_collider_poses(self._h, poses, coms, n))
         _ffi.check(self.lib, self.lib.wgs_set_body_velocities(self._h, vels, n))
         self.set_body_mass_properties(colliders)
+
+    def set_rigid_particles(self, rb: dict):
+        """`rb` = sampling.build_rigid_particles(...): local sample points, (vertex ids, collider) per sample, local
+        mesh vertices and their collider (GpuRigidParticles + the shape vertex buffers)."""
+        pts = np.ascontiguousarray(rb["local_pts"], F32)
+        ids = np.ascontiguousarray(rb["ids"], np.uint32)
+        vtx = np.ascontiguousarray(rb["local_vtx"], F32)
+        vcol = np.ascontiguousarray(rb["vtx_collider"], np.uint32)
+        fp, up = C.POINTER(C.c_float), C.POINTER(C.c_uint32)
+        _ffi.check(self.lib, self.lib.wgs_set_rigid_particles(
+            self._h, pts.ctypes.data_as(fp), ids.ctypes.data_as(C.c_void_p), len(pts), vtx.ctypes.data_as(fp),
+            vcol.ctypes.data_as(up), len(vtx)))
 
     def set_body_mass_properties(self, colliders: Sequence[Collider]):
         """GpuBodySet::from_rapier's local mass properties: all zero = kinematic, else two-way coupling."""

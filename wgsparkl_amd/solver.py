@@ -160,6 +160,7 @@ class ParticleSet:
 SHAPE_BALL = 0
 SHAPE_CUBOID = 1
 SHAPE_CAPSULE = 2
+SHAPE_MESH = 3       # trimesh / heightfield (3D), polyline (2D): coupled through rigid particles (sampling.py)
 
 
 @dataclass
@@ -179,6 +180,9 @@ class Collider:
     # kinematic / fixed: the body follows its velocity only. Non-zero = dynamic: two-way coupling.
     inv_mass: Sequence[float] = (0.0, 0.0, 0.0)
     inv_inertia_local: Sequence[float] = (0.0,) * 9   # 3D: column-major, body frame; 2D: (1/I,)
+    # mesh colliders (shape_type == SHAPE_MESH): local-frame vertices [nv, D] and triangles [nt, 3] / segments [ns, 2]
+    vertices: Optional[np.ndarray] = None
+    indices: Optional[np.ndarray] = None
 
     def with_density(self, density: float, dim: int) -> "Collider":
         """Dynamic body of uniform density (rapier's MassProperties::from_ball / from_cuboid / from_capsule
@@ -211,6 +215,25 @@ class Collider:
     @staticmethod
     def cuboid(half_extents, translation, **kw) -> "Collider":
         return Collider(SHAPE_CUBOID, tuple(half_extents), tuple(translation), **kw)
+
+    @staticmethod
+    def trimesh(vertices, indices, translation, **kw) -> "Collider":
+        """TriMesh collider (src/solver/particle3d.rs:118-127)."""
+        return Collider(SHAPE_MESH, (0.0,), tuple(translation), vertices=np.asarray(vertices, np.float32),
+                        indices=np.asarray(indices, np.uint32), **kw)
+
+    @staticmethod
+    def polyline(vertices, indices, translation, **kw) -> "Collider":
+        """2D Polyline collider (src/solver/particle2d.rs:92-102)."""
+        return Collider(SHAPE_MESH, (0.0,), tuple(translation), vertices=np.asarray(vertices, np.float32),
+                        indices=np.asarray(indices, np.uint32), **kw)
+
+    @staticmethod
+    def heightfield(heights, scale, translation, **kw) -> "Collider":
+        """HeightField collider, converted to a trimesh like the reference does (src/solver/particle3d.rs:128-138)."""
+        from .sampling import heightfield_to_trimesh
+        v, i = heightfield_to_trimesh(heights, scale)
+        return Collider.trimesh(v, i, translation, **kw)
 
     @staticmethod
     def ball(radius, translation, **kw) -> "Collider":
