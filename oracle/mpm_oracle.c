@@ -29,6 +29,12 @@ static inline real r_abs(real x) { return x < 0 ? -x : x; }
 static inline real r_max(real a, real b) { return a > b ? a : b; }
 static inline real r_min(real a, real b) { return a < b ? a : b; }
 
+#ifdef _OPENMP
+#include <omp.h>
+int orc_num_threads(void) { return omp_get_max_threads(); }
+#else
+int orc_num_threads(void) { return 1; }
+#endif
 int orc_dim(void) { return D; }
 int orc_real_size(void) { return (int)sizeof(real); }
 
@@ -803,6 +809,7 @@ static int affinities_are_compatible(uint32_t a1, uint32_t a2) {
 /* ------------------------------------------------------------------------ */
 void orc_grid_update_cdf(const orc_params *prm, orc_grid *g) {
     const real h = prm->cell_width;
+#pragma omp parallel for schedule(static)
     for (int32_t b = 0; b < g->n_blocks; b++)
         for (uint32_t t = 0; t < NPB; t++) {
             uint32_t l[3];
@@ -903,6 +910,7 @@ static void solve_small(const real *m, const real *r, real *x) {
 void orc_g2p_cdf(orc_particles *p, const orc_params *prm, const orc_grid *g) {
     const real h = prm->cell_width;
     enum { N = D + 1 };
+    #pragma omp parallel for schedule(static)
     for (int32_t i = 0; i < p->n; i++) {
         float pf[3];
         int32_t b[3];
@@ -1015,6 +1023,8 @@ void orc_p2g(const orc_particles *p, const orc_params *prm, orc_grid *g) {
     const real h = prm->cell_width;
     /* the accumulators are zeroed by their consumer (rigid_impulses.wgsl:104-109); orc_step, which has
      * no bodies, clears them itself */
+    /* blocks are independent (per-node gather); the only shared state is the integer impulse sum */
+#pragma omp parallel for schedule(dynamic, 4)
     for (int32_t b = 0; b < g->n_blocks; b++) {
         for (uint32_t t = 0; t < NPB; t++) {
             int tl[3] = {0, 0, 0};
@@ -1112,9 +1122,17 @@ void orc_p2g(const orc_particles *p, const orc_params *prm, orc_grid *g) {
             if (collider_id != ORC_NONE && collider_id < 16) {
                 /* rigid_impulses.wgsl:52-54 flt2int: i32(flt * 1e5), accumulated atomically */
                 for (int k = 0; k < D; k++)
-                    g->impulses[collider_id * (D + ORC_ANG) + k] += flt2int((float)imp[k]);
+                {
+                    const int32_t v = flt2int((float)imp[k]);
+#pragma omp atomic
+                    g->impulses[collider_id * (D + ORC_ANG) + k] += v;
+                }
                 for (int k = 0; k < ORC_ANG; k++)
-                    g->impulses[collider_id * (D + ORC_ANG) + D + k] += flt2int((float)ang[k]);
+                {
+                    const int32_t v = flt2int((float)ang[k]);
+#pragma omp atomic
+                    g->impulses[collider_id * (D + ORC_ANG) + D + k] += v;
+                }
             }
         }
     }
@@ -1126,6 +1144,7 @@ void orc_p2g(const orc_particles *p, const orc_params *prm, orc_grid *g) {
 void orc_grid_update(const orc_params *prm, orc_grid *g) {
     const real dt = prm->dt, h = prm->cell_width;
     size_t nn = (size_t)g->n_blocks * NPB;
+    #pragma omp parallel for schedule(static)
     for (size_t i = 0; i < nn; i++) {
         real *mv = &g->node_mv[i * (D + 1)];
         real mass = mv[D];
@@ -1145,6 +1164,7 @@ void orc_grid_update(const orc_params *prm, orc_grid *g) {
 void orc_g2p(orc_particles *p, const orc_params *prm, const orc_grid *g) {
     const real h = prm->cell_width;
     const real invd = inv_d(h);
+    #pragma omp parallel for schedule(static)
     for (int32_t i = 0; i < p->n; i++) {
         float pf[3];
         int32_t b[3];
@@ -1218,6 +1238,7 @@ void orc_g2p(orc_particles *p, const orc_params *prm, const orc_grid *g) {
 /* ------------------------------------------------------------------------ */
 void orc_particle_update(orc_particles *p, const orc_params *prm) {
     const real dt = prm->dt, h = prm->cell_width;
+    #pragma omp parallel for schedule(static)
     for (int32_t i = 0; i < p->n; i++) {
         real vel[D], nrm[D], rv[D];
         for (int k = 0; k < D; k++) {

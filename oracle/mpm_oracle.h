@@ -159,6 +159,7 @@ extern "C" {
 #endif
 
 int orc_dim(void);
+int orc_num_threads(void);   /* 1 unless built with -fopenmp (the _omp flavour used as bench.py's CPU baseline) */
 int orc_real_size(void);
 
 /* index math — grid.wgsl:82-105, 284-292; particle3d.wgsl:41-45 */

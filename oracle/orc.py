@@ -25,16 +25,17 @@ def build(force: bool = False) -> None:
     subprocess.run(["make", "-C", _HERE, "all"], check=True, capture_output=True)
 
 
-def _lib_path(dim: int, dtype) -> str:
+def _lib_path(dim: int, dtype, omp: bool = False) -> str:
     suffix = "f32" if np.dtype(dtype) == np.float32 else "f64"
-    return os.path.join(_BUILD, f"liborc{dim}d_{suffix}.so")
+    return os.path.join(_BUILD, f"liborc{dim}d_{suffix}{'_omp' if omp else ''}.so")
 
 
 class Oracle:
     """One (dim, precision) flavour of the oracle."""
 
-    def __init__(self, dim: int = 3, dtype=np.float32):
-        path = _lib_path(dim, dtype)
+    def __init__(self, dim: int = 3, dtype=np.float32, omp: bool = False):
+        """`omp`: the OpenMP build of the same source (3D fp32 only; bench.py's multi-core CPU baseline)."""
+        path = _lib_path(dim, dtype, omp)
         if not os.path.exists(path):
             build()
         self.dim = dim
@@ -42,6 +43,7 @@ class Oracle:
         self.real = C.c_float if self.dtype == np.float32 else C.c_double
         self.lib = C.CDLL(path)
         assert self.lib.orc_dim() == dim and self.lib.orc_real_size() == self.dtype.itemsize
+        self.num_threads = int(self.lib.orc_num_threads())
         R = self.real
         RP = C.POINTER(R)
         U32P = C.POINTER(C.c_uint32)

@@ -120,21 +120,38 @@ class FixedExchange:
     def __init__(self, dist, rank: int, world: int):
         import torch
         self.torch, self.dist, self.rank, self.world = torch, dist, rank, world
+        self.lower = rank - 1 if rank > 0 else None
+        self.upper = rank + 1 if rank < world - 1 else None
+        # send buffers are persistent (GpuShard owns them), so the receive buffers and the P2POp lists are
+        # built once per (lower buffer, upper buffer) pair and reused: two receive sets alternate, the
+        # previous one may still be read by a kernel enqueued on the stream
+        self._plans = {}
+
+    def _plan(self, to_lower, to_upper):
+        torch, dist = self.torch, self.dist
+        key = (None if to_lower is None else to_lower.data_ptr(), None if to_upper is None else to_upper.data_ptr())
+        plan = self._plans.get(key)
+        if plan is None:
+            sets = []
+            for _ in range(2):
+                ops, from_lower, from_upper = [], None, None
+                # every rank uses the same buffer capacities, so both directions of a face carry same-sized messages
+                if self.lower is not None and to_lower is not None:
+                    from_lower = torch.empty_like(to_lower)
+                    ops += [dist.P2POp(dist.isend, to_lower, self.lower), dist.P2POp(dist.irecv, from_lower, self.lower)]
+                if self.upper is not None and to_upper is not None:
+                    from_upper = torch.empty_like(to_upper)
+                    ops += [dist.P2POp(dist.isend, to_upper, self.upper), dist.P2POp(dist.irecv, from_upper, self.upper)]
+                sets.append((ops, from_lower, from_upper))
+            plan = self._plans[key] = [sets, 0]
+        sets, turn = plan
+        plan[1] = turn ^ 1
+        return sets[turn]
 
     def __call__(self, to_lower, to_upper):
-        torch, dist = self.torch, self.dist
-        lower = self.rank - 1 if self.rank > 0 else None
-        upper = self.rank + 1 if self.rank < self.world - 1 else None
-        ops, from_lower, from_upper = [], None, None
-        # every rank uses the same buffer capacities, so both directions of a face carry same-sized messages
-        if lower is not None and to_lower is not None:
-            from_lower = torch.empty_like(to_lower)
-            ops += [dist.P2POp(dist.isend, to_lower, lower), dist.P2POp(dist.irecv, from_lower, lower)]
-        if upper is not None and to_upper is not None:
-            from_upper = torch.empty_like(to_upper)
-            ops += [dist.P2POp(dist.isend, to_upper, upper), dist.P2POp(dist.irecv, from_upper, upper)]
+        ops, from_lower, from_upper = self._plan(to_lower, to_upper)
         if ops:
-            for w in dist.batch_isend_irecv(ops):
+            for w in self.dist.batch_isend_irecv(ops):
                 w.wait()     # stream-level wait on NCCL/RCCL (does not block the host)
         return from_lower, from_upper
 
