@@ -128,8 +128,9 @@ typedef struct {
 enum { WGS_MODEL_COROTATED = 0, WGS_MODEL_NEO_HOOKEAN = 1 };
 
 /* The reference's 10 timestamped passes (src/pipeline.rs:201-271). The fused
- * G2P + particle update reports its time under WGS_PASS_G2P and 0 under
- * WGS_PASS_PARTICLES_UPDATE. */
+ * G2P + particle update reports its time under WGS_PASS_G2P; in collider simulations
+ * the same kernel's second launch, over the blocks near a collider, is reported under
+ * WGS_PASS_PARTICLES_UPDATE (0 without colliders). */
 enum {
     WGS_PASS_UPDATE_RIGID_PARTICLES = 0, WGS_PASS_GRID_SORT = 1, WGS_PASS_GRID_UPDATE_CDF = 2,
     WGS_PASS_P2G_CDF = 3, WGS_PASS_G2P_CDF = 4, WGS_PASS_P2G = 5, WGS_PASS_GRID_UPDATE = 6,

@@ -72,6 +72,29 @@ def test_c3_sand_column_four_million(hip_libs):
     assert s["overflow"] == 0 and s["num_active_blocks"] > 10_000
 
 
+def test_c4_eight_million_corotated_with_kinematic_paddle(hip_libs):
+    """configs[3] on one GPU: 8M corotated particles on the floor, one kinematic rotating cuboid pushing into them
+    (collision = CPIC, src/collision + rigid_impulses.wgsl for the body pose)."""
+    sc = scenes.corotated_cube_with_paddle(n_side=200)
+    n = sc["particles"].n
+    assert n == 8_000_000
+    k = 6
+    data = run_gpu(sc, k)
+    check_sort_structure(data, n)
+    got = data.read_particles()
+    assert np.isfinite(got.pos).all() and np.isfinite(got.affine).all()
+    s = data.stats()
+    assert s["overflow"] == 0
+    assert ((got.cdf_affinity & 1) != 0).sum() > 10_000 and ((got.cdf_affinity & 2) != 0).sum() > 1_000   # floor, paddle
+    # the kinematic paddle: w = (0, 0.8, 0) about its own centre, v = (-2, 0, 0); caps apply once it touches particles
+    body = data.read_body_poses()[1]
+    dt = sc["params"].dt
+    assert np.allclose(body["angvel"], [0.0, 0.8, 0.0]) and body["linvel"][0] < 0.0
+    ang = 0.8 * dt * k
+    assert np.allclose(body["rotation"], [0.0, np.sin(ang / 2), 0.0, np.cos(ang / 2)], atol=1e-6)
+    assert body["translation"][0] < sc["colliders"][1].translation[0]
+
+
 def test_bit_identical_reruns_at_scale(hip_libs):
     sc = scenes.neo_hookean_cube(n_side=64)
     rng = np.random.default_rng(2)

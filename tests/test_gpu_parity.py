@@ -141,6 +141,41 @@ def test_grid_overflow_is_reported(hip_libs):
         run_gpu(sc, 1)
 
 
+def test_sharded_run_with_kinematic_collider(hip_libs):
+    """configs[3]'s decomposition on one GPU: 4 slabs, a floor and a kinematic rotating cuboid that every rank
+    integrates identically; particles, CPIC state and the body pose match the single-domain run."""
+    from helpers import pipeline
+    from wgsparkl_amd.sharded import GpuShard, SlabPartition, associated_block_x, lockstep_substep, split_scene
+    sc = scenes.corotated_cube_with_paddle(n_side=40)
+    ps = sc["particles"]
+    k, world = 30, 4
+    single = run_gpu(sc, k)
+    ref, ref_body = single.read_particles(), single.read_body_poses()
+    assert ((ref.cdf_affinity & 2) != 0).sum() > 100       # the paddle does touch the block
+    part = SlabPartition.balanced(associated_block_x(ps.pos, sc["cell_width"], 3), world)
+    pipe = pipeline(3)
+    shards = []
+    for r, (sub, gids) in enumerate(split_scene(ps, part, sc["cell_width"])):
+        lo, hi = part.block_range(r)
+        shards.append(GpuShard(pipe, sc["params"], sub, gids, sc["colliders"], sc["cell_width"], sc["grid_capacity"],
+                               lo, hi, r > 0, r < world - 1, particle_capacity=ps.n, model=sc["model"]))
+    for _ in range(k):
+        lockstep_substep(shards)
+    outs = [s.export() for s in shards]
+    ids = np.concatenate([o["ids"] for o in outs])
+    assert np.array_equal(np.sort(ids), np.arange(ps.n, dtype=np.uint32))
+    order = np.argsort(ids)
+    for f in ("pos", "vel"):
+        got = np.concatenate([o[f] for o in outs])[order]
+        assert rel_rms(got, getattr(ref, f)) < 1e-5, f
+    poses = (shards[0].T.Pose * 2)()
+    from wgsparkl_amd import _ffi
+    for s in shards:                                        # every rank holds the same body state
+        _ffi.check(s.lib, s.lib.wgs_read_body_poses(s._h, poses, None, None, 2))
+        assert np.allclose(list(poses[1].rotation), ref_body[1]["rotation"], atol=1e-6)
+        assert np.allclose(list(poses[1].translation), ref_body[1]["translation"], atol=1e-5)
+
+
 def test_body_setters_and_readback(hip_libs, oracle_libs):
     """wgs_set_body_velocities / wgs_set_collider_poses / wgs_set_body_mass_properties between steps, and the
     pose read-back of the testbed (src_testbed/step.rs:79-132): the device-integrated poses are not rolled back

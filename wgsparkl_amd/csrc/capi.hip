@@ -51,7 +51,7 @@ wgs_status fail(wgs_status code, const std::string &msg) {
 
 struct Events {
     static constexpr int MAX_SUBSTEPS = 64;
-    static constexpr int MARKS = 8;  // boundaries: start, sort, cdf_nodes, cdf_particles, p2g, grid, g2p, bodies(end)
+    static constexpr int MARKS = 9;  // boundaries: start, sort, cdf_nodes, cdf_particles, p2g, grid, g2p, g2p near colliders, bodies(end)
     hipEvent_t ev[MAX_SUBSTEPS][MARKS];
     int used = 0;
     bool created = false;
@@ -368,11 +368,12 @@ void resolve_timings(wgs_data *d) {
     hipStreamSynchronize(d->stream);
     for (int p = 0; p < WGS_NUM_PASSES; p++) d->timings[p] = 0.f;
     // marks: 0 start | 1 after sort | 2 after node cdf | 3 after particle cdf | 4 after p2g | 5 after grid update |
-    //        6 after fused g2p | 7 after integrate_bodies
-    const int pass_of_mark[7] = {WGS_PASS_GRID_SORT, WGS_PASS_GRID_UPDATE_CDF, WGS_PASS_G2P_CDF,   WGS_PASS_P2G,
-                                 WGS_PASS_GRID_UPDATE, WGS_PASS_G2P,           WGS_PASS_INTEGRATE_BODIES};
+    //        6 after the fused g2p launch | 7 after its near-collider launch | 8 after integrate_bodies
+    const int pass_of_mark[8] = {WGS_PASS_GRID_SORT,   WGS_PASS_GRID_UPDATE_CDF, WGS_PASS_G2P_CDF,          WGS_PASS_P2G,
+                                 WGS_PASS_GRID_UPDATE, WGS_PASS_G2P,             WGS_PASS_PARTICLES_UPDATE, WGS_PASS_INTEGRATE_BODIES};
     for (int s = 0; s < d->events.used; s++)
-        for (int m = 0; m < 7; m++) {
+        for (int m = 0; m < 8; m++) {
+            if (m == 6 && !d->cpic) continue;  // no second G2P launch: the two marks are adjacent
             float ms = 0.f;
             if (hipEventElapsedTime(&ms, d->events.ev[s][m], d->events.ev[s][m + 1]) == hipSuccess)
                 d->timings[pass_of_mark[m]] += ms;
@@ -467,6 +468,7 @@ template <bool TS> wgs_status enqueue_substep(wgs_data *d, int ts_slot, int part
     do {                                    \
         if (d->cpic) {                      \
             WGS_LAUNCH_G2P(MODEL, PL, 1);   \
+            mark(6);                        \
             WGS_LAUNCH_G2P(MODEL, PL, 2);   \
         } else {                            \
             WGS_LAUNCH_G2P(MODEL, PL, 0);   \
@@ -482,12 +484,13 @@ template <bool TS> wgs_status enqueue_substep(wgs_data *d, int ts_slot, int part
 #undef WGS_LAUNCH_G2P_MP
 #undef WGS_LAUNCH_G2P
         }
-        mark(6);
+        if (!(d->cpic && dev.nv > 0)) mark(6);  // (collider simulations: recorded between the two G2P launches)
+        mark(7);
         // ---- "integrate_bodies" (rigid_impulses.wgsl:95-136) + the world mass properties of the next substep
         // (pipeline.rs:204-205). Skipped while no body has a velocity or a mass: it would be the identity.
         if (d->bodies_move && dev.n_colliders > 0)
             hipLaunchKernelGGL(k_bodies_integrate<D>, dim3(1), dim3(16), 0, s, dev);
-        mark(7);
+        mark(8);
         d->side ^= 1;
         d->substeps++;
         d->prev_sorted = true;

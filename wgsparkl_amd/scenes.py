@@ -72,6 +72,21 @@ def neo_hookean_cube(n_side=100, with_floor=False, jitter=0.05, cell_width=1.0, 
                 grid_capacity=grid_capacity, model=MODEL_NEO_HOOKEAN)
 
 
+def corotated_cube_with_paddle(n_side=200, jitter=0.05, cell_width=1.0, paddle_speed=0.8):
+    """C4 (single-GPU form): n_side^3 corotated elastic particles on the floor cuboid, hit by one kinematic rotating
+    cuboid (the `sand3.rs:95-103` pattern: a body whose angular velocity is set by the host and whose pose the
+    device integrates every substep)."""
+    sc = neo_hookean_cube(n_side=n_side, with_floor=True, jitter=jitter, cell_width=cell_width)
+    h = cell_width
+    sc["model"] = MODEL_COROTATED
+    side = n_side * h / 2.0
+    sc["particles"].pos[:, 1] -= 5.6 * h                       # resting on the floor (top face at y = 2 h)
+    centre = (20.0 * h + side + 2.2 * h, 2.4 * h + side / 2.0, 20.0 * h + side / 2.0)
+    sc["colliders"].append(Collider.cuboid((2.0 * h, side / 2.0, side / 3.0), centre, angvel=(0.0, paddle_speed, 0.0),
+                                           linvel=(-2.0, 0.0, 0.0)))
+    return sc
+
+
 def sand_column(nx=100, ny=400, nz=100, with_floor=False, jitter=0.05, grid_capacity=None):
     """C3: Drucker-Prager sand column (sand3.rs:45-46 material), corotated stress, phase None."""
     h = 1.0
