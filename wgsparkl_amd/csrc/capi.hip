@@ -144,6 +144,9 @@ struct Unpacked {
     float dp[6], st[3], phase[2];
 };
 
+// index into a 3x3 matrix; the 3D branch below is parsed (never run) in the 2D library too
+[[maybe_unused]] constexpr int m9(int k) { return DD == 9 ? k : 0; }
+
 template <int DIM> __device__ inline void unpack_slot(const float *in, uint32_t npad, uint32_t j, bool plastic, bool cpic_in, uint32_t cdf_epoch, Unpacked &u) {
     // cdf quads are valid only if stamped with the epoch of the last substep (0 = echo the input)
     const bool cpic = cpic_in && (cdf_epoch == 0u || ldstamp<DIM>(in, npad, j) == cdf_epoch);
@@ -154,10 +157,10 @@ template <int DIM> __device__ inline void unpack_slot(const float *in, uint32_t 
                      f2 = ldq(in, npad, P::F2, j);
         u.x[0] = xm.x; u.x[1] = xm.y; u.x[D - 1] = xm.z; u.mass = xm.w;
         u.C[0] = c0.x; u.C[1] = c0.y; u.C[2] = c0.z; u.C[3] = c0.w;
-        u.C[DD - 5] = c1.x; u.C[DD - 4] = c1.y; u.C[DD - 3] = c1.z; u.C[DD - 2] = c1.w; u.C[DD - 1] = c2.x;
+        u.C[m9(4)] = c1.x; u.C[m9(5)] = c1.y; u.C[m9(6)] = c1.z; u.C[m9(7)] = c1.w; u.C[m9(8)] = c2.x;
         u.v[0] = c2.y; u.v[1] = c2.z; u.v[D - 1] = c2.w;
         u.F[0] = f0.x; u.F[1] = f0.y; u.F[2] = f0.z; u.F[3] = f0.w;
-        u.F[DD - 5] = f1.x; u.F[DD - 4] = f1.y; u.F[DD - 3] = f1.z; u.F[DD - 2] = f1.w; u.F[DD - 1] = f2.x;
+        u.F[m9(4)] = f1.x; u.F[m9(5)] = f1.y; u.F[m9(6)] = f1.z; u.F[m9(7)] = f1.w; u.F[m9(8)] = f2.x;
         u.vol = f2.y; u.lam = f2.z; u.mu = f2.w;
     } else {
         const float4 xm = ldq(in, npad, P::XM, j), c0 = ldq(in, npad, P::CV0, j), vl = ldq(in, npad, P::CV2, j),
