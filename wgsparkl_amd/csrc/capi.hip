@@ -75,6 +75,8 @@ struct wgs_data {
     bool cpic = false;
     bool deterministic = true;
     bool prev_sorted = false;   // the current buffer is the sorted output of the previous substep (perm_cell, links valid)
+    bool tail_known = false;    // sharded: wgs_shard_add_migrants ran since the last substep (CTR_NPREV is current)
+    uint32_t tail_slots = 0;    // sharded: upper bound of the arrivals appended behind the residents
     uint64_t substeps = 0;
     uint64_t device_bytes = 0;
     uint32_t sticky_errors = 0;
@@ -402,7 +404,7 @@ template <bool TS> wgs_status enqueue_substep(wgs_data *d, int ts_slot, int part
     // block (k_rebin: no hash lookups except for the few particles that changed block). The full k_bin runs
     // on the first substep, on table-rebuild substeps and in sharded runs (particles arrive from neighbours).
     const bool rehash = d->substeps % REHASH_PERIOD == 0;
-    const bool use_rebin = d->prev_sorted && !rehash && !dev.sharded && !(dev.dbg & 128u);
+    const bool use_rebin = d->prev_sorted && !rehash && !(dev.dbg & 128u) && (!dev.sharded || d->tail_known);
     if (part != 2) {
         mark(0);
         // ---- "grid sort" (grid.rs:30-207)
@@ -415,8 +417,14 @@ template <bool TS> wgs_status enqueue_substep(wgs_data *d, int ts_slot, int part
         if (dev.n_rigid > 0)
             hipLaunchKernelGGL(k_rigid_transform<D>, dim3(grid_for(d, 1)), dim3(256), 0, s, dev);
         if (n > 0) {
-            if (use_rebin) hipLaunchKernelGGL(k_rebin<D>, dim3(pgrid), dim3(SORT_THREADS), 0, s, dev, side, epoch);
-            else hipLaunchKernelGGL(k_bin<D>, dim3(pgrid), dim3(SORT_THREADS), 0, s, dev, side, epoch);
+            if (use_rebin) {
+                hipLaunchKernelGGL(k_rebin<D>, dim3(pgrid), dim3(SORT_THREADS), 0, s, dev, side, epoch);
+                if (dev.sharded && d->tail_slots > 0)  // the particles that arrived from the neighbours
+                    hipLaunchKernelGGL(k_bin<D>, dim3((d->tail_slots + SORT_THREADS - 1) / SORT_THREADS), dim3(SORT_THREADS), 0, s,
+                                       dev, side, epoch, 1);
+            } else {
+                hipLaunchKernelGGL(k_bin<D>, dim3(pgrid), dim3(SORT_THREADS), 0, s, dev, side, epoch, 0);
+            }
             if (dev.n_rigid > 0) {  // blocks a mesh sample reaches must exist (sort.wgsl:38-86)
                 hipLaunchKernelGGL(k_rigid_mark<D>, dim3(grid_for(d, 1)), dim3(256), 0, s, dev, epoch);
                 hipLaunchKernelGGL(k_rigid_touch<D>, dim3(grid_for(d, 1)), dim3(256), 0, s, dev, epoch);
@@ -497,6 +505,7 @@ template <bool TS> wgs_status enqueue_substep(wgs_data *d, int ts_slot, int part
         d->side ^= 1;
         d->substeps++;
         d->prev_sorted = true;
+        d->tail_known = false;
         dev.n = dev.nv;  // the buffer just written holds the valid particles only, in sorted order
     }
     HIP_TRY(hipGetLastError());
@@ -803,6 +812,8 @@ wgs_status wgs_shard_add_migrants(wgs_data *d, const void *in_lo, const void *in
                                   uint32_t capacity_records) {
     if (!d) return fail(WGS_ERR_INVALID_ARGUMENT, "NULL argument");
     HIP_TRY(hipSetDevice(d->pipeline->device));
+    d->tail_known = true;
+    d->tail_slots = (in_lo ? capacity_records : 0u) + (in_hi ? capacity_records : 0u);
     if (in_lo || in_hi)
         hipLaunchKernelGGL(k_append_migrants<D>, dim3((2 * capacity_records + 255) / 256), dim3(256), 0, d->stream, d->dev,
                            d->side, static_cast<const float *>(in_lo), static_cast<const float *>(in_hi), capacity_records);

@@ -155,6 +155,7 @@ __global__ void k_shard_counts(Dev d, const float *in_lo, const float *in_hi, co
     auto cnt = [&](const float *b) { return b ? min(reinterpret_cast<const uint32_t *>(b)[0], cap) : 0u; };
     const uint32_t nv = d.counters[CTR_NV];
     const uint32_t arrivals = min(cnt(in_lo) + cnt(in_hi), d.n - nv);
+    d.counters[CTR_NPREV] = nv;  // [0, nv): the sorted output of the last substep (some slots vacated)
     d.counters[CTR_N] = nv + arrivals;
     d.counters[CTR_NV] = nv - cnt(out_lo) - cnt(out_hi) + arrivals;
 }

@@ -64,7 +64,9 @@ __device__ inline void count_cells(const Dev &d, uint32_t *hist, int lane, uint3
 }
 
 // sort.wgsl:26-36 touch_particle_blocks + sort.wgsl:89-99 update_block_particle_count, fused.
-template <int D> __global__ __launch_bounds__(SORT_THREADS) void k_bin(Dev d, int side, uint32_t epoch) {
+// `tail`: sharded steady state — only the particles that arrived from the neighbours, slots [NPREV, N); the
+// residents go through k_rebin.
+template <int D> __global__ __launch_bounds__(SORT_THREADS) void k_bin(Dev d, int side, uint32_t epoch, int tail) {
     constexpr int BS = Dim<D>::BSHIFT, BW = Dim<D>::BW, NN = Dim<D>::NNBR;
     __shared__ uint32_t s_keys[TOUCH_SET], s_ids[TOUCH_SET];
     __shared__ uint32_t s_hist[SORT_THREADS / 64][NPB];
@@ -72,7 +74,7 @@ template <int D> __global__ __launch_bounds__(SORT_THREADS) void k_bin(Dev d, in
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (tid < TOUCH_SET) s_keys[tid] = NONE;
     __syncthreads();
-    const uint32_t i = blockIdx.x * SORT_THREADS + tid;
+    const uint32_t i = (tail ? d.counters[CTR_NPREV] : 0u) + blockIdx.x * SORT_THREADS + tid;
     bool valid = i < num_slots(d);
     if (d.sharded && valid) valid = ldpid<D>(in, d.npad, i) != 0xffffffffu;  // slot vacated by a migrated particle
     int b[3] = {0, 0, 0};
@@ -160,7 +162,11 @@ template <int D> __global__ __launch_bounds__(SORT_THREADS) void k_rebin(Dev d, 
     const float *in = d.buf[side];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t i = blockIdx.x * SORT_THREADS + tid;
-    const bool valid = i < num_slots(d);
+    // sharded runs: the residents only (arrivals have no previous cell: k_bin's tail pass), minus the slots
+    // vacated by particles that migrated away
+    const bool in_range = i < (d.sharded ? min(d.counters[CTR_NPREV], d.counters[CTR_N]) : num_slots(d));
+    bool valid = in_range;
+    if (d.sharded && valid) valid = ldpid<D>(in, d.npad, i) != 0xffffffffu;
     uint32_t myid = NONE, local = 0;
     if (valid) {
         const uint32_t old = d.perm_cell[i];  // NONE only after a grid overflow: take the hash path then
@@ -207,7 +213,7 @@ template <int D> __global__ __launch_bounds__(SORT_THREADS) void k_rebin(Dev d, 
     }
     uint32_t cid = NONE, rank = 0;
     count_cells(d, s_hist[wave], lane, myid, local, cid, rank);
-    if (valid) {
+    if (in_range) {  // (a vacated slot gets NONE: k_scatter skips it)
         d.cellid[i] = cid;
         d.rank[i] = rank;
     }

@@ -96,7 +96,9 @@ struct NodeCdf {        // grid.wgsl:233-240
 };
 
 // Counter slots in Dev::counters
-enum { CTR_NBLOCKS = 0, CTR_ERRORS = 1, CTR_NPHYS = 2, CTR_NCPIC = 3, CTR_N = 4, CTR_NV = 5, CTR_COUNT = 8 };
+enum { CTR_NBLOCKS = 0, CTR_ERRORS = 1, CTR_NPHYS = 2, CTR_NCPIC = 3, CTR_N = 4, CTR_NV = 5,
+       CTR_NPREV = 6,  // sharded runs: slots [0, NPREV) are the sorted output of the last substep, [NPREV, N) arrivals
+       CTR_COUNT = 8 };
 enum { ERRBIT_OVERFLOW = 1u, ERRBIT_KEYRANGE = 2u, ERRBIT_SHARD = 4u };
 
 // Everything a kernel needs, passed by value.
