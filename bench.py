@@ -91,7 +91,7 @@ def main():
     else:
         # Weak scaling: `world` C2 cubes side by side along x form one elastic bar; x-slab domain
         # decomposition, one slab per GPU, halo + migration exchanges over RCCL point-to-point (sharded.py).
-        from wgsparkl_amd.sharded import FixedExchange, GpuShard, substep_phases
+        from wgsparkl_amd.sharded import FixedExchange, GpuShard, finish_migration, pipelined_substep
         scene = scenes.neo_hookean_bar(n_side=args.n_side, world=world, rank=rank)
         if args.no_floor:
             scene["colliders"] = []
@@ -106,8 +106,10 @@ def main():
         exch = FixedExchange(dist, rank, world)
 
         def run(k):
+            pending = None       # the migration of a substep stays in flight while the next one re-bins its residents
             for _ in range(k):
-                substep_phases(data, exch)
+                pending = pipelined_substep(data, exch, pending)
+            finish_migration(data, pending)
         sync = data.sync
         parallelism = f"{world} x-slabs, halo + migration over RCCL p2p"
 

@@ -286,6 +286,10 @@ wgs_status wgs_set_stream(wgs_data *data, void *hip_stream);
 /* All of the following are ASYNCHRONOUS (stream-ordered) and fixed-capacity: buffers are device memory of
  * header + capacity_records * record bytes; the record count travels in the header. Overflowing a buffer or
  * the particle capacity is reported by the next wgs_sync(). */
+/* Optional, before wgs_shard_add_migrants of the previous substep's migration: re-bins the particles that stayed,
+ * so that this pass overlaps the migration messages still in flight; wgs_shard_step_begin then bins the arrivals
+ * only. A no-op on the substeps that need the full pass. */
+wgs_status wgs_shard_bin_residents(wgs_pipeline *pipeline, wgs_data *data);
 /* sort, CDF, P2G, gather of the partial node sums */
 wgs_status wgs_shard_step_begin(wgs_pipeline *pipeline, wgs_data *data);
 /* partial sums of the active blocks of layer `layer_bx` (= this rank's block_hi, or its block_lo) */

@@ -31,6 +31,9 @@ class OracleShard:
         self.st = self.orc.new_state(ps, sc["params"], sc["colliders"], sc["cell_width"], sc["grid_capacity"], sc.get("model", 0))
 
     # ---- protocol
+    def bin_residents(self):
+        """(an optimisation hook of the GPU backend: nothing to pre-compute for the CPU oracle)"""
+
     def step_begin(self):
         st = self.st
         st.sort(); st.grid_update_cdf(); st.g2p_cdf(); st.p2g()

@@ -23,10 +23,11 @@ def test_partition_helpers():
     assert counts.min() >= 200 and counts.sum() == 1000
 
 
-@pytest.mark.parametrize("dim,k", [(3, 20), (2, 20)])
-def test_gloo_world2_matches_single_domain(oracle_libs, tmp_path, dim, k):
+@pytest.mark.parametrize("dim,k,pipelined", [(3, 20, False), (2, 20, False), (3, 20, True)])
+def test_gloo_world2_matches_single_domain(oracle_libs, tmp_path, dim, k, pipelined):
     out = str(tmp_path / "shard")
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29611 + dim), WORLD_SIZE="2", OMP_NUM_THREADS="1")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29611 + dim + (7 if pipelined else 0)), WORLD_SIZE="2",
+               OMP_NUM_THREADS="1", WGS_PIPELINED="1" if pipelined else "0")
     procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "shard_gloo_worker.py"), str(dim), str(k), out],
                               env=dict(env, RANK=str(r)), stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
              for r in range(2)]

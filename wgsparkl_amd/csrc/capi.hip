@@ -77,6 +77,7 @@ struct wgs_data {
     bool prev_sorted = false;   // the current buffer is the sorted output of the previous substep (perm_cell, links valid)
     bool tail_known = false;    // sharded: wgs_shard_add_migrants ran since the last substep (CTR_NPREV is current)
     uint32_t tail_slots = 0;    // sharded: upper bound of the arrivals appended behind the residents
+    bool residents_binned = false;  // sharded: wgs_shard_bin_residents already ran k_rebin for the coming substep
     uint64_t substeps = 0;
     uint64_t device_bytes = 0;
     uint32_t sticky_errors = 0;
@@ -404,7 +405,18 @@ template <bool TS> wgs_status enqueue_substep(wgs_data *d, int ts_slot, int part
     // block (k_rebin: no hash lookups except for the few particles that changed block). The full k_bin runs
     // on the first substep, on table-rebuild substeps and in sharded runs (particles arrive from neighbours).
     const bool rehash = d->substeps % REHASH_PERIOD == 0;
-    const bool use_rebin = d->prev_sorted && !rehash && !(dev.dbg & 128u) && (!dev.sharded || d->tail_known);
+    const bool use_rebin = d->prev_sorted && !rehash && !(dev.dbg & 128u) && (!dev.sharded || d->tail_known || part == 3);
+    if (part == 3) {
+        // Sharded runs, optional: re-bin the residents while the particle migration is still in flight (it only
+        // needs the buffer the last G2P wrote). Part 1 then bins just the arrivals. Nothing to do on the substeps
+        // that rebuild the table or follow no sorted substep: part 1 runs the full pass then.
+        if (use_rebin && n > 0 && !d->residents_binned) {
+            hipLaunchKernelGGL(k_rebin<D>, dim3(pgrid), dim3(SORT_THREADS), 0, s, dev, side, epoch);
+            d->residents_binned = true;
+        }
+        HIP_TRY(hipGetLastError());
+        return WGS_OK;
+    }
     if (part != 2) {
         mark(0);
         // ---- "grid sort" (grid.rs:30-207)
@@ -418,7 +430,7 @@ template <bool TS> wgs_status enqueue_substep(wgs_data *d, int ts_slot, int part
             hipLaunchKernelGGL(k_rigid_transform<D>, dim3(grid_for(d, 1)), dim3(256), 0, s, dev);
         if (n > 0) {
             if (use_rebin) {
-                hipLaunchKernelGGL(k_rebin<D>, dim3(pgrid), dim3(SORT_THREADS), 0, s, dev, side, epoch);
+                if (!d->residents_binned) hipLaunchKernelGGL(k_rebin<D>, dim3(pgrid), dim3(SORT_THREADS), 0, s, dev, side, epoch);
                 if (dev.sharded && d->tail_slots > 0)  // the particles that arrived from the neighbours
                     hipLaunchKernelGGL(k_bin<D>, dim3((d->tail_slots + SORT_THREADS - 1) / SORT_THREADS), dim3(SORT_THREADS), 0, s,
                                        dev, side, epoch, 1);
@@ -506,6 +518,7 @@ template <bool TS> wgs_status enqueue_substep(wgs_data *d, int ts_slot, int part
         d->substeps++;
         d->prev_sorted = true;
         d->tail_known = false;
+        d->residents_binned = false;
         dev.n = dev.nv;  // the buffer just written holds the valid particles only, in sorted order
     }
     HIP_TRY(hipGetLastError());
@@ -764,6 +777,13 @@ wgs_status wgs_shard_step_begin(wgs_pipeline *pipeline, wgs_data *d) {
     if (!d->dev.sharded) return fail(WGS_ERR_INVALID_ARGUMENT, "not a sharded wgs_data");
     HIP_TRY(hipSetDevice(pipeline->device));
     return enqueue_substep<false>(d, 0, 1);
+}
+
+wgs_status wgs_shard_bin_residents(wgs_pipeline *pipeline, wgs_data *d) {
+    if (!pipeline || !d) return fail(WGS_ERR_INVALID_ARGUMENT, "NULL argument");
+    if (!d->dev.sharded) return fail(WGS_ERR_INVALID_ARGUMENT, "not a sharded wgs_data");
+    HIP_TRY(hipSetDevice(pipeline->device));
+    return enqueue_substep<false>(d, 0, 3);
 }
 
 wgs_status wgs_shard_step_end(wgs_pipeline *pipeline, wgs_data *d) {

@@ -162,7 +162,10 @@ __global__ void k_shard_counts(Dev d, const float *in_lo, const float *in_hi, co
 
 // After the fused G2P kernel the other buffer holds exactly the valid particles, in sorted order.
 __global__ void k_shard_compacted(Dev d) {
-    if (threadIdx.x == 0 && blockIdx.x == 0) d.counters[CTR_N] = d.counters[CTR_NV];
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        d.counters[CTR_N] = d.counters[CTR_NV];
+        d.counters[CTR_NPREV] = d.counters[CTR_NV];  // residents of the next substep (arrivals are appended behind)
+    }
 }
 
 }  // namespace wgs

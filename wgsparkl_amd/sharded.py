@@ -91,6 +91,32 @@ def substep_phases(backend, exchange):
     backend.add_migrants(in_lower, in_upper)
 
 
+def pipelined_substep(backend, exchange, pending):
+    """`substep_phases` with the particle migration of the PREVIOUS substep still in flight while the residents
+    are re-binned (`pending` = what the previous call returned, None at the start). Returns the handle of this
+    substep's migration; `finish_migration` must absorb the last one before the state is read."""
+    lo, hi = backend.block_lo, backend.block_hi
+    backend.bin_residents()                       # overlaps the messages in flight
+    if pending is not None:
+        finish_migration(backend, pending)
+    backend.step_begin()
+    to_lower = backend.pack_halo(lo) if backend.has_lower else None
+    to_upper = backend.pack_halo(hi) if backend.has_upper else None
+    from_lower, from_upper = exchange(to_lower, to_upper)
+    if from_lower is not None:
+        backend.add_halo(from_lower)
+    if from_upper is not None:
+        backend.add_halo(from_upper)
+    backend.step_end()
+    out_lower, out_upper = backend.pack_migrants()
+    return exchange.start(out_lower if backend.has_lower else None, out_upper if backend.has_upper else None)
+
+
+def finish_migration(backend, pending):
+    in_lower, in_upper = pending.finish()
+    backend.add_migrants(in_lower, in_upper)
+
+
 def lockstep_substep(backends: List):
     """All ranks inside ONE process (tests, single-GPU emulation of the decomposition): runs the
     phases of every rank in lockstep and routes the messages directly."""
@@ -109,6 +135,46 @@ def lockstep_substep(backends: List):
     mig = [b.pack_migrants() for b in backends]
     for r, b in enumerate(backends):
         b.add_migrants(mig[r - 1][1] if r > 0 else None, mig[r + 1][0] if r < n - 1 else None)
+
+
+def lockstep_pipelined_substep(backends: List, pending):
+    """`lockstep_substep` in the order of `pipelined_substep`: residents re-binned before the previous substep's
+    migrants are absorbed. `pending` = the return value of the previous call (None at the start); finish a run
+    with `lockstep_finish(backends, pending)`."""
+    n = len(backends)
+    for b in backends:
+        b.bin_residents()
+    if pending is not None:
+        lockstep_finish(backends, pending)
+    for b in backends:
+        b.step_begin()
+    up = [b.pack_halo(b.block_hi) if b.has_upper else None for b in backends]
+    down = [b.pack_halo(b.block_lo) if b.has_lower else None for b in backends]
+    for r, b in enumerate(backends):
+        if r > 0:
+            b.add_halo(up[r - 1])
+        if r < n - 1:
+            b.add_halo(down[r + 1])
+    for b in backends:
+        b.step_end()
+    mig = [b.pack_migrants() for b in backends]
+    return [(mig[r - 1][1] if r > 0 else None, mig[r + 1][0] if r < n - 1 else None) for r in range(n)]
+
+
+def lockstep_finish(backends: List, pending):
+    for b, (in_lower, in_upper) in zip(backends, pending):
+        b.add_migrants(in_lower, in_upper)
+
+
+class _PendingExchange:
+    def __init__(self, works, from_lower, from_upper):
+        self.works, self.from_lower, self.from_upper = works, from_lower, from_upper
+
+    def finish(self):
+        for w in self.works:
+            w.wait()
+        self.works = []
+        return self.from_lower, self.from_upper
 
 
 class FixedExchange:
@@ -149,11 +215,14 @@ class FixedExchange:
         return sets[turn]
 
     def __call__(self, to_lower, to_upper):
+        return self.start(to_lower, to_upper).finish()
+
+    def start(self, to_lower, to_upper):
+        """Issue the sends / receives and return at once; `.finish()` makes the current stream wait for them
+        (it does not block the host with NCCL/RCCL) and hands out the received buffers."""
         ops, from_lower, from_upper = self._plan(to_lower, to_upper)
-        if ops:
-            for w in self.dist.batch_isend_irecv(ops):
-                w.wait()     # stream-level wait on NCCL/RCCL (does not block the host)
-        return from_lower, from_upper
+        works = self.dist.batch_isend_irecv(ops) if ops else []
+        return _PendingExchange(works, from_lower, from_upper)
 
 
 class DistExchange:
@@ -164,6 +233,10 @@ class DistExchange:
         import torch
         self.torch, self.dist, self.rank, self.world, self.device = torch, dist, rank, world, device
         self.dtype = dtype or torch.float32
+
+    def start(self, to_lower, to_upper):
+        """Same interface as FixedExchange.start; this transport needs a size handshake, so it completes here."""
+        return _PendingExchange([], *self(to_lower, to_upper))
 
     def __call__(self, to_lower, to_upper):
         torch, dist = self.torch, self.dist
@@ -251,6 +324,9 @@ class GpuShard:
         _ffi.check(self.lib, self.lib.wgs_set_stream(self._h, C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)))
 
     # -- protocol (all asynchronous)
+    def bin_residents(self):
+        _ffi.check(self.lib, self.lib.wgs_shard_bin_residents(self.pipeline._h, self._h))
+
     def step_begin(self):
         self._keep = self._keep[-8:]
         _ffi.check(self.lib, self.lib.wgs_shard_step_begin(self.pipeline._h, self._h))
