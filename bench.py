@@ -102,7 +102,9 @@ def main():
         data = GpuShard(pipe, scene["params"], ps, scene["global_ids"], scene["colliders"], scene["cell_width"],
                         scene["grid_capacity"], lo, hi, rank > 0, rank < world - 1,
                         particle_capacity=int(n * 1.25) + 4096, model=scene["model"],
-                        halo_capacity_blocks=2048, migrant_capacity=4096)
+                        # message capacities from the face area: (n_side / 8 + 3)^2 interface blocks, x2 margin;
+                        # a few hundred particles cross a face per substep at these velocities
+                        halo_capacity_blocks=max(256, 2 * (args.n_side // 8 + 3) ** 2), migrant_capacity=2048)
         exch = FixedExchange(dist, rank, world)
 
         def run(k):
