@@ -261,6 +261,10 @@ wgs_status wgs_read_blocks(wgs_data *data, wgs_block_record *out, size_t capacit
 /* GpuTimestamps read-back (src_testbed/step.rs:219-251): ms per pass summed over the substeps of the
  * last wgs_step(.., timestamps=1) call. */
 wgs_status wgs_read_timings(wgs_data *data, float ms[WGS_NUM_PASSES]);
+/* The cost of one timing mark (a HIP event is a barrier packet of its own): the average distance of two marks
+ * recorded back to back in the same timestamped substeps. Every pass time of wgs_read_timings includes one; a pass
+ * with K launches between its marks took (time - overhead) of kernel time. */
+wgs_status wgs_read_timing_overhead(wgs_data *data, float *ms_per_mark);
 wgs_status wgs_get_stats(wgs_data *data, wgs_stats *out);
 
 /* ---------------------------------------------------------------------------------------------

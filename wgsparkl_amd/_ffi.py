@@ -18,7 +18,7 @@ PASS_NAMES = ("update rigid particles", "grid sort", "grid_update_cdf", "p2g_cdf
 EXPORTS = (
     "wgs_last_error", "wgs_dim", "wgs_pipeline_create", "wgs_pipeline_destroy", "wgs_data_create",
     "wgs_data_destroy", "wgs_set_constitutive_model", "wgs_step", "wgs_sync", "wgs_set_sim_params",
-    "wgs_set_collider_poses", "wgs_set_body_velocities", "wgs_set_body_mass_properties", "wgs_read_body_poses", "wgs_set_plastic_state", "wgs_set_rigid_particles", "wgs_prep_vertex_buffer", "wgs_prep_vertex_buffer_device", "wgs_read_positions", "wgs_read_particles",
+    "wgs_set_collider_poses", "wgs_set_body_velocities", "wgs_set_body_mass_properties", "wgs_read_body_poses", "wgs_set_plastic_state", "wgs_read_timing_overhead", "wgs_set_rigid_particles", "wgs_prep_vertex_buffer", "wgs_prep_vertex_buffer_device", "wgs_read_positions", "wgs_read_particles",
     "wgs_read_grid", "wgs_read_blocks", "wgs_read_timings", "wgs_get_stats",
     # multi-GPU (x-slab decomposition; new design, no reference counterpart)
     "wgs_data_create_sharded", "wgs_shard_halo_record_bytes", "wgs_shard_particle_record_bytes",
@@ -154,6 +154,7 @@ def load(dim: int):
     lib.wgs_read_blocks.argtypes = [vp, C.POINTER(T.BlockRecord), C.c_size_t, C.POINTER(C.c_size_t),
                                     C.POINTER(C.c_uint32)]
     lib.wgs_read_timings.argtypes = [vp, C.POINTER(C.c_float)]
+    lib.wgs_read_timing_overhead.argtypes = [vp, C.POINTER(C.c_float)]
     lib.wgs_get_stats.argtypes = [vp, C.POINTER(T.Stats)]
     u32p = C.POINTER(C.c_uint32)
     lib.wgs_data_create_sharded.argtypes = [vp, C.POINTER(T.SimParams), C.POINTER(T.Particle), C.c_size_t, u32p,

@@ -51,7 +51,8 @@ wgs_status fail(wgs_status code, const std::string &msg) {
 
 struct Events {
     static constexpr int MAX_SUBSTEPS = 64;
-    static constexpr int MARKS = 9;  // boundaries: start, sort, cdf_nodes, cdf_particles, p2g, grid, g2p, g2p near colliders, bodies(end)
+    static constexpr int MARKS = 11;  // + 2 calibration marks (9, 10) recorded back to back: the cost of a mark itself
+    static constexpr int PASS_MARKS = 9;  // boundaries: start, sort, cdf_nodes, cdf_particles, p2g, grid, g2p, g2p near colliders, bodies(end)
     hipEvent_t ev[MAX_SUBSTEPS][MARKS];
     int used = 0;
     bool created = false;
@@ -99,6 +100,7 @@ struct wgs_data {
     SimParamsDev host_sp{};
     Events events;
     float timings[WGS_NUM_PASSES] = {0};
+    float mark_overhead_ms = 0.f;   // average distance of two adjacent timing marks in the last timestamped step
     bool timings_pending = false;
 };
 
@@ -377,6 +379,12 @@ void resolve_timings(wgs_data *d) {
     //        6 after the fused g2p launch | 7 after its near-collider launch | 8 after integrate_bodies
     const int pass_of_mark[8] = {WGS_PASS_GRID_SORT,   WGS_PASS_GRID_UPDATE_CDF, WGS_PASS_G2P_CDF,          WGS_PASS_P2G,
                                  WGS_PASS_GRID_UPDATE, WGS_PASS_G2P,             WGS_PASS_PARTICLES_UPDATE, WGS_PASS_INTEGRATE_BODIES};
+    d->mark_overhead_ms = 0.f;
+    for (int s = 0; s < d->events.used; s++) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, d->events.ev[s][9], d->events.ev[s][10]) == hipSuccess) d->mark_overhead_ms += ms;
+    }
+    if (d->events.used > 0) d->mark_overhead_ms /= (float)d->events.used;
     for (int s = 0; s < d->events.used; s++)
         for (int m = 0; m < 8; m++) {
             if (m == 6 && !d->cpic) continue;  // no second G2P launch: the two marks are adjacent
@@ -418,6 +426,10 @@ template <bool TS> wgs_status enqueue_substep(wgs_data *d, int ts_slot, int part
         return WGS_OK;
     }
     if (part != 2) {
+        if (TS) {  // two adjacent marks: their distance is what every interval below pays for its closing mark
+            mark(9);
+            mark(10);
+        }
         mark(0);
         // ---- "grid sort" (grid.rs:30-207)
         if (rehash) {  // reset_hmap, amortised (device_math.h)
@@ -880,7 +892,7 @@ wgs_status wgs_step(wgs_pipeline *pipeline, wgs_data *d, uint32_t num_substeps, 
     if (timestamps) {
         if (!d->events.created) {
             for (int s = 0; s < Events::MAX_SUBSTEPS; s++)
-                for (int m = 0; m < Events::MARKS; m++) HIP_TRY(hipEventCreate(&d->events.ev[s][m]));
+                for (int m = 0; m < Events::MARKS; m++) HIP_TRY(hipEventCreateWithFlags(&d->events.ev[s][m], hipEventDisableSystemFence));  // timing only: no cache writeback per mark
             d->events.created = true;
         }
         d->events.used = 0;
@@ -1207,6 +1219,14 @@ wgs_status wgs_read_blocks(wgs_data *d, wgs_block_record *out, size_t capacity, 
         HIP_TRY(hipMemcpyAsync(sorted_ids, pidp, sizeof(uint32_t) * (size_t)d->dev.n, hipMemcpyDeviceToHost, d->stream));
         HIP_TRY(hipStreamSynchronize(d->stream));
     }
+    return WGS_OK;
+}
+
+wgs_status wgs_read_timing_overhead(wgs_data *d, float *ms_per_mark) {
+    if (!d || !ms_per_mark) return fail(WGS_ERR_INVALID_ARGUMENT, "NULL argument");
+    HIP_TRY(hipSetDevice(d->pipeline->device));
+    resolve_timings(d);
+    *ms_per_mark = d->mark_overhead_ms;
     return WGS_OK;
 }
 
