@@ -284,6 +284,50 @@ def test_prep_vertex_buffer_modes(hip_libs, name):
         data.prep_vertex_buffer(17, base)
 
 
+def test_c_abi_rejects_bad_arguments(hip_libs):
+    """Error behaviour of the boundary: every entry point returns a status, nothing throws or aborts, and
+    wgs_last_error explains."""
+    import ctypes as C
+    from golden_cases import mesh_floor3d
+    from helpers import pipeline
+    from wgsparkl_amd import MpmData
+    from wgsparkl_amd.sampling import build_rigid_particles
+    sc = mesh_floor3d()
+    pipe = pipeline(3)
+    data = MpmData.new(pipe, sc["params"], sc["particles"], sc["colliders"], sc["cell_width"], sc["grid_capacity"], sc["model"])
+    lib, T, h = data.lib, data.T, data._h
+    assert lib.wgs_step(None, h, 1, 0) != 0 and lib.wgs_step(pipe._h, None, 1, 0) != 0
+    assert lib.wgs_set_sim_params(h, None) != 0
+    poses = (T.Pose * 3)()
+    assert lib.wgs_set_collider_poses(h, poses, None, 3) != 0            # more poses than colliders
+    assert lib.wgs_set_body_velocities(h, None, 1) != 0
+    assert lib.wgs_set_body_mass_properties(h, None, 2) != 0
+    assert lib.wgs_read_body_poses(h, poses, None, None, 3) != 0
+    assert lib.wgs_prep_vertex_buffer(h, 99, C.c_void_p(1)) != 0
+    assert lib.wgs_set_plastic_state(h, None) != 0
+    # rigid particles: ids must refer to existing vertices / colliders; a valid re-upload replaces the old buffers
+    rb = build_rigid_particles(sc["colliders"], 3, sc["cell_width"])
+    bad = dict(rb, ids=rb["ids"].copy())
+    bad["ids"][0, 0] = len(rb["local_vtx"]) + 5
+    with pytest.raises(Exception):
+        data.set_rigid_particles(bad)
+    bad = dict(rb, ids=rb["ids"].copy())
+    bad["ids"][0, 3] = 7
+    with pytest.raises(Exception):
+        data.set_rigid_particles(bad)
+    data.set_rigid_particles(rb)
+    before = data.stats()["device_bytes"]
+    for _ in range(3):
+        data.set_rigid_particles(rb)
+    assert data.stats()["device_bytes"] == before                        # no growth: the old buffers are released
+    pipe.step(data, 5)
+    data.sync()
+    assert np.isfinite(data.read_positions()).all()
+    many = [Collider.ball(1.0, (0.0, 0.0, 0.0))] * 17                    # the CPIC mask has 16 bits
+    with pytest.raises(Exception):
+        MpmData.new(pipe, sc["params"], sc["particles"], many, sc["cell_width"], sc["grid_capacity"], sc["model"])
+
+
 def test_checkpoint_restart_is_bit_exact(hip_libs):
     """read_particles (+ plastic state, + body poses) -> MpmData.new -> set_plastic_state continues the
     run bit-for-bit (every reduction is in canonical particle order, whatever the storage order)."""

@@ -9,6 +9,7 @@
 // enqueues; nothing on the step path synchronises with the host.
 #include "../../include/wgsparkl_hip.h"
 
+#include <algorithm>
 #include <cfloat>
 #include <cmath>
 #include <climits>
@@ -86,6 +87,7 @@ struct wgs_data {
     uint32_t capacity = 0;      // particle slots allocated
     uint32_t *shard_counts = nullptr;  // device scratch for pack kernels
     std::vector<void *> allocs;
+    std::vector<size_t> alloc_bytes;  // parallel to allocs
     // by-pid static tables (never reordered)
     float *static_radius = nullptr;
     float *static_dp = nullptr;     // n*6
@@ -112,6 +114,7 @@ template <typename T> wgs_status dev_alloc(wgs_data *d, T **out, size_t count, b
     HIP_TRY(hipMalloc(&p, bytes));
     if (zero) HIP_TRY(hipMemsetAsync(p, 0, bytes, d->stream));
     d->allocs.push_back(p);
+    d->alloc_bytes.push_back(bytes);
     d->device_bytes += bytes;
     *out = static_cast<T *>(p);
     return WGS_OK;
@@ -1024,7 +1027,24 @@ wgs_status wgs_set_rigid_particles(wgs_data *d, const float *local_points, const
     HIP_TRY(hipSetDevice(d->pipeline->device));
     HIP_TRY(hipStreamSynchronize(d->stream));
     Dev &dev = d->dev;
-    dev.n_rigid = 0;  // (buffers of an earlier call stay owned by the data and are released with it)
+    dev.n_rigid = 0;
+    // buffers of an earlier call are released (the mesh accumulators, sized by the grid capacity, are kept)
+    float *old_f[4] = {dev.rp_local, dev.rp_world, dev.rv_local, dev.rv_world};
+    void *old[7] = {old_f[0], old_f[1], old_f[2], old_f[3], dev.rp_ids, dev.rv_collider, dev.rp_needs};
+    for (void *p : old) {
+        if (!p) continue;
+        for (size_t i = 0; i < d->allocs.size(); i++)
+            if (d->allocs[i] == p) {
+                d->device_bytes -= d->alloc_bytes[i];
+                d->allocs.erase(d->allocs.begin() + (long)i);
+                d->alloc_bytes.erase(d->alloc_bytes.begin() + (long)i);
+                break;
+            }
+        hipFree(p);
+    }
+    dev.rp_local = dev.rp_world = dev.rv_local = dev.rv_world = nullptr;
+    dev.rp_ids = nullptr;
+    dev.rv_collider = dev.rp_needs = nullptr;
     if (n == 0) return WGS_OK;
     wgs_status st;
 #define RP_ALLOC(ptr, count) \
@@ -1142,6 +1162,7 @@ wgs_status wgs_prep_vertex_buffer_device(wgs_data *d, uint32_t mode, wgs_instanc
 
 wgs_status wgs_prep_vertex_buffer(wgs_data *d, uint32_t mode, wgs_instance *instances) {
     if (!d || !instances) return fail(WGS_ERR_INVALID_ARGUMENT, "NULL argument");
+    if (mode > WGS_RENDER_CDF_SIGNS) return fail(WGS_ERR_INVALID_ARGUMENT, "unknown render mode");
     HIP_TRY(hipSetDevice(d->pipeline->device));
     const size_t bytes = sizeof(wgs_instance) * (size_t)d->dev.n;
     if (bytes == 0) return WGS_OK;
