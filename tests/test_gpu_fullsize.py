@@ -95,6 +95,35 @@ def test_c4_eight_million_corotated_with_kinematic_paddle(hip_libs):
     assert body["translation"][0] < sc["colliders"][1].translation[0]
 
 
+def test_bench_slabs_at_full_size_fit_their_exchange_buffers(hip_libs):
+    """bench.py's N > 1 workload at its real size per rank (1M particles, two neighbouring slabs of the bar on one
+    GPU): the halo / migration buffers sized from the face area do not overflow and nobody is lost."""
+    from helpers import pipeline
+    from wgsparkl_amd.sharded import GpuShard, lockstep_finish, lockstep_pipelined_substep
+    world, n_side, k = 2, 100, 20
+    pipe = pipeline(3)
+    shards, total = [], 0
+    for rank in range(world):
+        sc = scenes.neo_hookean_bar(n_side=n_side, world=world, rank=rank)
+        ps = sc["particles"]
+        ps.vel[:, 0] = (2.0 * np.sin(0.37 * sc["global_ids"].astype(np.float64))).astype(np.float32)
+        total += ps.n
+        lo, hi = sc["partition"].block_range(rank)
+        shards.append(GpuShard(pipe, sc["params"], ps, sc["global_ids"], sc["colliders"], sc["cell_width"],
+                               sc["grid_capacity"], lo, hi, rank > 0, rank < world - 1,
+                               particle_capacity=int(ps.n * 1.25) + 4096, model=sc["model"],
+                               halo_capacity_blocks=max(256, 2 * (n_side // 8 + 3) ** 2), migrant_capacity=2048))
+    assert total == 2_000_000
+    pending = None
+    for _ in range(k):
+        pending = lockstep_pipelined_substep(shards, pending)
+    lockstep_finish(shards, pending)
+    for s in shards:
+        s.sync()                                       # raises on a halo / migration / capacity overflow
+    n_now = [s.num_particles() for s in shards]
+    assert sum(n_now) == total and n_now != [1_000_000, 1_000_000]
+
+
 def test_bit_identical_reruns_at_scale(hip_libs):
     sc = scenes.neo_hookean_cube(n_side=64)
     rng = np.random.default_rng(2)

@@ -176,6 +176,50 @@ def test_sharded_pipelined_protocol_matches_single_domain(hip_libs):
         assert rel_rms(got, getattr(ref, f)) < 1e-5, f
 
 
+def test_bench_decomposition_eight_ranks_on_one_gpu(hip_libs):
+    """The N = 8 workload of bench.py (one elastic bar cut into 8 x-slabs, every rank generating only its own slab,
+    the floor collider, bench.py's buffer capacities) advanced in lockstep on one GPU in the pipelined order: same
+    particles as the single-domain run of the whole bar, none lost."""
+    from helpers import pipeline
+    from wgsparkl_amd import MpmData
+    from wgsparkl_amd.sharded import GpuShard, lockstep_finish, lockstep_pipelined_substep
+    world, n_side, k = 8, 24, 40
+    pipe = pipeline(3)
+    full = scenes.neo_hookean_bar(n_side=n_side, world=world, rank=None)
+    vx = lambda gid: (3.0 * np.sin(0.37 * gid.astype(np.float64))).astype(np.float32)   # particles cross the faces
+    full["particles"].vel[:, 0] = vx(full["global_ids"])
+    ref_data = MpmData.new(pipe, full["params"], full["particles"], full["colliders"], full["cell_width"],
+                           full["grid_capacity"] * 4, full["model"])
+    pipe.step(ref_data, k)
+    ref = ref_data.read_particles()
+    shards, total = [], 0
+    for rank in range(world):
+        sc = scenes.neo_hookean_bar(n_side=n_side, world=world, rank=rank)
+        ps = sc["particles"]
+        ps.vel[:, 0] = vx(sc["global_ids"])
+        total += ps.n
+        lo, hi = sc["partition"].block_range(rank)
+        shards.append(GpuShard(pipe, sc["params"], ps, sc["global_ids"], sc["colliders"], sc["cell_width"],
+                               sc["grid_capacity"], lo, hi, rank > 0, rank < world - 1,
+                               particle_capacity=int(ps.n * 1.25) + 4096, model=sc["model"],
+                               halo_capacity_blocks=max(256, 2 * (n_side // 8 + 3) ** 2), migrant_capacity=2048))
+    assert total == full["global_particles"] == full["particles"].n
+    pending = None
+    for _ in range(k):
+        pending = lockstep_pipelined_substep(shards, pending)
+    lockstep_finish(shards, pending)
+    for s in shards:
+        s.sync()                                             # would report a halo / migration / capacity overflow
+    outs = [s.export() for s in shards]
+    ids = np.concatenate([o["ids"] for o in outs])
+    assert np.array_equal(np.sort(ids), np.sort(full["global_ids"]))
+    order = np.argsort(ids)
+    ref_order = np.argsort(full["global_ids"])
+    for f in ("pos", "vel"):
+        got = np.concatenate([o[f] for o in outs])[order]
+        assert rel_rms(got, getattr(ref, f)[ref_order]) < 1e-5, f
+
+
 def test_sharded_run_with_kinematic_collider(hip_libs):
     """configs[3]'s decomposition on one GPU: 4 slabs, a floor and a kinematic rotating cuboid that every rank
     integrates identically; particles, CPIC state and the body pose match the single-domain run."""
