@@ -55,7 +55,10 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     import torch
     dist = None
-    if world > 1:
+    # WGS_BENCH_FORCE_SHARDED=1: the N > 1 code path (RCCL process group, sharded data, collectives of the harness)
+    # with however many ranks were launched, even one — a functional check for 1-GPU boxes
+    sharded_path = world > 1 or os.environ.get("WGS_BENCH_FORCE_SHARDED") == "1"
+    if sharded_path:
         import torch.distributed as dist
         # WGS_BENCH_ONE_GPU=1: functional test of the N > 1 path on a 1-GPU box (all ranks on cuda:0, gloo)
         one_gpu = os.environ.get("WGS_BENCH_ONE_GPU") == "1"
@@ -66,7 +69,7 @@ def main():
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    dev_index = local_rank if world > 1 else 0
+    dev_index = local_rank if sharded_path else 0
 
     import numpy as np
     from wgsparkl_amd import MpmData, MpmPipeline, scenes
@@ -78,7 +81,7 @@ def main():
         torch.cuda.synchronize()
 
     pipe = MpmPipeline(dev_index, 3)
-    if world == 1:
+    if not sharded_path:
         scene = scenes.neo_hookean_cube(n_side=args.n_side, with_floor=not args.no_floor)
         ps = scene["particles"]
         n = ps.n
@@ -133,7 +136,7 @@ def main():
 
     # Per-pass device times (HIP events on the data's own stream) of K more substeps of the local slab.
     k_ts = min(args.steps, 64)
-    if world == 1:
+    if not sharded_path:
         pipe.step(data, k_ts, timestamps=True)
         data.sync()
         timings = data.read_timings()

@@ -290,6 +290,13 @@ wgs_status wgs_set_stream(wgs_data *data, void *hip_stream);
 /* All of the following are ASYNCHRONOUS (stream-ordered) and fixed-capacity: buffers are device memory of
  * header + capacity_records * record bytes; the record count travels in the header. Overflowing a buffer or
  * the particle capacity is reported by the next wgs_sync(). */
+/* Optional: the four outgoing message buffers this rank reuses every substep (halo to the lower / upper neighbour,
+ * migrants to the lower / upper neighbour; NULL where there is none). Their record counts are then reset inside
+ * the substep instead of by a launch of their own in every wgs_shard_pack_*. */
+wgs_status wgs_shard_register_buffers(wgs_data *data, void *halo_out_lo, void *halo_out_hi, void *mig_out_lo, void *mig_out_hi);
+/* wgs_shard_pack_halo for both faces / wgs_shard_add_halo for both neighbours in ONE launch each (NULL = no neighbour) */
+wgs_status wgs_shard_pack_halos(wgs_data *data, void *buf_lo, void *buf_hi, uint32_t capacity_records);
+wgs_status wgs_shard_add_halos(wgs_data *data, const void *in_lo, const void *in_hi, uint32_t capacity_records);
 /* Optional, before wgs_shard_add_migrants of the previous substep's migration: re-bins the particles that stayed,
  * so that this pass overlaps the migration messages still in flight; wgs_shard_step_begin then bins the arrivals
  * only. A no-op on the substeps that need the full pass. */

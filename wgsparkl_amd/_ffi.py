@@ -23,7 +23,8 @@ EXPORTS = (
     # multi-GPU (x-slab decomposition; new design, no reference counterpart)
     "wgs_data_create_sharded", "wgs_shard_halo_record_bytes", "wgs_shard_particle_record_bytes",
     "wgs_shard_buffer_header_bytes", "wgs_set_stream",
-    "wgs_shard_step_begin", "wgs_shard_bin_residents", "wgs_shard_pack_halo", "wgs_shard_add_halo", "wgs_shard_step_end",
+    "wgs_shard_step_begin", "wgs_shard_bin_residents", "wgs_shard_register_buffers", "wgs_shard_pack_halos",
+    "wgs_shard_add_halos", "wgs_shard_pack_halo", "wgs_shard_add_halo", "wgs_shard_step_end",
     "wgs_shard_pack_migrants", "wgs_shard_add_migrants", "wgs_shard_export",
 )
 
@@ -164,6 +165,9 @@ def load(dim: int):
     lib.wgs_shard_particle_record_bytes.restype = C.c_uint32
     lib.wgs_shard_step_begin.argtypes = [vp, vp]
     lib.wgs_shard_bin_residents.argtypes = [vp, vp]
+    lib.wgs_shard_register_buffers.argtypes = [vp, vp, vp, vp, vp]
+    lib.wgs_shard_pack_halos.argtypes = [vp, vp, vp, C.c_uint32]
+    lib.wgs_shard_add_halos.argtypes = [vp, vp, vp, C.c_uint32]
     lib.wgs_shard_step_end.argtypes = [vp, vp]
     lib.wgs_shard_buffer_header_bytes.restype = C.c_uint32
     lib.wgs_set_stream.argtypes = [vp, vp]

@@ -79,6 +79,8 @@ struct wgs_data {
     bool prev_sorted = false;   // the current buffer is the sorted output of the previous substep (perm_cell, links valid)
     bool tail_known = false;    // sharded: wgs_shard_add_migrants ran since the last substep (CTR_NPREV is current)
     uint32_t tail_slots = 0;    // sharded: upper bound of the arrivals appended behind the residents
+    bool fused_halo = false;        // sharded: the caller uses wgs_shard_pack_halos / add_halos (registered with wgs_shard_register_buffers)
+    bool needs_compact = false;     // sharded: the counters of the compacted buffer are still to be set
     bool residents_binned = false;  // sharded: wgs_shard_bin_residents already ran k_rebin for the coming substep
     uint64_t substeps = 0;
     uint64_t device_bytes = 0;
@@ -417,6 +419,10 @@ template <bool TS> wgs_status enqueue_substep(wgs_data *d, int ts_slot, int part
     // on the first substep, on table-rebuild substeps and in sharded runs (particles arrive from neighbours).
     const bool rehash = d->substeps % REHASH_PERIOD == 0;
     const bool use_rebin = d->prev_sorted && !rehash && !(dev.dbg & 128u) && (!dev.sharded || d->tail_known || part == 3);
+    if (dev.sharded && d->needs_compact && part != 2) {
+        hipLaunchKernelGGL(k_shard_compacted, dim3(1), dim3(64), 0, s, dev);
+        d->needs_compact = false;
+    }
     if (part == 3) {
         // Sharded runs, optional: re-bin the residents while the particle migration is still in flight (it only
         // needs the buffer the last G2P wrote). Part 1 then bins just the arrivals. Nothing to do on the substeps
@@ -485,7 +491,9 @@ template <bool TS> wgs_status enqueue_substep(wgs_data *d, int ts_slot, int part
             }
         }
         mark(4);
-        if (part == 1 && n > 0) hipLaunchKernelGGL((k_grid_update<D, 1>), dim3(grid_for(d, 4)), dim3(256), 0, s, dev);
+        // sharded runs: the interface layers are gathered by wgs_shard_pack_halos (fused protocol); the per-face
+        // wgs_shard_pack_halo needs the gather-only pass
+        if (part == 1 && n > 0 && !d->fused_halo) hipLaunchKernelGGL((k_grid_update<D, 1>), dim3(grid_for(d, 4)), dim3(256), 0, s, dev);
     }
     if (part != 1) {
         if (n > 0) {
@@ -493,6 +501,7 @@ template <bool TS> wgs_status enqueue_substep(wgs_data *d, int ts_slot, int part
             if (part == 0 && d->two_way)
                 hipLaunchKernelGGL((k_grid_update<D, 0, true>), dim3(grid_for(d, 4)), dim3(256), 0, s, dev);
             else if (part == 0) hipLaunchKernelGGL((k_grid_update<D, 0>), dim3(grid_for(d, 4)), dim3(256), 0, s, dev);
+            else if (d->fused_halo) hipLaunchKernelGGL((k_grid_update<D, 3>), dim3(grid_for(d, 4)), dim3(256), 0, s, dev);
             else hipLaunchKernelGGL((k_grid_update<D, 2>), dim3(grid_for(d, 4)), dim3(256), 0, s, dev);
         }
         mark(5);
@@ -807,7 +816,52 @@ wgs_status wgs_shard_step_end(wgs_pipeline *pipeline, wgs_data *d) {
     HIP_TRY(hipSetDevice(pipeline->device));
     wgs_status st = enqueue_substep<false>(d, 0, 2);
     if (st != WGS_OK) return st;
-    hipLaunchKernelGGL(k_shard_compacted, dim3(1), dim3(64), 0, d->stream, d->dev);
+    d->needs_compact = true;  // CTR_N / CTR_NPREV := CTR_NV: done by the next wgs_shard_pack_migrants (or the fallbacks)
+    return WGS_OK;
+}
+
+namespace {
+bool hdr_registered(const wgs_data *d, const void *p) {
+    for (int k = 0; k < 4; k++)
+        if (p && d->dev.hdr_clear[k] == p) return true;
+    return false;
+}
+}  // namespace
+
+wgs_status wgs_shard_register_buffers(wgs_data *d, void *halo_out_lo, void *halo_out_hi, void *mig_out_lo, void *mig_out_hi) {
+    if (!d) return fail(WGS_ERR_INVALID_ARGUMENT, "NULL argument");
+    if (!d->dev.sharded) return fail(WGS_ERR_INVALID_ARGUMENT, "not a sharded wgs_data");
+    void *p[4] = {halo_out_lo, halo_out_hi, mig_out_lo, mig_out_hi};
+    for (int k = 0; k < 4; k++) d->dev.hdr_clear[k] = static_cast<uint32_t *>(p[k]);
+    // registering also selects the fused halo protocol: wgs_shard_step_begin stops after P2G, wgs_shard_pack_halos
+    // gathers the interface layers itself (it must then be called every substep, even without neighbours), and
+    // wgs_shard_step_end runs the single-pass grid update
+    d->fused_halo = true;
+    return WGS_OK;
+}
+
+wgs_status wgs_shard_pack_halos(wgs_data *d, void *buf_lo, void *buf_hi, uint32_t capacity_records) {
+    if (!d) return fail(WGS_ERR_INVALID_ARGUMENT, "NULL argument");
+    if (!buf_lo && !buf_hi) return WGS_OK;  // no neighbour on either side: no interface layer
+    HIP_TRY(hipSetDevice(d->pipeline->device));
+    if ((buf_lo && !hdr_registered(d, buf_lo)) || (buf_hi && !hdr_registered(d, buf_hi)))
+        hipLaunchKernelGGL(k_clear_headers, dim3(1), dim3(64), 0, d->stream, static_cast<uint32_t *>(buf_lo), static_cast<uint32_t *>(buf_hi));
+    hipLaunchKernelGGL(k_pack_halos<D>, dim3(grid_for(d, 4)), dim3(64), 0, d->stream, d->dev, d->dev.shard_lo,
+                       static_cast<float4 *>(buf_lo), d->dev.shard_hi, static_cast<float4 *>(buf_hi), capacity_records,
+                       d->fused_halo ? 1 : 0);
+    HIP_TRY(hipGetLastError());
+    return WGS_OK;
+}
+
+wgs_status wgs_shard_add_halos(wgs_data *d, const void *in_lo, const void *in_hi, uint32_t capacity_records) {
+    if (!d) return fail(WGS_ERR_INVALID_ARGUMENT, "NULL argument");
+    if (!in_lo && !in_hi) return WGS_OK;
+    HIP_TRY(hipSetDevice(d->pipeline->device));
+    const uint32_t epoch = (uint32_t)(d->substeps + 1);
+    const uint32_t g = capacity_records < 2048u ? (capacity_records ? capacity_records : 1u) : 2048u;
+    const void *a = in_lo ? in_lo : in_hi, *b = in_lo ? in_hi : nullptr;
+    hipLaunchKernelGGL(k_add_halo<D>, dim3(g, b ? 2 : 1), dim3(64), 0, d->stream, d->dev, static_cast<const float4 *>(a),
+                       static_cast<const float4 *>(b), capacity_records, epoch);
     HIP_TRY(hipGetLastError());
     return WGS_OK;
 }
@@ -815,7 +869,8 @@ wgs_status wgs_shard_step_end(wgs_pipeline *pipeline, wgs_data *d) {
 wgs_status wgs_shard_pack_halo(wgs_data *d, int32_t layer_bx, void *device_buf, uint32_t capacity_records) {
     if (!d || !device_buf) return fail(WGS_ERR_INVALID_ARGUMENT, "NULL argument");
     HIP_TRY(hipSetDevice(d->pipeline->device));
-    hipLaunchKernelGGL(k_clear_headers, dim3(1), dim3(64), 0, d->stream, static_cast<uint32_t *>(device_buf), (uint32_t *)nullptr);
+    if (!hdr_registered(d, device_buf))
+        hipLaunchKernelGGL(k_clear_headers, dim3(1), dim3(64), 0, d->stream, static_cast<uint32_t *>(device_buf), (uint32_t *)nullptr);
     hipLaunchKernelGGL(k_pack_halo<D>, dim3(grid_for(d, 4)), dim3(64), 0, d->stream, d->dev, layer_bx,
                        static_cast<float4 *>(device_buf), capacity_records);
     HIP_TRY(hipGetLastError());
@@ -828,7 +883,7 @@ wgs_status wgs_shard_add_halo(wgs_data *d, const void *device_buf, uint32_t capa
     const uint32_t epoch = (uint32_t)(d->substeps + 1);
     const uint32_t g = capacity_records < 2048u ? (capacity_records ? capacity_records : 1u) : 2048u;
     hipLaunchKernelGGL(k_add_halo<D>, dim3(g), dim3(64), 0, d->stream, d->dev, static_cast<const float4 *>(device_buf),
-                       capacity_records, epoch);
+                       static_cast<const float4 *>(nullptr), capacity_records, epoch);
     HIP_TRY(hipGetLastError());
     return WGS_OK;
 }
@@ -836,7 +891,9 @@ wgs_status wgs_shard_add_halo(wgs_data *d, const void *device_buf, uint32_t capa
 wgs_status wgs_shard_pack_migrants(wgs_data *d, void *dev_lo, void *dev_hi, uint32_t capacity_records) {
     if (!d || !dev_lo || !dev_hi) return fail(WGS_ERR_INVALID_ARGUMENT, "NULL argument");
     HIP_TRY(hipSetDevice(d->pipeline->device));
-    hipLaunchKernelGGL(k_clear_headers, dim3(1), dim3(64), 0, d->stream, static_cast<uint32_t *>(dev_lo), static_cast<uint32_t *>(dev_hi));
+    if (!hdr_registered(d, dev_lo) || !hdr_registered(d, dev_hi))
+        hipLaunchKernelGGL(k_clear_headers, dim3(1), dim3(64), 0, d->stream, static_cast<uint32_t *>(dev_lo), static_cast<uint32_t *>(dev_hi));
+    d->needs_compact = false;  // k_pack_migrants does the bookkeeping of the compacted buffer itself
     hipLaunchKernelGGL(k_pack_migrants<D>, dim3(grid_for(d, 4)), dim3(256), 0, d->stream, d->dev, d->side, 0,
                        static_cast<float *>(dev_lo), static_cast<float *>(dev_hi), capacity_records);
     HIP_TRY(hipGetLastError());
@@ -849,12 +906,14 @@ wgs_status wgs_shard_add_migrants(wgs_data *d, const void *in_lo, const void *in
     HIP_TRY(hipSetDevice(d->pipeline->device));
     d->tail_known = true;
     d->tail_slots = (in_lo ? capacity_records : 0u) + (in_hi ? capacity_records : 0u);
-    if (in_lo || in_hi)
-        hipLaunchKernelGGL(k_append_migrants<D>, dim3((2 * capacity_records + 255) / 256), dim3(256), 0, d->stream, d->dev,
-                           d->side, static_cast<const float *>(in_lo), static_cast<const float *>(in_hi), capacity_records);
-    hipLaunchKernelGGL(k_shard_counts, dim3(1), dim3(64), 0, d->stream, d->dev, static_cast<const float *>(in_lo),
-                       static_cast<const float *>(in_hi), static_cast<const float *>(out_lo), static_cast<const float *>(out_hi),
-                       capacity_records);
+    if (d->needs_compact) {  // no wgs_shard_pack_migrants since the last substep: do its bookkeeping here
+        hipLaunchKernelGGL(k_shard_compacted, dim3(1), dim3(64), 0, d->stream, d->dev);
+        d->needs_compact = false;
+    }
+    // append + the bookkeeping of the round, one launch (at least one workgroup even without arrivals)
+    hipLaunchKernelGGL(k_append_migrants<D>, dim3(std::max(1u, (d->tail_slots + 255u) / 256u)), dim3(256), 0, d->stream, d->dev,
+                       d->side, static_cast<const float *>(in_lo), static_cast<const float *>(in_hi),
+                       static_cast<const float *>(out_lo), static_cast<const float *>(out_hi), capacity_records);
     HIP_TRY(hipGetLastError());
     return WGS_OK;
 }
@@ -862,6 +921,10 @@ wgs_status wgs_shard_add_migrants(wgs_data *d, const void *in_lo, const void *in
 wgs_status wgs_shard_export(wgs_data *d, void *device_buf, uint32_t capacity_records, uint32_t *count) {
     if (!d || !device_buf || !count) return fail(WGS_ERR_INVALID_ARGUMENT, "NULL argument");
     HIP_TRY(hipSetDevice(d->pipeline->device));
+    if (d->needs_compact) {
+        hipLaunchKernelGGL(k_shard_compacted, dim3(1), dim3(64), 0, d->stream, d->dev);
+        d->needs_compact = false;
+    }
     hipLaunchKernelGGL(k_clear_headers, dim3(1), dim3(64), 0, d->stream, static_cast<uint32_t *>(device_buf), (uint32_t *)nullptr);
     hipLaunchKernelGGL(k_pack_migrants<D>, dim3(grid_for(d, 4)), dim3(256), 0, d->stream, d->dev, d->side, 1,
                        static_cast<float *>(device_buf), static_cast<float *>(device_buf), capacity_records);

@@ -65,9 +65,45 @@ template <int D> __global__ __launch_bounds__(64) void k_pack_halo(Dev d, int la
     }
 }
 
-// Add a neighbour's partial sums to the blocks this rank has active.
-template <int D> __global__ __launch_bounds__(64) void k_add_halo(Dev d, const float4 *buf, uint32_t cap, uint32_t epoch) {
+// Both interface layers in one launch (a launch costs ~4.5 us whatever it does): layer_lo -> buf_lo, layer_hi -> buf_hi;
+// a null buffer = no neighbour on that side.
+// `gather`: the node sums are not in nodes[] yet (no separate gather pass ran): compute them here from the slabs and
+// leave them in nodes[] for k_add_halo / the PHASE 3 grid update.
+template <int D> __device__ inline float4 gather_slabs(const Dev &d, uint32_t b, uint32_t ln);  // kernels_transfer.h
+template <int D> __global__ __launch_bounds__(64) void k_pack_halos(Dev d, int layer_lo, float4 *buf_lo, int layer_hi, float4 *buf_hi, uint32_t cap,
+                                                                      int gather) {
     using H = HaloCfg<D>;
+    const uint32_t B = min(d.counters[CTR_NBLOCKS], d.cap);
+    const int lane = threadIdx.x;
+    for (uint32_t a = blockIdx.x; a < B; a += gridDim.x) {
+        const uint32_t b = d.active[a];
+        int bc[3] = {0, 0, 0};
+        unpack_key<D>(d.block_key[b], bc);
+        float4 *buf = (buf_lo && bc[0] == layer_lo) ? buf_lo : ((buf_hi && bc[0] == layer_hi) ? buf_hi : nullptr);  // wave-uniform
+        if (gather && (bc[0] == layer_lo || bc[0] == layer_hi) && lane < H::NODES) {
+            const uint32_t ln = halo_node<D>(lane);
+            d.nodes[(size_t)b * NPB + ln] = gather_slabs<D>(d, b, ln);  // (read back below by the same lane)
+        }
+        if (!buf) continue;
+        uint32_t slot = 0;
+        if (lane == 0) slot = atomicAdd(reinterpret_cast<uint32_t *>(buf), 1u);
+        slot = __shfl(slot, 0);
+        if (slot >= cap) {
+            if (lane == 0) atomicOr(&d.counters[CTR_ERRORS], ERRBIT_SHARD);
+            continue;
+        }
+        float4 *rec = buf + 1 + (size_t)slot * H::REC_F4;
+        if (lane == 0) rec[0] = make_float4(__uint_as_float(d.block_key[b]), 0.f, 0.f, 0.f);
+        if (lane < H::NODES) rec[1 + lane] = d.nodes[(size_t)b * NPB + halo_node<D>(lane)];
+    }
+}
+
+// Add a neighbour's partial sums to the blocks this rank has active.
+// blockIdx.y selects the message (buf, or buf2 of the other neighbour when given): the two touch different block layers.
+template <int D> __global__ __launch_bounds__(64) void k_add_halo(Dev d, const float4 *buf, const float4 *buf2, uint32_t cap, uint32_t epoch) {
+    using H = HaloCfg<D>;
+    if (blockIdx.y == 1) buf = buf2;
+    if (!buf) return;
     const uint32_t n_rec = min(reinterpret_cast<const uint32_t *>(buf)[0], cap);
     const float4 *in = buf + 1;
     const int lane = threadIdx.x;
@@ -97,6 +133,12 @@ template <int D> __global__ __launch_bounds__(256) void k_pack_migrants(Dev d, i
     // right after a substep (mode 0) the buffer holds the valid particles only; a read-back (mode 1) may come
     // after a migration round, when vacated slots and appended particles coexist
     const uint32_t n = mode == 1 ? num_slots(d) : num_valid(d);
+    if (mode == 0 && blockIdx.x == 0 && threadIdx.x == 0) {
+        // after the fused G2P kernel this buffer holds exactly the valid particles, in sorted order (nothing in this
+        // launch reads CTR_N / CTR_NPREV)
+        d.counters[CTR_N] = n;
+        d.counters[CTR_NPREV] = n;  // residents of the next substep (arrivals are appended behind)
+    }
     for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
         const uint32_t pid = ldpid<D>(buf, npad, i);
         if (pid == PID_DEAD) continue;
@@ -129,12 +171,21 @@ template <int D> __global__ __launch_bounds__(256) void k_pack_migrants(Dev d, i
 }
 
 // Append the particles received from both neighbours after the current ones.
-template <int D> __global__ __launch_bounds__(256) void k_append_migrants(Dev d, int side, const float *in_lo, const float *in_hi, uint32_t cap) {
+template <int D> __global__ __launch_bounds__(256) void k_append_migrants(Dev d, int side, const float *in_lo, const float *in_hi, const float *out_lo,
+                                                                          const float *out_hi, uint32_t cap) {
     constexpr int NQ = Pl<D>::NQ, RF = particle_record_floats<D>();
     float *buf = d.buf[side];
     const uint32_t n_lo = in_lo ? min(reinterpret_cast<const uint32_t *>(in_lo)[0], cap) : 0u;
     const uint32_t n_hi = in_hi ? min(reinterpret_cast<const uint32_t *>(in_hi)[0], cap) : 0u;
-    const uint32_t first = num_valid(d);  // == slots right after a substep
+    const uint32_t first = d.counters[CTR_NPREV];  // the valid particles of the last substep occupy [0, NPREV)
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        // bookkeeping of the migration round (nothing in this launch reads these two): slots = residents + arrivals,
+        // valid = residents - departures + arrivals
+        auto cnt = [&](const float *b) { return b ? min(reinterpret_cast<const uint32_t *>(b)[0], cap) : 0u; };
+        const uint32_t arrivals = min(n_lo + n_hi, d.n - first);
+        d.counters[CTR_N] = first + arrivals;
+        d.counters[CTR_NV] = first - cnt(out_lo) - cnt(out_hi) + arrivals;
+    }
     for (uint32_t r = blockIdx.x * 256 + threadIdx.x; r < n_lo + n_hi; r += gridDim.x * 256) {
         const float *rec = r < n_lo ? in_lo + 4 + (size_t)r * RF : in_hi + 4 + (size_t)(r - n_lo) * RF;
         const uint32_t i = first + r;
@@ -147,17 +198,6 @@ template <int D> __global__ __launch_bounds__(256) void k_append_migrants(Dev d,
         stpid<D>(buf, d.npad, i, __float_as_uint(rec[NQ * 4]));
         ststamp<D>(buf, d.npad, i, __float_as_uint(rec[NQ * 4 + 1]));
     }
-}
-
-// Bookkeeping after a migration round (one thread): slots = old valid + arrivals, valid = old valid - departures + arrivals.
-__global__ void k_shard_counts(Dev d, const float *in_lo, const float *in_hi, const float *out_lo, const float *out_hi, uint32_t cap) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    auto cnt = [&](const float *b) { return b ? min(reinterpret_cast<const uint32_t *>(b)[0], cap) : 0u; };
-    const uint32_t nv = d.counters[CTR_NV];
-    const uint32_t arrivals = min(cnt(in_lo) + cnt(in_hi), d.n - nv);
-    d.counters[CTR_NPREV] = nv;  // [0, nv): the sorted output of the last substep (some slots vacated)
-    d.counters[CTR_N] = nv + arrivals;
-    d.counters[CTR_NV] = nv - cnt(out_lo) - cnt(out_hi) + arrivals;
 }
 
 // After the fused G2P kernel the other buffer holds exactly the valid particles, in sorted order.

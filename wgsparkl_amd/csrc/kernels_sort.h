@@ -271,6 +271,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan_active(Dev d, uint32_t ep
         if (tid == SCAN_THREADS - 1) carry_s = run;
         __syncthreads();
     }
+    if (tid < 4 && d.hdr_clear[tid]) d.hdr_clear[tid][0] = 0u;  // outgoing halo / migrant message counts of this substep
     if (tid == 0) {
         d.counters[CTR_NBLOCKS] = (uint32_t)(carry_s >> 32);
         d.counters[CTR_NCPIC] = 0;

@@ -341,8 +341,30 @@ __global__ __launch_bounds__(P2GCfg<D>::NW * 64) void k_p2g(Dev d, int side, int
 
 // ------------------------------------------------------------ grid update
 // Gather of the slabs covering each node + solver/grid_update.wgsl:55-64.
-// PHASE 0: gather + update in one pass (single GPU). Sharded runs split it around the halo exchange:
-// PHASE 1 = gather only (partial momentum/mass sums into nodes[]), PHASE 2 = update from nodes[].
+// PHASE 0: gather + update in one pass (single GPU). Sharded runs: PHASE 3 = the same single pass, except that the
+// interface node layers come from nodes[] (gathered and exchanged by k_pack_halos / k_add_halo). PHASE 1 = gather only
+// (partial momentum / mass sums into nodes[]) and PHASE 2 = update from nodes[] remain for callers that pack the two
+// faces separately (wgs_shard_pack_halo).
+
+// Partial (momentum, mass) sum of one node from the (at most 2^D) slabs that cover it, in the fixed order of the
+// grid update.
+template <int D> __device__ inline float4 gather_slabs(const Dev &d, uint32_t b, uint32_t ln) {
+    constexpr int BW = Dim<D>::BW, BS = Dim<D>::BSHIFT, TW = Dim<D>::TW, TILE = Dim<D>::TILE, NN = Dim<D>::NNBR;
+    const int l[3] = {(int)(ln & (BW - 1)), (int)((ln >> BS) & (BW - 1)), D == 3 ? (int)(ln >> (2 * BS)) : 0};
+    float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int o = 0; o < NN; o++) {
+        const int tt[3] = {l[0] + BW * (o & 1), l[1] + BW * ((o >> 1) & 1), l[2] + BW * ((o >> 2) & 1)};
+        const bool in_tile = tt[0] < TW && tt[1] < TW && (D == 2 || tt[2] < TW);
+        if (!in_tile) continue;
+        const uint32_t src = d.nbr_minus[b * 8u + o];
+        if (src == NONE || d.block_count[src] == 0) continue;
+        const float4 p = d.slab[(size_t)src * TILE + tt[0] + TW * tt[1] + (D == 3 ? TW * TW * tt[2] : 0)];
+        sum.x += p.x; sum.y += p.y; sum.z += p.z; sum.w += p.w;
+    }
+    return sum;
+}
+
 template <int D, int PHASE, bool TWOWAY = false> __global__ __launch_bounds__(256) void k_grid_update(Dev d) {
     constexpr int BW = Dim<D>::BW, BS = Dim<D>::BSHIFT, TW = Dim<D>::TW, TILE = Dim<D>::TILE, NN = Dim<D>::NNBR;
     const uint32_t B = min(d.counters[CTR_NBLOCKS], d.cap);
@@ -358,6 +380,14 @@ template <int D, int PHASE, bool TWOWAY = false> __global__ __launch_bounds__(25
         l[1] = (ln >> BS) & (BW - 1);
         l[2] = D == 3 ? (ln >> (2 * BS)) : 0;
         float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
+        // PHASE 3 (sharded runs): the two interface node layers of the blocks of layer shard_lo / shard_hi were
+        // gathered by k_pack_halos and completed with the neighbour's partial sums (k_add_halo): take them from nodes[]
+        bool from_nodes = false;
+        if constexpr (PHASE == 3) {
+            int bc[3] = {0, 0, 0};
+            unpack_key<D>(d.block_key[b], bc);
+            from_nodes = l[0] < 2 && (bc[0] == d.shard_lo || bc[0] == d.shard_hi);
+        }
         float isum[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};  // node impulse (two-way coupling): linear, angular
         uint32_t srcs[NN];
         int tis[NN];
@@ -372,7 +402,7 @@ template <int D, int PHASE, bool TWOWAY = false> __global__ __launch_bounds__(25
             int ti = tt[0] + TW * tt[1] + (D == 3 ? TW * TW * tt[2] : 0);
             srcs[o] = src;
             tis[o] = ti;
-            if constexpr (PHASE != 2) {
+            if (PHASE != 2 && !(PHASE == 3 && from_nodes)) {
                 float4 p = d.slab[(size_t)src * TILE + ti];
                 sum.x += p.x; sum.y += p.y; sum.z += p.z; sum.w += p.w;
                 if constexpr (TWOWAY) {
@@ -406,6 +436,9 @@ template <int D, int PHASE, bool TWOWAY = false> __global__ __launch_bounds__(25
             continue;
         }
         if constexpr (PHASE == 2) sum = d.nodes[node];
+        if constexpr (PHASE == 3) {
+            if (from_nodes) sum = d.nodes[node];
+        }
         float mass = D == 3 ? sum.w : sum.z;
         float inv_mass = mass > 0.f ? 1.0f / mass : 0.f;
         float mom[3] = {sum.x, sum.y, sum.z};

@@ -148,6 +148,7 @@ struct Dev {
     BodyDev *bodies;         // 16: mass properties
     int32_t *impulses;       // 16 * 8: fixed-point (x 1e5) linear[D] + angular impulses accumulated by P2G
     float4 *imp_slab;        // cap*TILE*IMPQ per-block partial node impulses (two-way coupling only), or null
+    uint32_t *hdr_clear[4];  // sharded: headers of the registered outgoing message buffers, zeroed by k_scan_active
     // rigid particles of mesh colliders (kernels_rigid.h); n_rigid == 0 when there is none
     uint32_t n_rigid, n_rvtx;
     float *rp_local, *rp_world;          // n_rigid * D: sample points, body frame / world

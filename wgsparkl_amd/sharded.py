@@ -73,18 +73,29 @@ def associated_block_x(pos: np.ndarray, cell_width: float, dim: int) -> np.ndarr
 # ------------------------------------------------------------------------------------------------
 # protocol (backend-agnostic)
 # ------------------------------------------------------------------------------------------------
-def substep_phases(backend, exchange):
-    """One substep of one rank. `exchange(to_lower, to_upper) -> (from_lower, from_upper)` moves opaque
-    record buffers between neighbours (None where there is no neighbour)."""
-    lo, hi = backend.block_lo, backend.block_hi
-    backend.step_begin()
-    to_lower = backend.pack_halo(lo) if backend.has_lower else None
-    to_upper = backend.pack_halo(hi) if backend.has_upper else None
-    from_lower, from_upper = exchange(to_lower, to_upper)
+def _pack_halos(backend):
+    if hasattr(backend, "pack_halos"):
+        return backend.pack_halos()
+    return (backend.pack_halo(backend.block_lo) if backend.has_lower else None,
+            backend.pack_halo(backend.block_hi) if backend.has_upper else None)
+
+
+def _add_halos(backend, from_lower, from_upper):
+    if hasattr(backend, "add_halos"):
+        backend.add_halos(from_lower, from_upper)
+        return
     if from_lower is not None:
         backend.add_halo(from_lower)
     if from_upper is not None:
         backend.add_halo(from_upper)
+
+
+def substep_phases(backend, exchange):
+    """One substep of one rank. `exchange(to_lower, to_upper) -> (from_lower, from_upper)` moves opaque
+    record buffers between neighbours (None where there is no neighbour)."""
+    backend.step_begin()
+    to_lower, to_upper = _pack_halos(backend)
+    _add_halos(backend, *exchange(to_lower, to_upper))
     backend.step_end()
     out_lower, out_upper = backend.pack_migrants()
     in_lower, in_upper = exchange(out_lower if backend.has_lower else None, out_upper if backend.has_upper else None)
@@ -95,18 +106,12 @@ def pipelined_substep(backend, exchange, pending):
     """`substep_phases` with the particle migration of the PREVIOUS substep still in flight while the residents
     are re-binned (`pending` = what the previous call returned, None at the start). Returns the handle of this
     substep's migration; `finish_migration` must absorb the last one before the state is read."""
-    lo, hi = backend.block_lo, backend.block_hi
     backend.bin_residents()                       # overlaps the messages in flight
     if pending is not None:
         finish_migration(backend, pending)
     backend.step_begin()
-    to_lower = backend.pack_halo(lo) if backend.has_lower else None
-    to_upper = backend.pack_halo(hi) if backend.has_upper else None
-    from_lower, from_upper = exchange(to_lower, to_upper)
-    if from_lower is not None:
-        backend.add_halo(from_lower)
-    if from_upper is not None:
-        backend.add_halo(from_upper)
+    to_lower, to_upper = _pack_halos(backend)
+    _add_halos(backend, *exchange(to_lower, to_upper))
     backend.step_end()
     out_lower, out_upper = backend.pack_migrants()
     return exchange.start(out_lower if backend.has_lower else None, out_upper if backend.has_upper else None)
@@ -123,13 +128,9 @@ def lockstep_substep(backends: List):
     n = len(backends)
     for b in backends:
         b.step_begin()
-    up = [b.pack_halo(b.block_hi) if b.has_upper else None for b in backends]
-    down = [b.pack_halo(b.block_lo) if b.has_lower else None for b in backends]
+    packed = [_pack_halos(b) for b in backends]          # (to_lower, to_upper) of every rank
     for r, b in enumerate(backends):
-        if r > 0:
-            b.add_halo(up[r - 1])
-        if r < n - 1:
-            b.add_halo(down[r + 1])
+        _add_halos(b, packed[r - 1][1] if r > 0 else None, packed[r + 1][0] if r < n - 1 else None)
     for b in backends:
         b.step_end()
     mig = [b.pack_migrants() for b in backends]
@@ -148,13 +149,9 @@ def lockstep_pipelined_substep(backends: List, pending):
         lockstep_finish(backends, pending)
     for b in backends:
         b.step_begin()
-    up = [b.pack_halo(b.block_hi) if b.has_upper else None for b in backends]
-    down = [b.pack_halo(b.block_lo) if b.has_lower else None for b in backends]
+    packed = [_pack_halos(b) for b in backends]          # (to_lower, to_upper) of every rank
     for r, b in enumerate(backends):
-        if r > 0:
-            b.add_halo(up[r - 1])
-        if r < n - 1:
-            b.add_halo(down[r + 1])
+        _add_halos(b, packed[r - 1][1] if r > 0 else None, packed[r + 1][0] if r < n - 1 else None)
     for b in backends:
         b.step_end()
     mig = [b.pack_migrants() for b in backends]
@@ -320,6 +317,11 @@ class GpuShard:
         self._halo_out = [torch.zeros(self.hdr + self.halo_cap * self.halo_rec, dtype=f32, device=dev) for _ in range(2)]
         self._mig_out = [torch.zeros(self.hdr + self.mig_cap * self.part_rec, dtype=f32, device=dev) for _ in range(2)]
         self._keep = []   # received tensors stay alive until the stream has consumed them
+        # the outgoing buffers are reused every substep: their record counts are reset inside the substep
+        ptr = lambda t, ok: C.c_void_p(t.data_ptr()) if ok else None
+        _ffi.check(self.lib, self.lib.wgs_shard_register_buffers(
+            self._h, ptr(self._halo_out[0], has_lower), ptr(self._halo_out[1], has_upper),
+            ptr(self._mig_out[0], True), ptr(self._mig_out[1], True)))
         # kernels and RCCL messages are ordered on torch's current stream: no host sync inside a substep
         _ffi.check(self.lib, self.lib.wgs_set_stream(self._h, C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)))
 
@@ -335,6 +337,20 @@ class GpuShard:
         buf = self._halo_out[0 if layer_bx == self.block_lo else 1]
         _ffi.check(self.lib, self.lib.wgs_shard_pack_halo(self._h, int(layer_bx), C.c_void_p(buf.data_ptr()), self.halo_cap))
         return buf
+
+    def pack_halos(self):
+        """Both faces in one launch -> (to_lower, to_upper), None where there is no neighbour."""
+        lo = self._halo_out[0] if self.has_lower else None
+        hi = self._halo_out[1] if self.has_upper else None
+        ptr = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
+        _ffi.check(self.lib, self.lib.wgs_shard_pack_halos(self._h, ptr(lo), ptr(hi), self.halo_cap))
+        return lo, hi
+
+    def add_halos(self, from_lower, from_upper):
+        """Both neighbours' partial sums in one launch."""
+        ptr = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
+        self._keep += [t for t in (from_lower, from_upper) if t is not None]
+        _ffi.check(self.lib, self.lib.wgs_shard_add_halos(self._h, ptr(from_lower), ptr(from_upper), self.halo_cap))
 
     def add_halo(self, buf):
         if buf is None:
