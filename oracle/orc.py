@@ -14,7 +14,7 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_BUILD = os.path.join(_HERE, "_build")
+_BUILD = os.environ.get("WGS_ORACLE_BUILD_DIR") or os.path.join(_HERE, "_build")   # (override: sanitizer builds)
 NONE = 0xFFFFFFFF
 
 
