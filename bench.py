@@ -94,7 +94,7 @@ def main():
     else:
         # Weak scaling: `world` C2 cubes side by side along x form one elastic bar; x-slab domain
         # decomposition, one slab per GPU, halo + migration exchanges over RCCL point-to-point (sharded.py).
-        from wgsparkl_amd.sharded import FixedExchange, GpuShard, finish_migration, pipelined_substep
+        from wgsparkl_amd.sharded import FixedExchange, GpuShard, RcclExchange, finish_migration, pipelined_substep
         scene = scenes.neo_hookean_bar(n_side=args.n_side, world=world, rank=rank)
         if args.no_floor:
             scene["colliders"] = []
@@ -108,7 +108,25 @@ def main():
                         # message capacities from the face area: (n_side / 8 + 3)^2 interface blocks, x2 margin;
                         # a few hundred particles cross a face per substep at these velocities
                         halo_capacity_blocks=max(256, 2 * (args.n_side // 8 + 3) ** 2), migrant_capacity=2048)
-        exch = FixedExchange(dist, rank, world)
+        # transport: RCCL called directly (ctypes) unless WGS_EXCHANGE=torch or the process group is not RCCL (the
+        # 1-GPU functional mode runs over gloo)
+        use_rccl = os.environ.get("WGS_EXCHANGE", "rccl") == "rccl" and dist.get_backend() == "nccl"
+        exch = None
+        if use_rccl:
+            try:
+                exch = RcclExchange(dist, rank, world)
+                if os.environ.get("WGS_BENCH_FORCE_SHARDED") == "1":
+                    exch.selftest()
+            except Exception as e:  # noqa: BLE001 — any failure here means "use the torch transport", on every rank
+                print(f"[bench rank {rank}] direct RCCL transport unavailable ({e}); using torch.distributed p2p", file=sys.stderr)
+                exch = None
+            ok = torch.tensor([1 if exch is not None else 0], device=f"cuda:{local_rank}", dtype=torch.int32)
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)      # all ranks or none
+            if int(ok.item()) == 0:
+                exch, use_rccl = None, False
+        if exch is None:
+            exch = FixedExchange(dist, rank, world)
+        transport = "RCCL send/recv (direct)" if use_rccl else "torch.distributed p2p"
 
         def run(k):
             pending = None       # the migration of a substep stays in flight while the next one re-bins its residents
@@ -116,7 +134,7 @@ def main():
                 pending = pipelined_substep(data, exch, pending)
             finish_migration(data, pending)
         sync = data.sync
-        parallelism = f"{world} x-slabs, halo + migration over RCCL p2p"
+        parallelism = f"{world} x-slabs, halo + migration over {transport}"
 
     run(args.warmup)
     sync()

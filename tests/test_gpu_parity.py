@@ -220,6 +220,27 @@ def test_bench_decomposition_eight_ranks_on_one_gpu(hip_libs):
         assert rel_rms(got, getattr(ref, f)[ref_order]) < 1e-5, f
 
 
+def test_rccl_exchange_selftest(hip_libs):
+    """The transport bench.py uses for N > 1 (ncclSend / ncclRecv called directly on torch's librccl.so): two
+    communicators from broadcast unique ids, a grouped send + receive on the substep stream and on the side stream.
+    One rank only here (a second rank on the same GPU is refused by RCCL), so the peer is this rank itself."""
+    import torch
+    import torch.distributed as dist
+    from wgsparkl_amd.sharded import RcclExchange
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", init_method="tcp://127.0.0.1:29541", rank=0, world_size=1,
+                            device_id=torch.device("cuda", 0))
+    try:
+        ex = RcclExchange(dist, 0, 1)
+        assert ex.selftest()
+        a, b = ex(None, None)                      # no neighbours: nothing to move, nothing returned
+        assert a is None and b is None
+        assert ex.start(None, None).finish() == (None, None)
+        ex.close()
+    finally:
+        dist.destroy_process_group()
+
+
 def test_sharded_run_with_kinematic_collider(hip_libs):
     """configs[3]'s decomposition on one GPU: 4 slabs, a floor and a kinematic rotating cuboid that every rank
     integrates identically; particles, CPIC state and the body pose match the single-domain run."""

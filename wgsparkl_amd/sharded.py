@@ -222,6 +222,131 @@ class FixedExchange:
         return _PendingExchange(works, from_lower, from_upper)
 
 
+class RcclExchange:
+    """The same fixed-size neighbour exchange as FixedExchange, issued straight on RCCL (`ncclSend` / `ncclRecv` inside
+    one group per exchange, through ctypes on the librccl.so that torch itself loaded) instead of through
+    torch.distributed's point-to-point wrappers, whose host-side cost (work objects, coalescing, watchdog) would
+    otherwise bound a 200 us substep from the CPU side. Two communicators: the halo exchange runs on the substep's own
+    stream (it is on the critical path anyway), the particle migration on a side stream so that it overlaps the next
+    substep's re-binning. torch.distributed is only used to hand the unique ids around."""
+
+    NCCL_FLOAT32 = 7
+
+    def __init__(self, dist, rank: int, world: int):
+        import os
+        import torch
+        self.torch, self.rank, self.world = torch, rank, world
+        self.lower = rank - 1 if rank > 0 else None
+        self.upper = rank + 1 if rank < world - 1 else None
+        lib = C.CDLL(os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so"))
+
+        class UniqueId(C.Structure):
+            _fields_ = [("internal", C.c_char * 128)]
+
+        lib.ncclGetUniqueId.argtypes = [C.POINTER(UniqueId)]
+        lib.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, UniqueId, C.c_int]
+        lib.ncclSend.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+        lib.ncclRecv.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+        lib.ncclCommDestroy.argtypes = [C.c_void_p]
+        lib.ncclGetErrorString.restype = C.c_char_p
+        lib.ncclGetErrorString.argtypes = [C.c_int]
+        self.lib = lib
+        dev = torch.device("cuda", torch.cuda.current_device())
+        self.comms = []
+        for _ in range(2):                                   # halo, migration
+            uid = UniqueId()
+            if rank == 0:
+                self._check(lib.ncclGetUniqueId(C.byref(uid)))
+            t = torch.tensor(list(C.string_at(C.byref(uid), 128)) if rank == 0 else [0] * 128, dtype=torch.uint8)  # all 128 bytes
+            t = t.to(dev) if dist.get_backend() == "nccl" else t
+            dist.broadcast(t, 0)
+            raw = bytes(t.cpu().numpy().tobytes())
+            uid = UniqueId()
+            C.memmove(C.byref(uid), raw, 128)
+            comm = C.c_void_p()
+            self._check(lib.ncclCommInitRank(C.byref(comm), world, uid, rank))
+            self.comms.append(comm)
+        self.side = torch.cuda.Stream(device=dev)
+        self._plans = {}
+
+    def _check(self, rc):
+        if rc != 0:
+            raise RuntimeError("RCCL: " + self.lib.ncclGetErrorString(rc).decode())
+
+    def _plan(self, to_lower, to_upper):
+        torch = self.torch
+        key = (None if to_lower is None else to_lower.data_ptr(), None if to_upper is None else to_upper.data_ptr())
+        plan = self._plans.get(key)
+        if plan is None:
+            sets = []
+            for _ in range(2):                               # two receive sets alternate (see FixedExchange)
+                ops, from_lower, from_upper = [], None, None
+                if self.lower is not None and to_lower is not None:
+                    from_lower = torch.empty_like(to_lower)
+                    ops.append((to_lower.data_ptr(), from_lower.data_ptr(), to_lower.numel(), self.lower))
+                if self.upper is not None and to_upper is not None:
+                    from_upper = torch.empty_like(to_upper)
+                    ops.append((to_upper.data_ptr(), from_upper.data_ptr(), to_upper.numel(), self.upper))
+                sets.append((ops, from_lower, from_upper))
+            plan = self._plans[key] = [sets, 0]
+        sets, turn = plan
+        plan[1] = turn ^ 1
+        return sets[turn]
+
+    def _issue(self, ops, comm, stream_ptr):
+        lib = self.lib
+        if not ops:
+            return
+        self._check(lib.ncclGroupStart())
+        for send_ptr, recv_ptr, count, peer in ops:
+            self._check(lib.ncclSend(send_ptr, count, self.NCCL_FLOAT32, peer, comm, stream_ptr))
+            self._check(lib.ncclRecv(recv_ptr, count, self.NCCL_FLOAT32, peer, comm, stream_ptr))
+        self._check(lib.ncclGroupEnd())
+
+    def __call__(self, to_lower, to_upper):
+        """Halo exchange: on the current stream, ordered with the kernels before and after it."""
+        ops, from_lower, from_upper = self._plan(to_lower, to_upper)
+        self._issue(ops, self.comms[0], C.c_void_p(self.torch.cuda.current_stream().cuda_stream))
+        return from_lower, from_upper
+
+    def start(self, to_lower, to_upper):
+        """Migration: on the side stream, after everything enqueued so far; `.finish()` makes the current stream wait."""
+        torch = self.torch
+        ops, from_lower, from_upper = self._plan(to_lower, to_upper)
+        cur = torch.cuda.current_stream()
+        if ops:
+            self.side.wait_stream(cur)
+            self._issue(ops, self.comms[1], C.c_void_p(self.side.cuda_stream))
+        side = self.side if ops else None
+
+        class _Pending:
+            def finish(_self):
+                if side is not None:
+                    torch.cuda.current_stream().wait_stream(side)
+                return from_lower, from_upper
+        return _Pending()
+
+    def selftest(self):
+        """One send + receive to this very rank inside a group on both communicators (exercises every entry point
+        this class binds; used on 1-GPU boxes where no second rank can exist)."""
+        torch = self.torch
+        a = torch.arange(1024, dtype=torch.float32, device="cuda")
+        for comm, stream in ((self.comms[0], torch.cuda.current_stream()), (self.comms[1], self.side)):
+            b = torch.zeros_like(a)
+            stream.wait_stream(torch.cuda.current_stream())
+            self._issue([(a.data_ptr(), b.data_ptr(), a.numel(), self.rank)], comm, C.c_void_p(stream.cuda_stream))
+            torch.cuda.current_stream().wait_stream(stream)
+            torch.cuda.synchronize()
+            if not bool((a == b).all()):
+                raise RuntimeError("RCCL self send/recv returned wrong data")
+        return True
+
+    def close(self):
+        for comm in self.comms:
+            self.lib.ncclCommDestroy(comm)
+        self.comms = []
+
+
 class DistExchange:
     """Neighbour exchange over torch.distributed point-to-point ops (nccl = RCCL on ROCm, gloo on CPU).
     Message = [count] then `count` records; neighbours are distinct peers, one xGMI link each."""
