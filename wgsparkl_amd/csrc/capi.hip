@@ -100,7 +100,8 @@ struct wgs_data {
     std::vector<ColliderDev> host_colliders;  // what the host last wrote (poses / velocities move on the device)
     std::vector<BodyDev> host_bodies;
     bool bodies_move = false;   // some body has a velocity or a mass: integrate_bodies runs every substep
-    bool two_way = false;       // some body is dynamic: P2G accumulates impulses
+    bool two_way = false;       // P2G accumulates the bodies' impulses: whenever a body can move (a kinematic body uses
+                                // them too: the velocity caps of rigid_impulses.wgsl:112-125 apply once it is pushed)
     SimParamsDev host_sp{};
     Events events;
     float timings[WGS_NUM_PASSES] = {0};
@@ -119,6 +120,20 @@ template <typename T> wgs_status dev_alloc(wgs_data *d, T **out, size_t count, b
     d->alloc_bytes.push_back(bytes);
     d->device_bytes += bytes;
     *out = static_cast<T *>(p);
+    return WGS_OK;
+}
+
+// Bodies that move need the impulse accumulation of P2G (rigid_impulses.wgsl reads it every substep). Sharded data
+// cannot provide it (the impulses of all ranks would have to be reduced): kinematic bodies then move without the
+// contact caps, dynamic ones are refused by the caller.
+wgs_status enable_impulses(wgs_data *d) {
+    if (d->dev.sharded || d->two_way) return WGS_OK;
+    if (!d->dev.imp_slab) {  // per-block partial node impulses
+        const size_t count = (size_t)d->dev.cap * Dim<D>::TILE * (D == 3 ? 2 : 1);
+        wgs_status st = dev_alloc(d, &d->dev.imp_slab, count);
+        if (st != WGS_OK) return st;
+    }
+    d->two_way = true;
     return WGS_OK;
 }
 
@@ -759,6 +774,7 @@ static wgs_status create_impl(wgs_pipeline *pipeline, const wgs_sim_params *para
             d->bodies_move = d->bodies_move || colliders[i].velocity.linear[k] != 0.f || colliders[i].velocity.angular[k] != 0.f;
     if (num_colliders)  // local centres of mass from the world ones (update_world_mass_properties' inverse)
         hipLaunchKernelGGL(k_bodies_refresh<D>, dim3(1), dim3(16), 0, d->stream, dev, 0xffffu);
+    if (d->bodies_move && enable_impulses(d) != WGS_OK) return bail(fail(WGS_ERR_HIP, "out of device memory for the impulse accumulators"));
 #undef H2D
     if (hipStreamSynchronize(d->stream) != hipSuccess) return bail(fail(WGS_ERR_HIP, "initial upload failed"));
     *out = d;
@@ -1037,8 +1053,13 @@ wgs_status wgs_set_body_velocities(wgs_data *d, const wgs_velocity *vels, size_t
         for (int k = 0; k < 3; k++) d->bodies_move = d->bodies_move || c.linvel[k] != 0.f || c.angvel[k] != 0.f;
     }
     static_assert(offsetof(ColliderDev, angvel) - offsetof(ColliderDev, linvel) == 12, "linvel|angvel contiguous");
+    if (d->bodies_move) {
+        wgs_status st = enable_impulses(d);
+        if (st != WGS_OK) return st;
+    }
     return upload_collider_field(d, offsetof(ColliderDev, linvel), sizeof(float) * 6, n);
 }
+
 
 wgs_status wgs_set_body_mass_properties(wgs_data *d, const wgs_mass_properties *mp, size_t n) {
     if (!d || (!mp && n)) return fail(WGS_ERR_INVALID_ARGUMENT, "NULL argument");
@@ -1056,13 +1077,11 @@ wgs_status wgs_set_body_mass_properties(wgs_data *d, const wgs_mass_properties *
     }
     if (dynamic && d->dev.sharded)
         return fail(WGS_ERR_UNSUPPORTED, "dynamic bodies on sharded data: the impulses would need a reduction over ranks");
-    if (dynamic && !d->dev.imp_slab) {  // per-block partial node impulses, only ever needed with dynamic bodies
-        const size_t count = (size_t)d->dev.cap * Dim<D>::TILE * (D == 3 ? 2 : 1);
-        wgs_status st = dev_alloc(d, &d->dev.imp_slab, count);
+    d->bodies_move = d->bodies_move || dynamic;
+    if (d->bodies_move) {
+        wgs_status st = enable_impulses(d);
         if (st != WGS_OK) return st;
     }
-    d->two_way = dynamic;
-    d->bodies_move = d->bodies_move || dynamic;
     // inv_mass | inv_inertia_local are the first 12 floats of BodyDev; local_com / world inertia stay device-owned
     static_assert(offsetof(BodyDev, local_com) == sizeof(float) * 12, "BodyDev layout");
     if (n)
