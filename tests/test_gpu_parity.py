@@ -263,7 +263,7 @@ def _random_scene(seed):
                 grid_capacity=2048, model=int(rng.integers(0, 2)))
 
 
-@pytest.mark.parametrize("seed", range(10))
+@pytest.mark.parametrize("seed", range(24))
 def test_random_scenes_match_oracle(hip_libs, oracle_libs, seed):
     """Fuzz-style parity: random materials and random collider sets (all shape kinds, kinematic and dynamic),
     12 substeps, against the fp32 oracle (same arithmetic): active cells and node affinity / sign bits exact,
@@ -290,6 +290,52 @@ def test_random_scenes_match_oracle(hip_libs, oracle_libs, seed):
         for gb, ob in zip(data.read_body_poses(), st.collider_states()):
             for key in ("rotation", "translation", "linvel", "angvel"):
                 assert np.allclose(gb[key], ob[key], rtol=0.0, atol=2e-3), (key, gb[key], ob[key])
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_random_scenes_sharded_match_single_domain(hip_libs, seed):
+    """Fuzz-style check of the decomposition: random clouds with kinematic analytic colliders cut into 2-4 slabs,
+    pipelined lockstep, against the single-domain run on the same GPU."""
+    from helpers import pipeline
+    from wgsparkl_amd.sharded import (GpuShard, SlabPartition, associated_block_x, lockstep_finish,
+                                      lockstep_pipelined_substep, split_scene)
+    rng = np.random.default_rng(500 + seed)
+    dim = 3 if seed % 2 == 0 else 2
+    world = int(rng.integers(2, 5))
+    ps = scenes.random_cloud(4000, dim=dim, seed=300 + seed, extent=22.0, young=1e6, phase=ParticlePhase(1.0, -1.0),
+                             vel_scale=2.5, perturb_F=0.02, perturb_C=0.2)
+    cols = []
+    for _ in range(int(rng.integers(0, 3))):
+        pos = tuple(float(x) for x in rng.uniform(2.0, 20.0, dim))
+        kw = dict(linvel=tuple(float(x) for x in rng.uniform(-1.0, 1.0, 3)),
+                  angvel=tuple(float(x) for x in rng.uniform(-0.5, 0.5, 3 if dim == 3 else 1)))
+        cols.append(Collider.ball(float(rng.uniform(1.0, 3.0)), pos, **kw) if rng.random() < 0.5 else
+                    Collider.cuboid(tuple(float(x) for x in rng.uniform(1.0, 4.0, dim)), pos, **kw))
+    g = (0.0, -9.81, 0.0)[:dim]
+    sc = dict(particles=ps, params=SimulationParams(gravity=g, dt=8e-4), colliders=cols, cell_width=1.0,
+              grid_capacity=4096, model=int(rng.integers(0, 2)))
+    k = 30
+    ref = run_gpu(sc, k).read_particles()
+    part = SlabPartition.balanced(associated_block_x(ps.pos, 1.0, dim), world)
+    pipe = pipeline(dim)
+    shards = []
+    for r, (sub, gids) in enumerate(split_scene(ps, part, 1.0)):
+        lo, hi = part.block_range(r)
+        shards.append(GpuShard(pipe, sc["params"], sub, gids, cols, 1.0, sc["grid_capacity"], lo, hi, r > 0, r < world - 1,
+                               particle_capacity=ps.n, model=sc["model"]))
+    pending = None
+    for _ in range(k):
+        pending = lockstep_pipelined_substep(shards, pending)
+    lockstep_finish(shards, pending)
+    for s in shards:
+        s.sync()
+    outs = [s.export() for s in shards]
+    ids = np.concatenate([o["ids"] for o in outs])
+    assert np.array_equal(np.sort(ids), np.arange(ps.n, dtype=np.uint32))
+    order = np.argsort(ids)
+    for f in ("pos", "vel"):
+        got = np.concatenate([o[f] for o in outs])[order]
+        assert rel_rms(got, getattr(ref, f)) < (1e-5 if f == "pos" else 2e-4), f
 
 
 def test_rccl_exchange_selftest(hip_libs):
