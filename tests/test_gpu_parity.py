@@ -384,6 +384,59 @@ def test_checkpoint_restart_random_scenes(hip_libs, seed):
             assert rel_rms(getattr(b, f), getattr(a, f)) < 1e-4, f
 
 
+@pytest.mark.parametrize("seed", range(6))
+def test_random_api_sequences_match_oracle(hip_libs, oracle_libs, seed):
+    """Fuzz of the per-frame host writes (src_testbed/step.rs:79-119, ui.rs:91-104) interleaved with steps: random
+    sequences of step / set_sim_params / set_body_velocities / full collider refresh, mirrored on the fp32 oracle."""
+    import dataclasses
+    from helpers import oracle, pipeline
+    from wgsparkl_amd import MpmData, _ffi
+    sc = _random_scene(seed)
+    if not sc["colliders"]:
+        sc["colliders"] = [Collider.ball(1.5, tuple([5.0] * sc["particles"].dim))]
+    dim = sc["particles"].dim
+    rng = np.random.default_rng(7000 + seed)
+    pipe = pipeline(dim)
+    args = (sc["colliders"], sc["cell_width"], sc["grid_capacity"], sc["model"])
+    data = MpmData.new(pipe, sc["params"], sc["particles"], *args)
+    st = oracle(dim, np.float32).new_state(sc["particles"], sc["params"], *args)
+    cols = list(sc["colliders"])
+    nc = len(cols)
+    for _ in range(7):
+        action = int(rng.integers(0, 4))
+        if action == 0:
+            p2 = SimulationParams(gravity=tuple(float(x) for x in rng.uniform(-10, 10, dim)), dt=float(rng.uniform(4e-4, 9e-4)))
+            data.set_sim_params(p2); st.set_params(p2)
+        elif action == 1:
+            vel = (data.T.Velocity * nc)()
+            for i in range(nc):
+                lin = [float(x) for x in rng.uniform(-1, 1, 3)]
+                ang = [float(x) for x in rng.uniform(-0.7, 0.7, 3)]
+                if dim == 2:
+                    lin[2] = 0.0; ang[1] = ang[2] = 0.0
+                vel[i].linear = tuple(lin); vel[i].angular = tuple(ang)
+                for kk in range(3):
+                    st.cols[i].linvel[kk] = lin[kk]
+                    st.cols[i].angvel[kk] = ang[kk]
+            _ffi.check(data.lib, data.lib.wgs_set_body_velocities(data._h, vel, nc))
+            st.moving = True
+        elif action == 2:
+            # full refresh from the host mirror: new poses (a small jump), velocities and mass properties
+            new = []
+            for c in cols:
+                tr = tuple(float(x + dx) for x, dx in zip(c.translation, rng.uniform(-0.2, 0.2, dim)))
+                new.append(dataclasses.replace(c, translation=tr, com=None if c.com is None else tr))
+            cols = new
+            data.set_colliders(cols); st.set_colliders(cols)
+        n_sub = int(rng.integers(1, 6))              # (action 3 = just step)
+        pipe.step(data, n_sub); st.step(n_sub)
+    data.sync()
+    got = data.read_particles()
+    same = got.cdf_affinity == st.arr["cdf_affinity"]
+    assert same.mean() > 0.98
+    assert rel_rms(got.pos[same], st.arr["pos"][same]) < 5e-5
+
+
 def test_rccl_exchange_selftest(hip_libs):
     """The transport bench.py uses for N > 1 (ncclSend / ncclRecv called directly on torch's librccl.so): two
     communicators from broadcast unique ids, a grouped send + receive on the substep stream and on the side stream.
