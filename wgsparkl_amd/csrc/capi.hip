@@ -80,6 +80,8 @@ struct wgs_data {
     bool tail_known = false;    // sharded: wgs_shard_add_migrants ran since the last substep (CTR_NPREV is current)
     uint32_t tail_slots = 0;    // sharded: upper bound of the arrivals appended behind the residents
     bool fused_halo = false;        // sharded: the caller uses wgs_shard_pack_halos / add_halos (registered with wgs_shard_register_buffers)
+    bool append_pending = false;    // sharded: wgs_shard_add_migrants recorded its buffers, the append has not run yet
+    MigIn mig{};                    // those buffers
     bool needs_compact = false;     // sharded: the counters of the compacted buffer are still to be set
     bool residents_binned = false;  // sharded: wgs_shard_bin_residents already ran k_rebin for the coming substep
     uint64_t substeps = 0;
@@ -371,7 +373,13 @@ __global__ void k_export_blocks(Dev d, uint32_t nblocks, wgs_block_record *out) 
     }
 }
 
+wgs_status flush_append(wgs_data *d);
+
 wgs_status fetch_counters(wgs_data *d) {
+    {
+        wgs_status fst = flush_append(d);  // sharded: a recorded but not yet executed migrant append
+        if (fst != WGS_OK) return fst;
+    }
     uint32_t host[CTR_COUNT];
     HIP_TRY(hipMemcpyAsync(host, d->dev.counters, sizeof(host), hipMemcpyDeviceToHost, d->stream));
     HIP_TRY(hipStreamSynchronize(d->stream));
@@ -413,6 +421,16 @@ void resolve_timings(wgs_data *d) {
                 d->timings[pass_of_mark[m]] += ms;
         }
     d->timings_pending = false;
+}
+
+// Sharded runs: run the pending append of the last migration round as a launch of its own.
+wgs_status flush_append(wgs_data *d) {
+    if (!d->append_pending) return WGS_OK;
+    d->append_pending = false;
+    hipLaunchKernelGGL(k_append_migrants<D>, dim3(std::max(1u, (d->tail_slots + 255u) / 256u)), dim3(256), 0, d->stream, d->dev,
+                       d->side, d->mig.in_lo, d->mig.in_hi, d->mig.out_lo, d->mig.out_hi, d->mig.cap);
+    HIP_TRY(hipGetLastError());
+    return WGS_OK;
 }
 
 // One substep = pipeline.rs:201-280 (MPM passes), enqueued on the data's stream.
@@ -467,11 +485,16 @@ template <bool TS> wgs_status enqueue_substep(wgs_data *d, int ts_slot, int part
         if (n > 0) {
             if (use_rebin) {
                 if (!d->residents_binned) hipLaunchKernelGGL(k_rebin<D>, dim3(pgrid), dim3(SORT_THREADS), 0, s, dev, side, epoch);
-                if (dev.sharded && d->tail_slots > 0)  // the particles that arrived from the neighbours
-                    hipLaunchKernelGGL(k_bin<D>, dim3((d->tail_slots + SORT_THREADS - 1) / SORT_THREADS), dim3(SORT_THREADS), 0, s,
-                                       dev, side, epoch, 1);
+                if (dev.sharded && d->tail_slots > 0) {  // the particles that arrived from the neighbours: append + bin
+                    const dim3 tg((d->tail_slots + SORT_THREADS - 1) / SORT_THREADS);
+                    if (d->append_pending) hipLaunchKernelGGL((k_bin<D, 2>), tg, dim3(SORT_THREADS), 0, s, dev, side, epoch, d->mig);
+                    else hipLaunchKernelGGL((k_bin<D, 1>), tg, dim3(SORT_THREADS), 0, s, dev, side, epoch, MigIn{});
+                    d->append_pending = false;
+                }
             } else {
-                hipLaunchKernelGGL(k_bin<D>, dim3(pgrid), dim3(SORT_THREADS), 0, s, dev, side, epoch, 0);
+                wgs_status fst = flush_append(d);  // (the full pass reads the appended particles from the buffer)
+                if (fst != WGS_OK) return fst;
+                hipLaunchKernelGGL((k_bin<D, 0>), dim3(pgrid), dim3(SORT_THREADS), 0, s, dev, side, epoch, MigIn{});
             }
             if (dev.n_rigid > 0) {  // blocks a mesh sample reaches must exist (sort.wgsl:38-86)
                 hipLaunchKernelGGL(k_rigid_mark<D>, dim3(grid_for(d, 1)), dim3(256), 0, s, dev, epoch);
@@ -926,11 +949,16 @@ wgs_status wgs_shard_add_migrants(wgs_data *d, const void *in_lo, const void *in
         hipLaunchKernelGGL(k_shard_compacted, dim3(1), dim3(64), 0, d->stream, d->dev);
         d->needs_compact = false;
     }
-    // append + the bookkeeping of the round, one launch (at least one workgroup even without arrivals)
-    hipLaunchKernelGGL(k_append_migrants<D>, dim3(std::max(1u, (d->tail_slots + 255u) / 256u)), dim3(256), 0, d->stream, d->dev,
-                       d->side, static_cast<const float *>(in_lo), static_cast<const float *>(in_hi),
-                       static_cast<const float *>(out_lo), static_cast<const float *>(out_hi), capacity_records);
-    HIP_TRY(hipGetLastError());
+    // The append itself rides in the next substep's tail binning launch (k_bin, tail = 2); anything that looks at the
+    // particles or the counters before that flushes it (flush_append).
+    d->mig = MigIn{static_cast<const float *>(in_lo), static_cast<const float *>(in_hi), static_cast<const float *>(out_lo),
+                   static_cast<const float *>(out_hi), capacity_records};
+    d->append_pending = true;
+    if (!in_lo && !in_hi && !out_lo && !out_hi) {  // no neighbour on either side: nobody left, nobody arrives
+        d->append_pending = false;
+        return WGS_OK;
+    }
+    if (d->tail_slots == 0) return flush_append(d);  // no inbound buffer: only the bookkeeping of the departures, now
     return WGS_OK;
 }
 
@@ -940,6 +968,10 @@ wgs_status wgs_shard_export(wgs_data *d, void *device_buf, uint32_t capacity_rec
     if (d->needs_compact) {
         hipLaunchKernelGGL(k_shard_compacted, dim3(1), dim3(64), 0, d->stream, d->dev);
         d->needs_compact = false;
+    }
+    {
+        wgs_status fst = flush_append(d);
+        if (fst != WGS_OK) return fst;
     }
     hipLaunchKernelGGL(k_clear_headers, dim3(1), dim3(64), 0, d->stream, static_cast<uint32_t *>(device_buf), (uint32_t *)nullptr);
     hipLaunchKernelGGL(k_pack_migrants<D>, dim3(grid_for(d, 4)), dim3(256), 0, d->stream, d->dev, d->side, 1,

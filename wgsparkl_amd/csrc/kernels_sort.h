@@ -65,8 +65,15 @@ __device__ inline void count_cells(const Dev &d, uint32_t *hist, int lane, uint3
 
 // sort.wgsl:26-36 touch_particle_blocks + sort.wgsl:89-99 update_block_particle_count, fused.
 // `tail`: sharded steady state — only the particles that arrived from the neighbours, slots [NPREV, N); the
-// residents go through k_rebin.
-template <int D> __global__ __launch_bounds__(SORT_THREADS) void k_bin(Dev d, int side, uint32_t epoch, int tail) {
+// residents go through k_rebin. `tail` = 2 also APPENDS them first: thread r copies record r of the two inbound
+// migration messages into slot NPREV + r and does the bookkeeping of the migration round (one launch instead of
+// append + bin).
+struct MigIn {
+    const float *in_lo, *in_hi, *out_lo, *out_hi;
+    uint32_t cap;
+};
+template <int D, int TAIL> __global__ __launch_bounds__(SORT_THREADS) void k_bin(Dev d, int side, uint32_t epoch, MigIn mig) {
+    constexpr int tail = TAIL;  // 0 = every slot, 1 = the arrivals (already appended), 2 = append + bin the arrivals
     constexpr int BS = Dim<D>::BSHIFT, BW = Dim<D>::BW, NN = Dim<D>::NNBR;
     __shared__ uint32_t s_keys[TOUCH_SET], s_ids[TOUCH_SET];
     __shared__ uint32_t s_hist[SORT_THREADS / 64][NPB];
@@ -74,8 +81,31 @@ template <int D> __global__ __launch_bounds__(SORT_THREADS) void k_bin(Dev d, in
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (tid < TOUCH_SET) s_keys[tid] = NONE;
     __syncthreads();
-    const uint32_t i = (tail ? d.counters[CTR_NPREV] : 0u) + blockIdx.x * SORT_THREADS + tid;
-    bool valid = i < num_slots(d);
+    const uint32_t first = tail ? d.counters[CTR_NPREV] : 0u;
+    const uint32_t i = first + blockIdx.x * SORT_THREADS + tid;
+    uint32_t slots_end = num_slots(d);
+    if constexpr (TAIL == 2) {
+        constexpr int NQ = Pl<D>::NQ, RF = Pl<D>::NQ * 4 + 2;  // record = quads, pid, cdf epoch (kernels_shard.h)
+        auto cnt = [&](const float *b) { return b ? min(reinterpret_cast<const uint32_t *>(b)[0], mig.cap) : 0u; };
+        const uint32_t n_lo = cnt(mig.in_lo), n_hi = cnt(mig.in_hi);
+        const uint32_t arrivals = min(n_lo + n_hi, d.n - first);  // d.n = allocated capacity in sharded mode
+        if (n_lo + n_hi > arrivals && blockIdx.x == 0 && tid == 0) atomicOr(&d.counters[CTR_ERRORS], ERRBIT_SHARD);
+        slots_end = first + arrivals;
+        if (blockIdx.x == 0 && tid == 0) {  // nothing else in this launch reads these two
+            d.counters[CTR_N] = slots_end;
+            d.counters[CTR_NV] = first - cnt(mig.out_lo) - cnt(mig.out_hi) + arrivals;
+        }
+        const uint32_t r = i - first;
+        if (r < arrivals) {
+            const float *rec = r < n_lo ? mig.in_lo + 4 + (size_t)r * RF : mig.in_hi + 4 + (size_t)(r - n_lo) * RF;
+            float *buf = d.buf[side];
+#pragma unroll
+            for (int q = 0; q < NQ; q++) stq(buf, d.npad, q, i, make_float4(rec[q * 4], rec[q * 4 + 1], rec[q * 4 + 2], rec[q * 4 + 3]));
+            stpid<D>(buf, d.npad, i, __float_as_uint(rec[NQ * 4]));
+            ststamp<D>(buf, d.npad, i, __float_as_uint(rec[NQ * 4 + 1]));
+        }
+    }
+    bool valid = i < slots_end;
     if (d.sharded && valid) valid = ldpid<D>(in, d.npad, i) != 0xffffffffu;  // slot vacated by a migrated particle
     int b[3] = {0, 0, 0};
     uint32_t key = NONE, local = 0;
@@ -145,7 +175,7 @@ template <int D> __global__ __launch_bounds__(SORT_THREADS) void k_bin(Dev d, in
     // ---- 3. count per cell
     uint32_t cid = NONE, rank = 0;
     count_cells(d, s_hist[wave], lane, myid, local, cid, rank);
-    if (i < num_slots(d)) {
+    if (i < slots_end) {
         d.cellid[i] = cid;
         d.rank[i] = rank;
     }

@@ -122,6 +122,12 @@ def finish_migration(backend, pending):
     backend.add_migrants(in_lower, in_upper)
 
 
+def _transported(buf):
+    """What a transport does: the receiver gets its own copy of the message (the sender resets and refills its
+    outgoing buffer in its next substep, possibly before the receiver has consumed the message)."""
+    return buf.clone() if hasattr(buf, "clone") else buf.copy()
+
+
 def lockstep_substep(backends: List):
     """All ranks inside ONE process (tests, single-GPU emulation of the decomposition): runs the
     phases of every rank in lockstep and routes the messages directly."""
@@ -135,7 +141,7 @@ def lockstep_substep(backends: List):
         b.step_end()
     mig = [b.pack_migrants() for b in backends]
     for r, b in enumerate(backends):
-        b.add_migrants(mig[r - 1][1] if r > 0 else None, mig[r + 1][0] if r < n - 1 else None)
+        b.add_migrants(_transported(mig[r - 1][1]) if r > 0 else None, _transported(mig[r + 1][0]) if r < n - 1 else None)
 
 
 def lockstep_pipelined_substep(backends: List, pending):
@@ -155,7 +161,7 @@ def lockstep_pipelined_substep(backends: List, pending):
     for b in backends:
         b.step_end()
     mig = [b.pack_migrants() for b in backends]
-    return [(mig[r - 1][1] if r > 0 else None, mig[r + 1][0] if r < n - 1 else None) for r in range(n)]
+    return [(_transported(mig[r - 1][1]) if r > 0 else None, _transported(mig[r + 1][0]) if r < n - 1 else None) for r in range(n)]
 
 
 def lockstep_finish(backends: List, pending):
