@@ -45,6 +45,46 @@ def test_struct_layouts(hip_libs, dim, size):
     assert C.sizeof(T.BlockRecord) == 4 * (dim + 2)
 
 
+@pytest.mark.parametrize("dim", [2, 3])
+def test_ctypes_structs_match_the_c_header(hip_libs, dim, tmp_path):
+    """sizeof / offsetof of every struct of include/wgsparkl_hip.h as gcc sees it against the ctypes twin."""
+    import subprocess
+    _, T = hip_libs.load(dim)
+    fields = {
+        "wgs_particle": ("Particle", ["position", "dynamics", "model", "has_plasticity", "plasticity", "has_phase", "phase"]),
+        "wgs_collider": ("Collider", ["shape_type", "shape", "pose", "velocity", "com"]),
+        "wgs_pose": ("Pose", ["rotation", "translation", "scale"]),
+        "wgs_velocity": ("Velocity", ["linear", "angular"]),
+        "wgs_mass_properties": ("MassProperties", ["inv_mass", "inv_inertia_local"]),
+        "wgs_sim_params": ("SimParams", ["gravity", "dt"]),
+        "wgs_node_record": ("NodeRecord", ["cell", "velocity", "mass", "cdf_distance", "cdf_affinities", "cdf_closest_id"]),
+        "wgs_block_record": ("BlockRecord", ["virtual_id", "first_particle", "num_particles"]),
+        "wgs_stats": ("Stats", ["num_particles", "num_active_blocks", "grid_capacity", "overflow", "substeps_done", "device_bytes"]),
+    }
+    lines = ['#include <stdio.h>', '#include <stddef.h>', f'#define WGS_DIM {dim}', '#include "wgsparkl_hip.h"', 'int main(void) {']
+    for cname, (_, fs) in fields.items():
+        lines.append(f'  printf("{cname} %zu", sizeof({cname}));')
+        for f in fs:
+            lines.append(f'  printf(" %zu", offsetof({cname}, {f}));')
+        lines.append('  printf("\\n");')
+    lines += ['  printf("wgs_instance %zu\\n", sizeof(wgs_instance));', '  printf("wgs_sample_ids %zu\\n", sizeof(wgs_sample_ids));',
+              '  printf("wgs_plastic_state %zu\\n", sizeof(wgs_plastic_state));', '  return 0; }']
+    src = tmp_path / "abi.c"
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "abi"
+    inc = os.path.join(ROOT, "include")
+    subprocess.run(["gcc", "-std=c11", f"-I{inc}", str(src), "-o", str(exe)], check=True)
+    out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.strip().splitlines()
+    seen = {l.split()[0]: [int(x) for x in l.split()[1:]] for l in out}
+    for cname, (tname, fs) in fields.items():
+        ct = getattr(T, tname)
+        assert seen[cname][0] == C.sizeof(ct), cname
+        offs = [getattr(ct, {"lambda": "lambda_"}.get(f, f)).offset for f in fs]
+        assert seen[cname][1:] == offs, (cname, seen[cname][1:], offs)
+    assert seen["wgs_instance"] == [96] and seen["wgs_sample_ids"] == [16]
+    assert seen["wgs_plastic_state"] == [C.sizeof(T.PlasticState)]
+
+
 def test_no_cpu_fallback(hip_libs):
     import torch
     if torch.cuda.is_available():
