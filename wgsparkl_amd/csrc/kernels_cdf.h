@@ -187,6 +187,118 @@ template <int N> __device__ inline float det_small(const float *m) {
     }
 }
 
+// g2p_cdf.wgsl:39-250 for one particle (`src` = its slot in the buffer): affinity / sign bits, distance and normal
+// from the node cdfs of its block's tile (LDS image s_cdf, tile origin = block coordinates bc). Writes the
+// particle's cdf quads and stamps them with the substep.
+template <int D> __device__ inline void particle_cdf_update(const Dev &d, float *buf, uint32_t src, const NodeCdf *s_cdf, const int *bc,
+                                                            uint32_t epoch) {
+    constexpr int BW = Dim<D>::BW, TW = Dim<D>::TW;
+    constexpr int N = D + 1;
+    using P = Pl<D>;
+    const uint32_t npad = d.npad;
+    const float h = d.h, inv_h = d.inv_h;
+    const bool any = true;
+    float nrm[D], dist = 0.f;
+    uint32_t aff = 0u;
+#pragma unroll
+    for (int k = 0; k < D; k++) nrm[k] = 0.f;
+    if (any) {
+        const float4 xm = ldq(buf, npad, P::XM, src);
+        const float4 cprev = ldq(buf, npad, D == 3 ? (int)P::CDF1 : (int)P::CDF0, src);
+        // previous affinity (sign persistence, g2p_cdf.wgsl:183-190): only if computed last substep
+        const uint32_t prev = ldstamp<D>(buf, npad, src) == epoch - 1u ? __float_as_uint(cprev.w) : 0u;
+        float x[D], ref[D], w[D][3];
+        x[0] = xm.x; x[1] = xm.y;
+        if constexpr (D == 3) x[2] = xm.z;
+        int tbase = 0, stride = 1;
+#pragma unroll
+        for (int k = 0; k < D; k++) {
+            int c = assoc_cell(x[k], h);
+            ref[k] = (float)c * h - x[k];
+            eval_all(-ref[k] * inv_h, w[k]);
+            tbase += (c - bc[k] * BW) * stride;
+            stride *= TW;
+        }
+        // pass 1 (g2p_cdf.wgsl:150-181): union of affinities, sign vote per collider
+        float signs[16];
+#pragma unroll
+        for (int c = 0; c < 16; c++) signs[c] = 0.f;
+        constexpr int SZN = D == 3 ? 3 : 1;
+        for (int sz = 0; sz < SZN; sz++)
+            for (int sy = 0; sy < 3; sy++)
+                for (int sx = 0; sx < 3; sx++) {
+                    NodeCdf nc = s_cdf[tbase + sx + TW * sy + (D == 3 ? TW * TW * sz : 0)];
+                    aff |= nc.affinities & 0xffffu;
+                    float wgt = w[0][sx] * w[1][sy];
+                    if constexpr (D == 3) wgt *= w[2][sz];
+                    if (nc.affinities & 0xffffu) {
+#pragma unroll
+                        for (int c = 0; c < 16; c++) {
+                            float compatible = (nc.affinities >> c) & 1u ? 1.f : 0.f;
+                            float sign = (nc.affinities >> (16 + c)) & 1u ? -1.f : 1.f;
+                            signs[c] += compatible * wgt * sign * nc.distance;
+                        }
+                    }
+                }
+#pragma unroll
+        for (int c = 0; c < 16; c++) {
+            uint32_t mask = 1u << (c + 16);
+            if ((prev & (1u << c)) == 0u) aff |= signs[c] < 0.f ? mask : 0u;
+            else aff |= prev & mask;
+        }
+        // pass 2 (g2p_cdf.wgsl:192-231): weighted least squares for (grad d, d)
+        float qtq[N * N], qtu[N];
+#pragma unroll
+        for (int k = 0; k < N * N; k++) qtq[k] = 0.f;
+#pragma unroll
+        for (int k = 0; k < N; k++) qtu[k] = 0.f;
+        for (int sz = 0; sz < SZN; sz++)
+            for (int sy = 0; sy < 3; sy++)
+                for (int sx = 0; sx < 3; sx++) {
+                    NodeCdf nc = s_cdf[tbase + sx + TW * sy + (D == 3 ? TW * TW * sz : 0)];
+                    uint32_t combined = nc.affinities & aff & 0xffffu;
+                    if (combined == 0u) continue;
+                    uint32_t sdiff = ((nc.affinities >> 16) ^ (aff >> 16)) & combined;
+                    float wgt = w[0][sx] * w[1][sy];
+                    float pv[N];
+                    pv[0] = ref[0] + (float)sx * h;
+                    pv[1] = ref[1] + (float)sy * h;
+                    if constexpr (D == 3) {
+                        wgt *= w[2][sz];
+                        pv[2] = ref[2] + (float)sz * h;
+                    }
+                    pv[D] = 1.f;
+                    float dd = sdiff == 0u ? nc.distance : -nc.distance;
+#pragma unroll
+                    for (int c = 0; c < N; c++)
+#pragma unroll
+                        for (int r = 0; r < N; r++) qtq[c * N + r] += (pv[r] * pv[c]) * wgt;
+#pragma unroll
+                    for (int r = 0; r < N; r++) qtu[r] += pv[r] * wgt * dd;
+                }
+        if (det_small<N>(qtq) > 1.0e-8f) {
+            solve_spd<N>(qtq, qtu);
+            float n2 = 0.f;
+#pragma unroll
+            for (int k = 0; k < D; k++) n2 += qtu[k] * qtu[k];
+            float len = sqrtf(n2);
+#pragma unroll
+            for (int k = 0; k < D; k++) nrm[k] = (D == 2 && !(len > 1.0e-6f)) ? 0.f : qtu[k] / len;
+            dist = qtu[D];
+        } else {
+            aff = 0u;  // default_cdf()
+        }
+    }
+    if constexpr (D == 3) {
+        stq(buf, npad, P::CDF0, src, make_float4(nrm[0], nrm[1], nrm[2], dist));
+        stq(buf, npad, P::CDF1, src, make_float4(0.f, 0.f, 0.f, __uint_as_float(aff)));
+    } else {
+        stq(buf, npad, P::CDF0, src, make_float4(nrm[0], nrm[1], dist, __uint_as_float(aff)));
+        stq(buf, npad, P::CDF1, src, make_float4(0.f, 0.f, 0.f, 0.f));
+    }
+    ststamp<D>(buf, npad, src, epoch);
+}
+
 // The three CDF passes of a substep in ONE launch, one single-wave workgroup per active block (every active
 // block is in flight at once; the pass costs one dependent-load chain):
 //   1. node cdf of the block's (BW+2)^D tile — its own nodes and the +1 rim. The rim belongs to the
@@ -259,108 +371,7 @@ template <int D> __global__ __launch_bounds__(CDF_THREADS) void k_cdf(Dev d, int
             if (any && cnt > 0) d.cpic_list[atomicAdd(&d.counters[CTR_NCPIC], 1u)] = b;  // few blocks
         }
         if (!any) continue;
-        for (uint32_t j = start + tid; j < start + cnt; j += CDF_THREADS) {
-            const uint32_t src = d.perm[j];
-            float nrm[D], dist = 0.f;
-            uint32_t aff = 0u;
-#pragma unroll
-            for (int k = 0; k < D; k++) nrm[k] = 0.f;
-            if (any) {
-                const float4 xm = ldq(buf, npad, P::XM, src);
-                const float4 cprev = ldq(buf, npad, D == 3 ? (int)P::CDF1 : (int)P::CDF0, src);
-                // previous affinity (sign persistence, g2p_cdf.wgsl:183-190): only if computed last substep
-                const uint32_t prev = ldstamp<D>(buf, npad, src) == epoch - 1u ? __float_as_uint(cprev.w) : 0u;
-                float x[D], ref[D], w[D][3];
-                x[0] = xm.x; x[1] = xm.y;
-                if constexpr (D == 3) x[2] = xm.z;
-                int tbase = 0, stride = 1;
-#pragma unroll
-                for (int k = 0; k < D; k++) {
-                    int c = assoc_cell(x[k], h);
-                    ref[k] = (float)c * h - x[k];
-                    eval_all(-ref[k] * inv_h, w[k]);
-                    tbase += (c - bc[k] * BW) * stride;
-                    stride *= TW;
-                }
-                // pass 1 (g2p_cdf.wgsl:150-181): union of affinities, sign vote per collider
-                float signs[16];
-#pragma unroll
-                for (int c = 0; c < 16; c++) signs[c] = 0.f;
-                constexpr int SZN = D == 3 ? 3 : 1;
-                for (int sz = 0; sz < SZN; sz++)
-                    for (int sy = 0; sy < 3; sy++)
-                        for (int sx = 0; sx < 3; sx++) {
-                            NodeCdf nc = s_cdf[tbase + sx + TW * sy + (D == 3 ? TW * TW * sz : 0)];
-                            aff |= nc.affinities & 0xffffu;
-                            float wgt = w[0][sx] * w[1][sy];
-                            if constexpr (D == 3) wgt *= w[2][sz];
-                            if (nc.affinities & 0xffffu) {
-#pragma unroll
-                                for (int c = 0; c < 16; c++) {
-                                    float compatible = (nc.affinities >> c) & 1u ? 1.f : 0.f;
-                                    float sign = (nc.affinities >> (16 + c)) & 1u ? -1.f : 1.f;
-                                    signs[c] += compatible * wgt * sign * nc.distance;
-                                }
-                            }
-                        }
-#pragma unroll
-                for (int c = 0; c < 16; c++) {
-                    uint32_t mask = 1u << (c + 16);
-                    if ((prev & (1u << c)) == 0u) aff |= signs[c] < 0.f ? mask : 0u;
-                    else aff |= prev & mask;
-                }
-                // pass 2 (g2p_cdf.wgsl:192-231): weighted least squares for (grad d, d)
-                float qtq[N * N], qtu[N];
-#pragma unroll
-                for (int k = 0; k < N * N; k++) qtq[k] = 0.f;
-#pragma unroll
-                for (int k = 0; k < N; k++) qtu[k] = 0.f;
-                for (int sz = 0; sz < SZN; sz++)
-                    for (int sy = 0; sy < 3; sy++)
-                        for (int sx = 0; sx < 3; sx++) {
-                            NodeCdf nc = s_cdf[tbase + sx + TW * sy + (D == 3 ? TW * TW * sz : 0)];
-                            uint32_t combined = nc.affinities & aff & 0xffffu;
-                            if (combined == 0u) continue;
-                            uint32_t sdiff = ((nc.affinities >> 16) ^ (aff >> 16)) & combined;
-                            float wgt = w[0][sx] * w[1][sy];
-                            float pv[N];
-                            pv[0] = ref[0] + (float)sx * h;
-                            pv[1] = ref[1] + (float)sy * h;
-                            if constexpr (D == 3) {
-                                wgt *= w[2][sz];
-                                pv[2] = ref[2] + (float)sz * h;
-                            }
-                            pv[D] = 1.f;
-                            float dd = sdiff == 0u ? nc.distance : -nc.distance;
-#pragma unroll
-                            for (int c = 0; c < N; c++)
-#pragma unroll
-                                for (int r = 0; r < N; r++) qtq[c * N + r] += (pv[r] * pv[c]) * wgt;
-#pragma unroll
-                            for (int r = 0; r < N; r++) qtu[r] += pv[r] * wgt * dd;
-                        }
-                if (det_small<N>(qtq) > 1.0e-8f) {
-                    solve_spd<N>(qtq, qtu);
-                    float n2 = 0.f;
-#pragma unroll
-                    for (int k = 0; k < D; k++) n2 += qtu[k] * qtu[k];
-                    float len = sqrtf(n2);
-#pragma unroll
-                    for (int k = 0; k < D; k++) nrm[k] = (D == 2 && !(len > 1.0e-6f)) ? 0.f : qtu[k] / len;
-                    dist = qtu[D];
-                } else {
-                    aff = 0u;  // default_cdf()
-                }
-            }
-            if constexpr (D == 3) {
-                stq(buf, npad, P::CDF0, src, make_float4(nrm[0], nrm[1], nrm[2], dist));
-                stq(buf, npad, P::CDF1, src, make_float4(0.f, 0.f, 0.f, __uint_as_float(aff)));
-            } else {
-                stq(buf, npad, P::CDF0, src, make_float4(nrm[0], nrm[1], dist, __uint_as_float(aff)));
-                stq(buf, npad, P::CDF1, src, make_float4(0.f, 0.f, 0.f, 0.f));
-            }
-            ststamp<D>(buf, npad, src, epoch);
-        }
+        for (uint32_t j = start + tid; j < start + cnt; j += CDF_THREADS) particle_cdf_update<D>(d, buf, d.perm[j], s_cdf, bc, epoch);
     }
 }
 
