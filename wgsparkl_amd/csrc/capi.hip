@@ -451,6 +451,7 @@ template <bool TS> wgs_status enqueue_substep(wgs_data *d, int ts_slot, int part
     // block (k_rebin: no hash lookups except for the few particles that changed block). The full k_bin runs
     // on the first substep, on table-rebuild substeps and in sharded runs (particles arrive from neighbours).
     const bool rehash = d->substeps % REHASH_PERIOD == 0;
+    const bool fused_cdf = d->cpic && dev.n_rigid == 0 && !(dev.dbg & 1024u);  // (mesh cdfs are only complete after k_p2g_cdf)
     const bool use_rebin = d->prev_sorted && !rehash && !(dev.dbg & 128u) && (!dev.sharded || d->tail_known || part == 3);
     if (dev.sharded && d->needs_compact && part != 2) {
         hipLaunchKernelGGL(k_shard_compacted, dim3(1), dim3(64), 0, s, dev);
@@ -501,7 +502,10 @@ template <bool TS> wgs_status enqueue_substep(wgs_data *d, int ts_slot, int part
                 hipLaunchKernelGGL(k_rigid_touch<D>, dim3(grid_for(d, 1)), dim3(256), 0, s, dev, epoch);
             }
             hipLaunchKernelGGL(k_scan_active, dim3(1), dim3(SCAN_THREADS), 0, s, dev, epoch);
-            hipLaunchKernelGGL(k_block_setup<D>, dim3(grid_for(d, 4)), dim3(SORT_THREADS), 0, s, dev, epoch);
+            // collider simulations without mesh colliders: node cdf + block classes ride in this launch, the particle
+            // cdf in the CPIC P2G launch (no CDF launch at all)
+            if (fused_cdf) hipLaunchKernelGGL((k_block_setup<D, true>), dim3(grid_for(d, 4)), dim3(SORT_THREADS), 0, s, dev, epoch);
+            else hipLaunchKernelGGL((k_block_setup<D, false>), dim3(grid_for(d, 4)), dim3(SORT_THREADS), 0, s, dev, epoch);
             hipLaunchKernelGGL(k_scatter<D>, dim3(pgrid), dim3(SORT_THREADS), 0, s, dev, side);
             if (d->deterministic)
                 hipLaunchKernelGGL(k_canonical_order, dim3(grid_for(d, 4)), dim3(SORT_THREADS), 0, s, dev);
@@ -513,7 +517,7 @@ template <bool TS> wgs_status enqueue_substep(wgs_data *d, int ts_slot, int part
         // (kernels_cdf.h); the reference's two pass names share its time in wgs_read_timings
         if (dev.n_rigid > 0 && n > 0)  // "p2g_cdf": mesh primitives -> node cdf accumulators
             hipLaunchKernelGGL(k_p2g_cdf<D>, dim3(grid_for(d, 1)), dim3(256), 0, s, dev, epoch);
-        if (d->cpic && n > 0)
+        if (d->cpic && n > 0 && !fused_cdf)
             hipLaunchKernelGGL(k_cdf<D>, dim3(grid_for(d, 16)), dim3(CDF_THREADS), 0, s, dev, side, epoch);
         mark(2);
         mark(3);
@@ -521,11 +525,13 @@ template <bool TS> wgs_status enqueue_substep(wgs_data *d, int ts_slot, int part
             // ---- "p2g"
             const dim3 p2g_grid(grid_for(d, 5)), p2g_block(P2GCfg<D>::NW * 64);
             if (d->cpic) {
-                hipLaunchKernelGGL((k_p2g<D, false>), p2g_grid, p2g_block, 0, s, dev, side, 1);
-                if (d->two_way) hipLaunchKernelGGL((k_p2g<D, true, true>), p2g_grid, p2g_block, 0, s, dev, side, 2);
-                else hipLaunchKernelGGL((k_p2g<D, true>), p2g_grid, p2g_block, 0, s, dev, side, 2);
+                hipLaunchKernelGGL((k_p2g<D, false>), p2g_grid, p2g_block, 0, s, dev, side, 1, epoch);
+                if (d->two_way && fused_cdf) hipLaunchKernelGGL((k_p2g<D, true, true, true>), p2g_grid, p2g_block, 0, s, dev, side, 2, epoch);
+                else if (d->two_way) hipLaunchKernelGGL((k_p2g<D, true, true>), p2g_grid, p2g_block, 0, s, dev, side, 2, epoch);
+                else if (fused_cdf) hipLaunchKernelGGL((k_p2g<D, true, false, true>), p2g_grid, p2g_block, 0, s, dev, side, 2, epoch);
+                else hipLaunchKernelGGL((k_p2g<D, true>), p2g_grid, p2g_block, 0, s, dev, side, 2, epoch);
             } else {
-                hipLaunchKernelGGL((k_p2g<D, false>), p2g_grid, p2g_block, 0, s, dev, side, 0);
+                hipLaunchKernelGGL((k_p2g<D, false>), p2g_grid, p2g_block, 0, s, dev, side, 0, epoch);
             }
         }
         mark(4);

@@ -18,7 +18,7 @@
 //     inside a cell is canonical (ascending persistent particle id), so every downstream
 //     fp32 sum is reproducible run to run (reference: atomic race order, sort.wgsl:126,133).
 #pragma once
-#include "device_math.h"
+#include "kernels_cdf.h"
 
 namespace wgs {
 
@@ -310,7 +310,10 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan_active(Dev d, uint32_t ep
 
 // Per active block, one wave: neighbour links (replaces the per-thread hash lookups of
 // p2g.wgsl:238-275 / g2p.wgsl:72-132), per-cell offsets, and reset of the accumulators.
-template <int D> __global__ __launch_bounds__(SORT_THREADS) void k_block_setup(Dev d, uint32_t epoch) {
+// CDF (collider simulations without mesh colliders): also the node cdf of the block's (BW+2)^D tile and the class of
+// the block (see k_cdf, whose steps 1 and 2 these are; step 3 then runs in the prologue of the CPIC P2G launch), so
+// that a collider simulation needs no CDF launch of its own.
+template <int D, bool CDF> __global__ __launch_bounds__(SORT_THREADS) void k_block_setup(Dev d, uint32_t epoch) {
     constexpr int NN = Dim<D>::NNBR;
     const uint32_t B = min(d.counters[CTR_NBLOCKS], d.cap);
     const int lane = threadIdx.x & 63;
@@ -318,12 +321,12 @@ template <int D> __global__ __launch_bounds__(SORT_THREADS) void k_block_setup(D
     const uint32_t nwaves = (gridDim.x * SORT_THREADS) >> 6;
     for (uint32_t a = wave; a < B; a += nwaves) {
         const uint32_t id = d.active[a];
+        uint32_t res = NONE;
+        int b[3] = {0, 0, 0};
+        unpack_key<D>(d.block_key[id], b);
         if (lane < 16) {
             const uint32_t o = lane & 7u;
             const bool minus = lane >= 8;
-            int b[3] = {0, 0, 0};
-            unpack_key<D>(d.block_key[id], b);
-            uint32_t res = NONE;
             if ((int)o < NN) {
                 const int sgn = minus ? -1 : 1;
                 int nb[3] = {b[0] + sgn * (int)(o & 1u), b[1] + sgn * (int)((o >> 1) & 1u), b[2] + sgn * (int)((o >> 2) & 1u)};
@@ -352,6 +355,29 @@ template <int D> __global__ __launch_bounds__(SORT_THREADS) void k_block_setup(D
             d.links_epoch[id] = epoch;     // the neighbour links written above are those of this substep
             d.block_acc[id] = 0;
             d.block_cdf_flag[id] = 0;
+        }
+        if constexpr (CDF) {
+            constexpr int BW = Dim<D>::BW, BS = Dim<D>::BSHIFT, TW = Dim<D>::TW, TILE = Dim<D>::TILE;
+            uint32_t mine = 0u;
+            for (int n = lane; n < ((TILE + 63) / 64) * 64; n += 64) {
+                int t[3] = {n % TW, (n / TW) % TW, D == 3 ? n / (TW * TW) : 0};
+                const int o = (t[0] >= BW ? 1 : 0) | (t[1] >= BW ? 2 : 0) | (t[2] >= BW ? 4 : 0);
+                const uint32_t nb = __shfl(res, o & 7);        // "+" links live in lanes 0..7
+                if (n < TILE && nb != NONE) {                  // nodes of blocks that are not active do not exist
+                    float pt[D];
+#pragma unroll
+                    for (int k = 0; k < D; k++) pt[k] = (float)(b[k] * BW + t[k]) * d.h;
+                    const NodeCdf c = node_cdf_eval<D>(d, pt);
+                    if (o == 0) d.node_cdf[(size_t)id * NPB + (t[0] + (t[1] << BS) + (D == 3 ? (t[2] << (2 * BS)) : 0))] = c;
+                    mine |= c.affinities;
+                }
+            }
+            const bool any = __ballot(mine != 0u) != 0ull;
+            const uint32_t total = __shfl(inc, 63);
+            if (lane == 0) {
+                d.block_cpic[id] = any ? 1u : 0u;
+                if (any && total > 0u) d.cpic_list[atomicAdd(&d.counters[CTR_NCPIC], 1u)] = id;  // few blocks
+            }
         }
     }
 }

@@ -43,8 +43,10 @@ template <> struct P2GCfg<2> {
 // as an impulse on the node's closest body (p2g.wgsl:200-228), per node, in a second LDS tile; the
 // per-block partial node sums go to imp_slab and are gathered, converted to fixed point and added to the
 // bodies by the grid update (p2g.wgsl:142-155).
-template <int D, bool CPIC, bool TWOWAY = false>
-__global__ __launch_bounds__(P2GCfg<D>::NW * 64) void k_p2g(Dev d, int side, int filter) {
+// PCDF (with CPIC): the particle cdf of the block's particles (g2p_cdf.wgsl) is computed in the prologue, from the
+// node cdfs k_block_setup<CDF> left in node_cdf — the third step of k_cdf without a launch of its own.
+template <int D, bool CPIC, bool TWOWAY = false, bool PCDF = false>
+__global__ __launch_bounds__(P2GCfg<D>::NW * 64) void k_p2g(Dev d, int side, int filter, uint32_t epoch) {
     using Cfg = P2GCfg<D>;
     constexpr int BW = Dim<D>::BW, BS = Dim<D>::BSHIFT, TW = Dim<D>::TW, TILE = Dim<D>::TILE;
     constexpr int NT = Cfg::NW * 64;
@@ -58,6 +60,7 @@ __global__ __launch_bounds__(P2GCfg<D>::NW * 64) void k_p2g(Dev d, int side, int
     __shared__ uint32_t s_cs[NPB], s_cn[NPB];
     constexpr int IMPQ = D == 3 ? 2 : 1;  // impulse quads per node: (lin, 0), (ang, 0) | (lin.xy, ang, 0)
     __shared__ float4 s_nrm[TWOWAY ? P2G_J * ROW : 1];
+    __shared__ NodeCdf s_ncdf[PCDF ? TILE : 1];
     __shared__ float4 s_imp[TWOWAY ? Cfg::NW : 1][TWOWAY ? IMPQ : 1][TWOWAY ? TILE : 1];
 
     const float *in = d.buf[side];
@@ -84,6 +87,23 @@ __global__ __launch_bounds__(P2GCfg<D>::NW * 64) void k_p2g(Dev d, int side, int
         const uint32_t cs = d.cell_start[b * NPB + cell];
         const uint32_t cn = d.cell_cursor[b * NPB + cell] - cs;
         __syncthreads();  // previous block fully consumed
+        if constexpr (PCDF) {
+            for (int n = tid; n < TILE; n += NT) {
+                const int tt[3] = {n % TW, (n / TW) % TW, D == 3 ? n / (TW * TW) : 0};
+                const int o = (tt[0] >= BW ? 1 : 0) | (tt[1] >= BW ? 2 : 0) | (tt[2] >= BW ? 4 : 0);
+                const int ln = (tt[0] & (BW - 1)) + ((tt[1] & (BW - 1)) << BS) + (D == 3 ? ((tt[2] & (BW - 1)) << (2 * BS)) : 0);
+                const uint32_t nb = d.nbr_plus[b * 8u + o];
+                NodeCdf c = {0.f, 0u, NONE, 0u};
+                if (nb != NONE) c = d.node_cdf[(size_t)nb * NPB + ln];
+                s_ncdf[n] = c;
+            }
+            __syncthreads();
+            const uint32_t bstart = d.block_start[b];
+            for (uint32_t j = bstart + tid; j < bstart + cnt; j += NT)
+                particle_cdf_update<D>(d, d.buf[side], d.perm[j], s_ncdf, bc, epoch);
+            __threadfence_block();
+            __syncthreads();  // the affinities written above are fetched below by other threads of the workgroup
+        }
         if (tid < NPB) {
             s_cs[cell] = cs;
             s_cn[cell] = cn;
