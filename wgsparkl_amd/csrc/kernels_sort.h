@@ -359,6 +359,28 @@ template <int D, bool CDF> __global__ __launch_bounds__(SORT_THREADS) void k_blo
         if constexpr (CDF) {
             constexpr int BW = Dim<D>::BW, BS = Dim<D>::BSHIFT, TW = Dim<D>::TW, TILE = Dim<D>::TILE;
             uint32_t mine = 0u;
+            // Quick reject, wave-uniform: a collider whose boundary is farther from the tile's centre than the tile's
+            // half diagonal plus the affinity reach (1.5 h per axis) touches none of its nodes, and a centre outside
+            // the shape then means every node is outside. One projection per collider instead of (BW+2)^D.
+            bool near = false;
+            {
+                float ctr[D];
+#pragma unroll
+                for (int k = 0; k < D; k++) ctr[k] = ((float)(b[k] * BW) + 0.5f * (float)(TW - 1)) * d.h;
+                const float reach = (0.5f * (float)(TW - 1) + 1.5f) * d.h * (D == 3 ? 1.7320508f : 1.4142136f) * 1.001f;
+                for (uint32_t i = 0; i < d.n_colliders && i < 16u; i++) {
+                    const ColliderDev &c = d.colliders[i];
+                    if (c.shape_type >= 3u) continue;
+                    float pl[D], projl[D], proj[D];
+                    pose_to_local<D>(c, ctr, pl);
+                    const bool inside = project_local_on_boundary<D>(c, pl, projl);
+                    pose_to_world<D>(c, projl, proj);
+                    float n2 = 0.f;
+#pragma unroll
+                    for (int k = 0; k < D; k++) n2 += (proj[k] - ctr[k]) * (proj[k] - ctr[k]);
+                    near = near || inside || !(n2 > reach * reach);
+                }
+            }
             for (int n = lane; n < ((TILE + 63) / 64) * 64; n += 64) {
                 int t[3] = {n % TW, (n / TW) % TW, D == 3 ? n / (TW * TW) : 0};
                 const int o = (t[0] >= BW ? 1 : 0) | (t[1] >= BW ? 2 : 0) | (t[2] >= BW ? 4 : 0);
@@ -367,7 +389,8 @@ template <int D, bool CDF> __global__ __launch_bounds__(SORT_THREADS) void k_blo
                     float pt[D];
 #pragma unroll
                     for (int k = 0; k < D; k++) pt[k] = (float)(b[k] * BW + t[k]) * d.h;
-                    const NodeCdf c = node_cdf_eval<D>(d, pt);
+                    const NodeCdf far_cdf = {1.0e10f, 0u, NONE, 0u};
+                    const NodeCdf c = near ? node_cdf_eval<D>(d, pt) : far_cdf;
                     if (o == 0) d.node_cdf[(size_t)id * NPB + (t[0] + (t[1] << BS) + (D == 3 ? (t[2] << (2 * BS)) : 0))] = c;
                     mine |= c.affinities;
                 }
