@@ -228,6 +228,20 @@ class FixedExchange:
         return _PendingExchange(works, from_lower, from_upper)
 
 
+class _PendingOnStream:
+    """Result of RcclExchange.start: `.finish()` makes the current stream wait for the side stream the transfer runs on."""
+    __slots__ = ("torch", "side", "from_lower", "from_upper")
+
+    def __init__(self, torch, side, from_lower, from_upper):
+        self.torch, self.side, self.from_lower, self.from_upper = torch, side, from_lower, from_upper
+
+    def finish(self):
+        if self.side is not None:
+            self.torch.cuda.current_stream().wait_stream(self.side)
+            self.side = None
+        return self.from_lower, self.from_upper
+
+
 class RcclExchange:
     """The same fixed-size neighbour exchange as FixedExchange, issued straight on RCCL (`ncclSend` / `ncclRecv` inside
     one group per exchange, through ctypes on the librccl.so that torch itself loaded) instead of through
@@ -323,14 +337,7 @@ class RcclExchange:
         if ops:
             self.side.wait_stream(cur)
             self._issue(ops, self.comms[1], C.c_void_p(self.side.cuda_stream))
-        side = self.side if ops else None
-
-        class _Pending:
-            def finish(_self):
-                if side is not None:
-                    torch.cuda.current_stream().wait_stream(side)
-                return from_lower, from_upper
-        return _Pending()
+        return _PendingOnStream(self.torch, self.side if ops else None, from_lower, from_upper)
 
     def selftest(self):
         """One send + receive to this very rank inside a group on both communicators (exercises every entry point
