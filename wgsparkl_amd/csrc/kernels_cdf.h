@@ -314,7 +314,6 @@ constexpr int CDF_THREADS = 64;
 template <int D> __global__ __launch_bounds__(CDF_THREADS) void k_cdf(Dev d, int side, uint32_t epoch) {
     constexpr int BW = Dim<D>::BW, BS = Dim<D>::BSHIFT, TW = Dim<D>::TW, TILE = Dim<D>::TILE, NN = Dim<D>::NNBR;
     constexpr int N = D + 1;
-    using P = Pl<D>;
     __shared__ NodeCdf s_cdf[TILE];
     __shared__ uint32_t s_any[2];
     float *buf = d.buf[side];
