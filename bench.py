@@ -117,6 +117,7 @@ def main():
                 exch = RcclExchange(dist, rank, world)
                 if os.environ.get("WGS_BENCH_FORCE_SHARDED") == "1":
                     exch.selftest()
+                exch.neighbour_test()
             except Exception as e:  # noqa: BLE001 — any failure here means "use the torch transport", on every rank
                 print(f"[bench rank {rank}] direct RCCL transport unavailable ({e}); using torch.distributed p2p", file=sys.stderr)
                 exch = None

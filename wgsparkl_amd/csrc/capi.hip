@@ -88,6 +88,7 @@ struct wgs_data {
     uint64_t device_bytes = 0;
     uint32_t sticky_errors = 0;
     uint32_t last_nblocks = 0;
+    uint32_t last_ncpic = UINT32_MAX;  // near-collider list length at the last wgs_sync (sizes the list half of k_g2p_pair)
     uint32_t capacity = 0;      // particle slots allocated
     uint32_t *shard_counts = nullptr;  // device scratch for pack kernels
     std::vector<void *> allocs;
@@ -156,6 +157,7 @@ void fill_collider(ColliderDev &c, const wgs_collider &in) {
     for (int k = 0; k < 3; k++) c.com[k] = in.com[k];
 }
 
+constexpr uint32_t PCDF_LAUNCH_MIN_BLOCKS = 48;  // near-collider blocks from which the particle cdf gets its own launch
 int grid_for(const wgs_data *d, int blocks_per_cu) { return d->pipeline->num_cus * blocks_per_cu; }
 
 // ---- read-back kernels ---------------------------------------------------
@@ -384,6 +386,8 @@ wgs_status fetch_counters(wgs_data *d) {
     HIP_TRY(hipMemcpyAsync(host, d->dev.counters, sizeof(host), hipMemcpyDeviceToHost, d->stream));
     HIP_TRY(hipStreamSynchronize(d->stream));
     d->last_nblocks = host[CTR_NBLOCKS] < d->dev.cap ? host[CTR_NBLOCKS] : d->dev.cap;
+    d->last_ncpic = host[CTR_NCPIC] < d->dev.cap ? host[CTR_NCPIC] : d->dev.cap;
+    if (d->dev.dbg & 16384u) fprintf(stderr, "[wgs] active blocks %u, near-collider blocks %u\n", d->last_nblocks, d->last_ncpic);
     d->sticky_errors |= host[CTR_ERRORS];
     if (host[CTR_NBLOCKS] > d->dev.cap) d->sticky_errors |= ERRBIT_OVERFLOW;
     return WGS_OK;
@@ -504,9 +508,12 @@ template <bool TS> wgs_status enqueue_substep(wgs_data *d, int ts_slot, int part
             hipLaunchKernelGGL(k_scan_active, dim3(1), dim3(SCAN_THREADS), 0, s, dev, epoch);
             // collider simulations without mesh colliders: node cdf + block classes ride in this launch, the particle
             // cdf in the CPIC P2G launch (no CDF launch at all)
-            if (fused_cdf) hipLaunchKernelGGL((k_block_setup<D, true>), dim3(grid_for(d, 4)), dim3(SORT_THREADS), 0, s, dev, epoch);
-            else hipLaunchKernelGGL((k_block_setup<D, false>), dim3(grid_for(d, 4)), dim3(SORT_THREADS), 0, s, dev, epoch);
-            hipLaunchKernelGGL(k_scatter<D>, dim3(pgrid), dim3(SORT_THREADS), 0, s, dev, side);
+            {
+                const uint32_t nsetup = (uint32_t)grid_for(d, 4);
+                const dim3 g(nsetup + (uint32_t)pgrid);
+                if (fused_cdf) hipLaunchKernelGGL((k_setup_scatter<D, true>), g, dim3(SORT_THREADS), 0, s, dev, side, epoch, nsetup);
+                else hipLaunchKernelGGL((k_setup_scatter<D, false>), g, dim3(SORT_THREADS), 0, s, dev, side, epoch, nsetup);
+            }
             if (d->deterministic)
                 hipLaunchKernelGGL(k_canonical_order, dim3(grid_for(d, 4)), dim3(SORT_THREADS), 0, s, dev);
         } else {
@@ -526,9 +533,17 @@ template <bool TS> wgs_status enqueue_substep(wgs_data *d, int ts_slot, int part
             const dim3 p2g_grid(grid_for(d, 5)), p2g_block(P2GCfg<D>::NW * 64);
             if (d->cpic) {
                 hipLaunchKernelGGL((k_p2g<D, false>), p2g_grid, p2g_block, 0, s, dev, side, 1, epoch);
-                if (d->two_way && fused_cdf) hipLaunchKernelGGL((k_p2g<D, true, true, true>), p2g_grid, p2g_block, 0, s, dev, side, 2, epoch);
+                // particle cdf of the near-collider blocks: in the prologue of the CPIC P2G launch while the list is
+                // short (one workgroup per block, no launch), as a chip-wide launch of its own once the host has seen
+                // a long list (kernels_transfer.h: k_particle_cdf)
+                const bool pcdf_launch = fused_cdf && d->last_ncpic != UINT32_MAX && d->last_ncpic >= PCDF_LAUNCH_MIN_BLOCKS && !(dev.dbg & 8192u);
+                if (pcdf_launch)
+                    hipLaunchKernelGGL(k_particle_cdf<D>, dim3(8, std::min((uint32_t)grid_for(d, 1) * 3u / 2u, std::max(32u, 2u * d->last_ncpic))),
+                                       dim3(64), 0, s, dev, side, epoch);
+                const bool pcdf_fused = fused_cdf && !pcdf_launch;
+                if (d->two_way && pcdf_fused) hipLaunchKernelGGL((k_p2g<D, true, true, true>), p2g_grid, p2g_block, 0, s, dev, side, 2, epoch);
                 else if (d->two_way) hipLaunchKernelGGL((k_p2g<D, true, true>), p2g_grid, p2g_block, 0, s, dev, side, 2, epoch);
-                else if (fused_cdf) hipLaunchKernelGGL((k_p2g<D, true, false, true>), p2g_grid, p2g_block, 0, s, dev, side, 2, epoch);
+                else if (pcdf_fused) hipLaunchKernelGGL((k_p2g<D, true, false, true>), p2g_grid, p2g_block, 0, s, dev, side, 2, epoch);
                 else hipLaunchKernelGGL((k_p2g<D, true>), p2g_grid, p2g_block, 0, s, dev, side, 2, epoch);
             } else {
                 hipLaunchKernelGGL((k_p2g<D, false>), p2g_grid, p2g_block, 0, s, dev, side, 0, epoch);
@@ -557,7 +572,15 @@ template <bool TS> wgs_status enqueue_substep(wgs_data *d, int ts_slot, int part
                        dim3(G2P_THREADS), 0, s, dev, side, epoch)
 #define WGS_LAUNCH_G2P_MP(MODEL, PL)        \
     do {                                    \
-        if (d->cpic) {                      \
+        if (d->cpic && !(dev.dbg & 4096u)) {                                                                      \
+            /* both bodies in one launch (k_g2p_pair) */                                                          \
+            /* list workgroups: 2 x the list length the host last saw (unknown: the whole chip) */                 \
+            const uint32_t full = (uint32_t)grid_for(d, 1) * 3u / 2u;                                             \
+            const uint32_t nlist = d->last_ncpic == UINT32_MAX ? full : std::min(full, std::max(32u, 2u * d->last_ncpic)); \
+            hipLaunchKernelGGL((k_g2p_pair<D, MODEL, PL>), dim3((uint32_t)g + 8u * nlist), dim3(G2P_THREADS), 0, s, \
+                               dev, side, epoch, (uint32_t)g, nlist);                                             \
+            mark(6);                                                                                              \
+        } else if (d->cpic) {               \
             WGS_LAUNCH_G2P(MODEL, PL, 1);   \
             mark(6);                        \
             WGS_LAUNCH_G2P(MODEL, PL, 2);   \

@@ -220,40 +220,51 @@ template <int D> __device__ inline void particle_cdf_update(const Dev &d, float 
             stride *= TW;
         }
         // pass 1 (g2p_cdf.wgsl:150-181): union of affinities, sign vote per collider
-        float signs[16];
-#pragma unroll
-        for (int c = 0; c < 16; c++) signs[c] = 0.f;
         constexpr int SZN = D == 3 ? 3 : 1;
+#pragma unroll
         for (int sz = 0; sz < SZN; sz++)
+#pragma unroll
             for (int sy = 0; sy < 3; sy++)
-                for (int sx = 0; sx < 3; sx++) {
-                    NodeCdf nc = s_cdf[tbase + sx + TW * sy + (D == 3 ? TW * TW * sz : 0)];
-                    aff |= nc.affinities & 0xffffu;
-                    float wgt = w[0][sx] * w[1][sy];
-                    if constexpr (D == 3) wgt *= w[2][sz];
-                    if (nc.affinities & 0xffffu) {
 #pragma unroll
-                        for (int c = 0; c < 16; c++) {
-                            float compatible = (nc.affinities >> c) & 1u ? 1.f : 0.f;
-                            float sign = (nc.affinities >> (16 + c)) & 1u ? -1.f : 1.f;
-                            signs[c] += compatible * wgt * sign * nc.distance;
-                        }
+                for (int sx = 0; sx < 3; sx++) aff |= s_cdf[tbase + sx + TW * sy + (D == 3 ? TW * TW * sz : 0)].affinities & 0xffffu;
+        // The vote of collider c is sum over the nodes of compatible * w * sign * distance (one accumulator per
+        // collider in the reference). Only colliders some lane of the wave has an affinity with are visited — scenes
+        // have one or two in reach, not 16 —, and a node that is not compatible with c adds an exact zero, so it is
+        // skipped: the sums are bit-identical to the 16-accumulator form.
+        uint32_t voters = 0u;
+#pragma unroll
+        for (int c = 0; c < 16; c++) voters |= __ballot((aff >> c) & 1u) != 0ull ? (1u << c) : 0u;
+        for (uint32_t vm = voters; vm != 0u; vm &= vm - 1u) {  // wave-uniform
+            const int c = __ffs((int)vm) - 1;
+            float vote = 0.f;
+#pragma unroll
+            for (int sz = 0; sz < SZN; sz++)
+#pragma unroll
+                for (int sy = 0; sy < 3; sy++)
+#pragma unroll
+                    for (int sx = 0; sx < 3; sx++) {
+                        const NodeCdf nc = s_cdf[tbase + sx + TW * sy + (D == 3 ? TW * TW * sz : 0)];
+                        float wgt = w[0][sx] * w[1][sy];
+                        if constexpr (D == 3) wgt *= w[2][sz];
+                        if ((nc.affinities >> c) & 1u) vote += (((nc.affinities >> (16 + c)) & 1u) ? -wgt : wgt) * nc.distance;
                     }
-                }
-#pragma unroll
-        for (int c = 0; c < 16; c++) {
-            uint32_t mask = 1u << (c + 16);
-            if ((prev & (1u << c)) == 0u) aff |= signs[c] < 0.f ? mask : 0u;
+            const uint32_t mask = 1u << (c + 16);
+            if ((prev & (1u << c)) == 0u) aff |= vote < 0.f ? mask : 0u;
             else aff |= prev & mask;
         }
+        // (colliders nobody voted on: vote = 0, so only a persisting sign bit of the previous substep can be set)
+        aff |= prev & (prev << 16) & ~(voters << 16) & 0xffff0000u;
         // pass 2 (g2p_cdf.wgsl:192-231): weighted least squares for (grad d, d)
         float qtq[N * N], qtu[N];
 #pragma unroll
         for (int k = 0; k < N * N; k++) qtq[k] = 0.f;
 #pragma unroll
         for (int k = 0; k < N; k++) qtu[k] = 0.f;
+#pragma unroll
         for (int sz = 0; sz < SZN; sz++)
+#pragma unroll
             for (int sy = 0; sy < 3; sy++)
+#pragma unroll
                 for (int sx = 0; sx < 3; sx++) {
                     NodeCdf nc = s_cdf[tbase + sx + TW * sy + (D == 3 ? TW * TW * sz : 0)];
                     uint32_t combined = nc.affinities & aff & 0xffffu;
@@ -272,10 +283,14 @@ template <int D> __device__ inline void particle_cdf_update(const Dev &d, float 
 #pragma unroll
                     for (int c = 0; c < N; c++)
 #pragma unroll
-                        for (int r = 0; r < N; r++) qtq[c * N + r] += (pv[r] * pv[c]) * wgt;
+                        for (int r = 0; r <= c; r++) qtq[c * N + r] += (pv[r] * pv[c]) * wgt;  // (symmetric: mirrored below)
 #pragma unroll
                     for (int r = 0; r < N; r++) qtu[r] += pv[r] * wgt * dd;
                 }
+#pragma unroll
+        for (int c = 0; c < N; c++)
+#pragma unroll
+            for (int r = c + 1; r < N; r++) qtq[c * N + r] = qtq[r * N + c];  // same products, same order: bit-identical
         if (det_small<N>(qtq) > 1.0e-8f) {
             solve_spd<N>(qtq, qtu);
             float n2 = 0.f;

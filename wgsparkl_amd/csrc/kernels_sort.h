@@ -313,12 +313,12 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan_active(Dev d, uint32_t ep
 // CDF (collider simulations without mesh colliders): also the node cdf of the block's (BW+2)^D tile and the class of
 // the block (see k_cdf, whose steps 1 and 2 these are; step 3 then runs in the prologue of the CPIC P2G launch), so
 // that a collider simulation needs no CDF launch of its own.
-template <int D, bool CDF> __global__ __launch_bounds__(SORT_THREADS) void k_block_setup(Dev d, uint32_t epoch) {
+template <int D, bool CDF> __device__ __forceinline__ void block_setup_body(const Dev &d, uint32_t epoch, uint32_t wg, uint32_t nwg) {
     constexpr int NN = Dim<D>::NNBR;
     const uint32_t B = min(d.counters[CTR_NBLOCKS], d.cap);
     const int lane = threadIdx.x & 63;
-    const uint32_t wave = (blockIdx.x * SORT_THREADS + threadIdx.x) >> 6;
-    const uint32_t nwaves = (gridDim.x * SORT_THREADS) >> 6;
+    const uint32_t wave = (wg * SORT_THREADS + threadIdx.x) >> 6;
+    const uint32_t nwaves = (nwg * SORT_THREADS) >> 6;
     for (uint32_t a = wave; a < B; a += nwaves) {
         const uint32_t id = d.active[a];
         uint32_t res = NONE;
@@ -344,8 +344,8 @@ template <int D, bool CDF> __global__ __launch_bounds__(SORT_THREADS) void k_blo
         }
         const uint32_t start = d.block_start[id] + inc - cnt;
         d.cell_start[idx] = start;
-        d.cell_cursor[idx] = start + cnt;  // cell end
-        d.cell_count[idx] = 0;             // accumulators are zero at rest
+        d.cell_cursor[idx] = start + cnt;  // cell end (cell_count itself is cleared by k_grid_update: the scatter
+                                           // half of this launch still reads it)
         if (d.n_rigid != 0u) {             // mesh-collider cdf accumulators of this substep (k_p2g_cdf)
             d.mesh_min[idx] = ~0ull;
             d.mesh_aff[idx] = 0u;
@@ -408,15 +408,44 @@ template <int D, bool CDF> __global__ __launch_bounds__(SORT_THREADS) void k_blo
 // sort.wgsl:117-127 finalize_particles_sort (the sorted-ids half). Also writes the particle
 // ids in sorted order (= the reference's sorted_particle_ids) so that the canonical-order
 // pass reads them contiguously instead of gathering through `perm`.
-template <int D> __global__ __launch_bounds__(SORT_THREADS) void k_scatter(Dev d, int side) {
-    uint32_t i = blockIdx.x * SORT_THREADS + threadIdx.x;
-    if (i >= num_slots(d)) return;
-    uint32_t cid = d.cellid[i];
+// The cell offsets are recomputed here from the cell counts (one coalesced 256-byte read + a wave scan per distinct
+// block of the wave: one to three blocks in a sorted buffer) instead of read from cell_start, so that this pass does
+// not depend on the block setup and shares its launch. Wave-uniform control flow: call with all 64 lanes.
+template <int D> __device__ __forceinline__ void scatter_body(const Dev &d, int side, uint32_t i, uint32_t *offs) {
+    const int lane = threadIdx.x & 63;
+    uint32_t cid = NONE;
+    if (i < num_slots(d)) cid = d.cellid[i];
+    const uint32_t myid = cid == NONE ? NONE : cid / NPB;
+    uint32_t start = 0;
+    unsigned long long todo = __ballot(myid != NONE);
+    while (todo) {
+        const int leader = __ffsll((long long)todo) - 1;
+        const uint32_t id0 = __shfl(myid, leader);
+        const bool mine = myid == id0;
+        todo &= ~__ballot(mine);
+        const uint32_t cnt = d.cell_count[id0 * NPB + lane];
+        uint32_t inc = cnt;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t v = __shfl_up(inc, off);
+            if (lane >= off) inc += v;
+        }
+        __hip_atomic_store(&offs[lane], d.block_start[id0] + inc - cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+        if (mine) start = __hip_atomic_load(&offs[cid % NPB], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+    }
     if (cid == NONE) return;
-    const uint32_t r = d.cell_start[cid] + d.rank[i];
+    const uint32_t r = start + d.rank[i];
     d.perm[r] = i;
     d.perm_cell[r] = cid;
     d.perm_pid[r] = ldpid<D>(d.buf[side], d.npad, i);
+}
+
+// Block setup and scatter in ONE launch: both only need the scan (active list, block_start) and the cell counts. The
+// first `nsetup` workgroups run the (longer) per-block setup, the others scatter 256 particles each.
+template <int D, bool CDF> __global__ __launch_bounds__(SORT_THREADS) void k_setup_scatter(Dev d, int side, uint32_t epoch, uint32_t nsetup) {
+    __shared__ uint32_t s_offs[SORT_THREADS / 64][64];
+    if (blockIdx.x < nsetup) block_setup_body<D, CDF>(d, epoch, blockIdx.x, nsetup);
+    else scatter_body<D>(d, side, (blockIdx.x - nsetup) * SORT_THREADS + threadIdx.x, s_offs[threadIdx.x >> 6]);
 }
 
 // Canonical order inside each cell: ascending persistent particle id. One thread per cell.

@@ -359,6 +359,41 @@ __global__ __launch_bounds__(P2GCfg<D>::NW * 64) void k_p2g(Dev d, int side, int
     }
 }
 
+// Particle cdf (g2p_cdf.wgsl:39-250) of the near-collider blocks as a launch of its own: one wave per 64 sorted
+// particles of a listed block (blockIdx.y strides the list, blockIdx.x the chunks a block spans), node cdfs of the
+// block's tile staged in LDS. The prologue of the CPIC P2G does the same work with ONE workgroup per block, which is the
+// right trade while the list is short (no launch); with hundreds of listed blocks that serial per-block loop is what
+// the substep waits for, and this launch spreads it over the chip (capi.hip chooses by the list length the host last saw).
+template <int D> __global__ __launch_bounds__(64) void k_particle_cdf(Dev d, int side, uint32_t epoch) {
+    constexpr int BW = Dim<D>::BW, BS = Dim<D>::BSHIFT, TW = Dim<D>::TW, TILE = Dim<D>::TILE;
+    __shared__ NodeCdf s_ncdf[TILE];
+    const int tid = threadIdx.x;
+    const uint32_t L = min(d.counters[CTR_NCPIC], d.cap);
+    for (uint32_t a = blockIdx.y; a < L; a += gridDim.y) {
+        const uint32_t b = d.cpic_list[a];
+        const uint32_t start = d.block_start[b], cnt = d.block_count[b];
+        const uint32_t first = start / 64u + blockIdx.x, last = (start + cnt - 1u) / 64u;
+        if (first > last) continue;  // (wave-uniform)
+        int bc[3] = {0, 0, 0};
+        unpack_key<D>(d.block_key[b], bc);
+        __syncthreads();  // single-wave workgroup: orders the reuse of the tile
+        for (int n = tid; n < TILE; n += 64) {
+            const int tt[3] = {n % TW, (n / TW) % TW, D == 3 ? n / (TW * TW) : 0};
+            const int o = (tt[0] >= BW ? 1 : 0) | (tt[1] >= BW ? 2 : 0) | (tt[2] >= BW ? 4 : 0);
+            const int ln = (tt[0] & (BW - 1)) + ((tt[1] & (BW - 1)) << BS) + (D == 3 ? ((tt[2] & (BW - 1)) << (2 * BS)) : 0);
+            const uint32_t nb = d.nbr_plus[b * 8u + o];
+            NodeCdf c = {0.f, 0u, NONE, 0u};
+            if (nb != NONE) c = d.node_cdf[(size_t)nb * NPB + ln];
+            s_ncdf[n] = c;
+        }
+        __syncthreads();
+        for (uint32_t chunk = first; chunk <= last; chunk += gridDim.x) {
+            const uint32_t j = chunk * 64u + (uint32_t)tid;
+            if (j >= start && j < start + cnt) particle_cdf_update<D>(d, d.buf[side], d.perm[j], s_ncdf, bc, epoch);
+        }
+    }
+}
+
 // ------------------------------------------------------------ grid update
 // Gather of the slabs covering each node + solver/grid_update.wgsl:55-64.
 // PHASE 0: gather + update in one pass (single GPU). Sharded runs: PHASE 3 = the same single pass, except that the
@@ -392,6 +427,14 @@ template <int D, int PHASE, bool TWOWAY = false> __global__ __launch_bounds__(25
     const float dt = d.sp->dt;
     const float lim = d.h / dt;
     float g[3] = {d.sp->gravity[0], d.sp->gravity[1], d.sp->gravity[2]};
+    // Two-way coupling: the node impulses are summed per body in LDS first (integers: any order gives the same sum) and
+    // leave the workgroup as at most 16 x 6 global atomics. One atomic per node and component instead serialises at the
+    // memory side: 40 k of them on a dozen addresses took 290 us in a scene whose cube rests on the floor.
+    __shared__ int32_t s_body_imp[TWOWAY ? 128 : 1];
+    if constexpr (TWOWAY) {
+        if (threadIdx.x < 128) s_body_imp[threadIdx.x] = 0;
+        __syncthreads();
+    }
     for (uint32_t t = blockIdx.x * 256 + threadIdx.x; t < total; t += gridDim.x * 256) {
         const uint32_t b = d.active[t >> 6], ln = t & 63u;
         const uint32_t node = b * NPB + ln;
@@ -447,7 +490,7 @@ template <int D, int PHASE, bool TWOWAY = false> __global__ __launch_bounds__(25
 #pragma unroll
                 for (int k = 0; k < NI; k++) {
                     const int32_t v = flt2int(isum[k]);
-                    if (v != 0) atomicAdd(&d.impulses[cl * 8u + k], v);
+                    if (v != 0) atomicAdd(&s_body_imp[cl * 8u + k], v);
                 }
             }
         }
@@ -455,6 +498,7 @@ template <int D, int PHASE, bool TWOWAY = false> __global__ __launch_bounds__(25
             d.nodes[node] = sum;
             continue;
         }
+        d.cell_count[node] = 0;  // the sort's per-cell accumulators are zero at rest (last read: k_setup_scatter)
         if constexpr (PHASE == 2) sum = d.nodes[node];
         if constexpr (PHASE == 3) {
             if (from_nodes) sum = d.nodes[node];
@@ -477,6 +521,13 @@ template <int D, int PHASE, bool TWOWAY = false> __global__ __launch_bounds__(25
         for (int o = 0; o < NN; o++)
             if (srcs[o] != NONE) d.slab[(size_t)srcs[o] * TILE + tis[o]] = nv;
         d.nodes[node] = nv;
+    }
+    if constexpr (TWOWAY) {
+        __syncthreads();
+        if (threadIdx.x < 128) {
+            const int32_t v = s_body_imp[threadIdx.x];
+            if (v != 0) atomicAdd(&d.impulses[threadIdx.x], v);
+        }
     }
 }
 
@@ -503,378 +554,64 @@ constexpr int G2P_THREADS = 64;
 // CMODE 2 walks the (short) list of blocks near a collider instead: blockIdx.y strides the list, blockIdx.x the
 // chunks a block spans, and only that block's particles are processed; the launch is nearly free while no
 // particle is near a collider.
-#define G2P_DONE                               \
-    {                                          \
-        if constexpr (CMODE == 2) continue;    \
-        else return;                           \
+#define G2P_DONE                                   \
+    {                                              \
+        if constexpr (G2P_CMODE == 2) continue;    \
+        else return;                               \
     }
 template <int D, int MODEL, bool PLASTIC, int CMODE>
 __global__ __launch_bounds__(G2P_THREADS, G2P_WAVES_PER_EU) void k_g2p_update(Dev d, int side, uint32_t epoch) {
-    constexpr bool CPIC = CMODE == 2;
-    constexpr int BW = Dim<D>::BW, BS = Dim<D>::BSHIFT, TW = Dim<D>::TW, TILE = Dim<D>::TILE, NN = Dim<D>::NNBR;
-    constexpr int DD = D * D;
-    using P = Pl<D>;
-    __shared__ float4 s_node[TILE];
-    __shared__ NodeCdf s_cdf[CPIC ? TILE : 1];
+    __shared__ float4 s_node[Dim<D>::TILE];
+    __shared__ NodeCdf s_cdf[CMODE == 2 ? Dim<D>::TILE : 1];
+#define G2P_CMODE CMODE
+#define G2P_BX blockIdx.x
+#define G2P_BY blockIdx.y
+#define G2P_GX gridDim.x
+#define G2P_GY gridDim.y
+#include "g2p_body.inc"
+#undef G2P_CMODE
+#undef G2P_BX
+#undef G2P_BY
+#undef G2P_GX
+#undef G2P_GY
+}
 
-    const float *in = d.buf[side];
-    float *out = d.buf[side ^ 1];
-    const uint32_t npad = d.npad;
-    const float h = d.h, inv_h = d.inv_h;
-    const float dt = d.sp->dt;
-    const float invd = 4.0f / (h * h);  // kernel.wgsl:56-58
-    const int tid = threadIdx.x;
-
-    // XCD-aware chunk mapping (CMODE 0 / 1): workgroups are dealt round-robin to the 8 XCDs (blockIdx % 8), each
-    // with its own L2. Give every XCD one contiguous eighth of the sorted particles, so that the ~8 waves
-    // that share a block (and therefore its node tile) hit the same L2 instead of eight different ones.
-    uint32_t chunk = (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3);
-    uint32_t only = NONE, list_a = blockIdx.y, c_next = 1u, c_last = 0u;
-    for (;;) {
-        if constexpr (CMODE == 2) {
-            if (c_next > c_last) {  // next block of the list
-                if (list_a >= min(d.counters[CTR_NCPIC], d.cap)) break;
-                only = d.cpic_list[list_a];
-                list_a += gridDim.y;
-                const uint32_t start = d.block_start[only], cnt = d.block_count[only];
-                c_next = start / G2P_THREADS + blockIdx.x;
-                c_last = (start + cnt - 1u) / G2P_THREADS;
-                continue;
-            }
-            chunk = c_next;
-            c_next += gridDim.x;
-        }
-
-        const uint32_t j = chunk * G2P_THREADS + tid;  // slot in sorted order = output index
-        const bool valid = j < num_valid(d);
-        const uint32_t src = valid ? d.perm[j] : 0u;
-        const uint32_t cid = valid ? d.perm_cell[j] : NONE;  // physical block id * 64 + cell in block
-        uint32_t myblock = cid == NONE ? NONE : (cid >> 6);
-        if constexpr (CMODE == 1) {
-            // lanes whose block belongs to the other launch drop out before touching particle state
-            if (myblock != NONE && d.block_cpic[myblock] != 0u) myblock = NONE;
-            if (__ballot(myblock != NONE) == 0ull) G2P_DONE;
-        }
-        if constexpr (CMODE == 2) {
-            if (myblock != only) myblock = NONE;
-        }
-
-        // Particle state: issued before the tile staging so both latencies overlap.
-        float x[D], Fm[DD], mass, vol0, lambda, mu;
-        if constexpr (D == 3) {
-            const float4 xm = ldq(in, npad, P::XM, src);
-            const float4 f0 = ldq(in, npad, P::F0, src), f1 = ldq(in, npad, P::F1, src), f2 = ldq(in, npad, P::F2, src);
-            x[0] = xm.x; x[1] = xm.y; x[2] = xm.z; mass = xm.w;
-            Fm[0] = f0.x; Fm[1] = f0.y; Fm[2] = f0.z; Fm[3] = f0.w;
-            Fm[4] = f1.x; Fm[5] = f1.y; Fm[6] = f1.z; Fm[7] = f1.w;
-            Fm[8] = f2.x; vol0 = f2.y; lambda = f2.z; mu = f2.w;
-        } else {
-            const float4 xm = ldq(in, npad, P::XM, src);
-            const float4 f0 = ldq(in, npad, P::F0, src);
-            const float4 vl = ldq(in, npad, P::CV2, src);
-            x[0] = xm.x; x[1] = xm.y; mass = xm.z; vol0 = xm.w;
-            Fm[0] = f0.x; Fm[1] = f0.y; Fm[2] = f0.z; Fm[3] = f0.w;
-            lambda = vl.z; mu = vl.w;
-        }
-        const uint32_t pid = ldpid<D>(in, npad, src);
-
-        float pvel[D], nrm[D], sdist = 0.f;
-        uint32_t paff = 0;
-        if constexpr (CPIC) {
-            const float4 c0 = ldq(in, npad, P::CDF0, src);
-            nrm[0] = c0.x; nrm[1] = c0.y;
-            if constexpr (D == 3) {
-                const float4 cv = ldq(in, npad, P::CV2, src);
-                const float4 c1 = ldq(in, npad, P::CDF1, src);
-                nrm[2] = c0.z; sdist = c0.w; paff = __float_as_uint(c1.w);
-                pvel[0] = cv.y; pvel[1] = cv.z; pvel[2] = cv.w;
-            } else {
-                const float4 vl = ldq(in, npad, P::CV2, src);
-                sdist = c0.z; paff = __float_as_uint(c0.w);
-                pvel[0] = vl.x; pvel[1] = vl.y;
-            }
-        }
-
-        if (d.dbg & 64u) {  // ablation: memory traffic of the kernel without tile staging / maths
-            if (valid) {
-                if constexpr (D == 3) {
-                    stq(out, npad, P::XM, j, make_float4(x[0], x[1], x[2], mass));
-                    stq(out, npad, P::CV0, j, make_float4(Fm[0], Fm[1], Fm[2], Fm[3]));
-                    stq(out, npad, P::CV1, j, make_float4(Fm[4], Fm[5], Fm[6], Fm[7]));
-                    stq(out, npad, P::CV2, j, make_float4(Fm[8], x[0], x[1], x[2]));
-                    stq(out, npad, P::F0, j, make_float4(Fm[0], Fm[1], Fm[2], Fm[3]));
-                    stq(out, npad, P::F1, j, make_float4(Fm[4], Fm[5], Fm[6], Fm[7]));
-                    stq(out, npad, P::F2, j, make_float4(Fm[8], vol0, lambda, mu));
-                }
-                stpid<D>(out, npad, j, pid);
-            }
-            G2P_DONE;
-        }
-        unsigned long long todo = __ballot(myblock != NONE);
-        while (todo) {  // wave-uniform: one iteration per distinct block among the 64 particles (1 or 2)
-            const int leader = __ffsll((long long)todo) - 1;
-            const uint32_t b = __shfl(myblock, leader);
-            const bool mine = myblock == b;
-            todo &= ~__ballot(mine);
-            int bc[3] = {0, 0, 0};
-            unpack_key<D>(d.block_key[b], bc);
-            __syncthreads();  // single-wave workgroup: orders the LDS tile reuse
-            // g2p.wgsl:72-132: velocities of the block's nodes and of its +1 rim -> LDS tile. The grid
-            // update left them as a contiguous per-block tile (slab), so this is one coalesced read.
-            for (int n = tid; n < TILE; n += G2P_THREADS) {
-                s_node[n] = d.slab[(size_t)b * TILE + n];
-                if constexpr (CPIC) {
-                    int t[3];
-                    t[0] = n % TW;
-                    t[1] = (n / TW) % TW;
-                    t[2] = D == 3 ? n / (TW * TW) : 0;
-                    int o = (t[0] >= BW ? 1 : 0) | (t[1] >= BW ? 2 : 0) | (t[2] >= BW ? 4 : 0);
-                    int ln = (t[0] & (BW - 1)) + ((t[1] & (BW - 1)) << BS) + (D == 3 ? ((t[2] & (BW - 1)) << (2 * BS)) : 0);
-                    uint32_t nb = d.nbr_plus[b * 8u + o];
-                    NodeCdf cdf = {0.f, 0u, NONE, 0u};
-                    if (nb != NONE) cdf = d.node_cdf[(size_t)nb * NPB + ln];
-                    s_cdf[n] = cdf;
-                }
-            }
-            __syncthreads();
-
-            if (mine) {
-                // ---- G2P (g2p.wgsl:150-218)
-                // The associated cell comes from the sort (perm_cell = block * 64 + cell in block, computed
-                // by k_bin from this very position with the bit-exact rule), so no fp32 division here.
-                float ref[D], w[D][3];
-                int tbase = 0;
-                {
-                    const uint32_t lc = cid & 63u;
-                    int lcell[3] = {(int)(lc & (BW - 1)), (int)((lc >> BS) & (BW - 1)), D == 3 ? (int)(lc >> (2 * BS)) : 0};
-                    int stride = 1;
-    #pragma unroll
-                    for (int k = 0; k < D; k++) {
-                        ref[k] = (float)(bc[k] * BW + lcell[k]) * h - x[k];
-                        eval_all(-ref[k] * inv_h, w[k]);
-                        tbase += lcell[k] * stride;
-                        stride *= TW;
-                    }
-                }
-                float vel[D], grad[DD];
-                constexpr int SZN = D == 3 ? 3 : 1;
-                if constexpr (!CPIC) {
-                    // Tensor-product evaluation of
-                    //   v = sum_n w_n v_n ,  G_c = sum_n w_n s_c(n) v_n   (s = node offset in {0,1,2}^D)
-                    // reducing along x, then y, then z: ~240 VALU instead of ~570 for the 27 direct terms.
-                    // grad = inv_d * sum_n w_n v_n (x) (ref + s h) = inv_d * (v (x) ref + h * [G_x G_y G_z]).
-                    float G[D][D];  // G[c][r]
-    #pragma unroll
-                    for (int k = 0; k < D; k++) vel[k] = 0.f;
-    #pragma unroll
-                    for (int c = 0; c < D; c++)
-    #pragma unroll
-                        for (int r = 0; r < D; r++) G[c][r] = 0.f;
-                    const float wx1 = w[0][1], wx2 = 2.0f * w[0][2];
-    #pragma unroll 1
-                    for (int sz = 0; sz < SZN; sz++) {
-                        float Pz[D], Gxz[D], Gyz[D];
-    #pragma unroll
-                        for (int k = 0; k < D; k++) { Pz[k] = 0.f; Gxz[k] = 0.f; Gyz[k] = 0.f; }
-    #pragma unroll
-                        for (int sy = 0; sy < 3; sy++) {
-                            const int idx = tbase + TW * sy + (D == 3 ? TW * TW * sz : 0);
-                            const float4 n0 = s_node[idx], n1 = s_node[idx + 1], n2 = s_node[idx + 2];
-                            float a0[3] = {n0.x, n0.y, n0.z}, a1[3] = {n1.x, n1.y, n1.z}, a2[3] = {n2.x, n2.y, n2.z};
-                            const float wy = w[1][sy];
-    #pragma unroll
-                            for (int k = 0; k < D; k++) {
-                                const float p = w[0][0] * a0[k] + w[0][1] * a1[k] + w[0][2] * a2[k];
-                                const float gx = wx1 * a1[k] + wx2 * a2[k];
-                                Pz[k] += wy * p;
-                                Gxz[k] += wy * gx;
-                                if (sy > 0) Gyz[k] += ((float)sy * wy) * p;
-                            }
-                        }
-                        float wz = 1.f;
-                        if constexpr (D == 3) wz = sz == 0 ? w[2][0] : (sz == 1 ? w[2][1] : w[2][2]);
-    #pragma unroll
-                        for (int k = 0; k < D; k++) {
-                            vel[k] += wz * Pz[k];
-                            G[0][k] += wz * Gxz[k];
-                            G[1][k] += wz * Gyz[k];
-                            if constexpr (D == 3) G[2][k] += ((float)sz * wz) * Pz[k];
-                        }
-                    }
-    #pragma unroll
-                    for (int c = 0; c < D; c++)
-    #pragma unroll
-                        for (int r = 0; r < D; r++) grad[c * D + r] = invd * (vel[r] * ref[c] + h * G[c][r]);
-                } else {
-    #pragma unroll
-                    for (int k = 0; k < D; k++) vel[k] = 0.f;
-    #pragma unroll
-                    for (int k = 0; k < DD; k++) grad[k] = 0.f;
-                    // The z loop is kept rolled on purpose: fully unrolled, hipcc issues all 27
-                    // ds_read_b128 up front (108 VGPRs of tile values) and the kernel drops to 2 waves/SIMD.
-    #pragma unroll 1
-                    for (int sz = 0; sz < SZN; sz++)
-    #pragma unroll
-                        for (int sy = 0; sy < 3; sy++)
-    #pragma unroll
-                            for (int sx = 0; sx < 3; sx++) {
-                                const int idx = tbase + sx + TW * sy + (D == 3 ? TW * TW * sz : 0);
-                                float4 nd = s_node[idx];
-                                float nv[D];
-                                nv[0] = nd.x; nv[1] = nd.y;
-                                if constexpr (D == 3) nv[2] = nd.z;
-                                float dpt[D];
-                                dpt[0] = ref[0] + (float)sx * h;
-                                dpt[1] = ref[1] + (float)sy * h;
-                                if constexpr (D == 3) dpt[2] = ref[2] + (float)sz * h;
-                                float wgt = w[0][sx] * w[1][sy];
-                                if constexpr (D == 3) wgt *= (sz == 0 ? w[2][0] : (sz == 1 ? w[2][1] : w[2][2]));
-                                NodeCdf nc = s_cdf[idx];
-                                if (!affinities_are_compatible(paff, nc.affinities)) {
-                                    if (nc.closest_id != NONE && nc.closest_id < d.n_colliders) {
-                                        const ColliderDev &col = d.colliders[nc.closest_id];
-                                        float cc[D], bv[D], rel[D], pr[D];
-    #pragma unroll
-                                        for (int k = 0; k < D; k++) cc[k] = dpt[k] + x[k];
-                                        velocity_at_point<D>(col, cc, bv);
-    #pragma unroll
-                                        for (int k = 0; k < D; k++) rel[k] = pvel[k] - bv[k];
-                                        project_velocity<D>(rel, nrm, pr);
-    #pragma unroll
-                                        for (int k = 0; k < D; k++) nv[k] = bv[k] + pr[k];
-                                    } else {
-    #pragma unroll
-                                        for (int k = 0; k < D; k++) nv[k] = pvel[k];
-                                    }
-                                }
-                                const float wi = wgt * invd;
-    #pragma unroll
-                                for (int k = 0; k < D; k++) vel[k] += nv[k] * wgt;
-    #pragma unroll
-                                for (int c = 0; c < D; c++)
-    #pragma unroll
-                                    for (int r = 0; r < D; r++) grad[c * D + r] += wi * (nv[r] * dpt[c]);
-                            }
-                }
-
-                float rvel[D];
-    #pragma unroll
-                for (int k = 0; k < D; k++) rvel[k] = 0.f;
-                if constexpr (CPIC) {  // g2p.wgsl:220-226 (bounded by the real collider count, quirk B9)
-                    for (uint32_t c = 0; c < d.n_colliders && c < 16u; c++)
-                        if (paff & (1u << c)) {
-                            float bv[D];
-                            velocity_at_point<D>(d.colliders[c], x, bv);
-    #pragma unroll
-                            for (int k = 0; k < D; k++) rvel[k] += bv[k];
-                        }
-                }
-
-                // ---- particle update (particle_update.wgsl:58-132)
-                if constexpr (CPIC) {
-                    if (sdist < -0.05f * h) {
-                        float rel[D], pr[D];
-    #pragma unroll
-                        for (int k = 0; k < D; k++) rel[k] = vel[k] - rvel[k];
-                        project_velocity<D>(rel, nrm, pr);
-    #pragma unroll
-                        for (int k = 0; k < D; k++) vel[k] = rvel[k] + pr[k];
-                    }
-                }
-                float l2 = 0.f;
-    #pragma unroll
-                for (int k = 0; k < D; k++) l2 += vel[k] * vel[k];
-                const float len = sqrtf(l2);
-                if (len > h / dt) {
-    #pragma unroll
-                    for (int k = 0; k < D; k++) vel[k] = vel[k] / len * h / dt;
-                }
-                float xn[D];
-    #pragma unroll
-                for (int k = 0; k < D; k++) xn[k] = x[k] + vel[k] * dt;
-                if constexpr (CPIC) {
-                    if (sdist < -0.05f * h) {
-                        const float corrected = fmaxf(sdist, -0.3f * h);
-                        const float imp = dt * -corrected * 1.0e3f;
-    #pragma unroll
-                        for (int k = 0; k < D; k++) vel[k] += imp * nrm[k];
-                    }
-                }
-                // F <- F + (grad * dt) * F
-                float gdt[DD], prod[DD];
-    #pragma unroll
-                for (int k = 0; k < DD; k++) gdt[k] = grad[k] * dt;
-                mat_mul<D>(gdt, Fm, prod);
-    #pragma unroll
-                for (int k = 0; k < DD; k++) Fm[k] += prod[k];
-
-                float tau[DD];
-                bool have_svd = false;
-                Svd<D> sv;
-                if constexpr (PLASTIC) {
-                    float dp[6], st[3], phase, max_stretch;
-                    {
-                        const float4 d0 = ldq(in, npad, P::DP0, src), d1 = ldq(in, npad, P::DP1, src), d2 = ldq(in, npad, P::DP2, src);
-                        dp[0] = d0.x; dp[1] = d0.y; dp[2] = d0.z; dp[3] = d0.w; dp[4] = d1.x; dp[5] = d1.y;
-                        st[0] = d1.z; st[1] = d1.w; st[2] = d2.x; phase = d2.y; max_stretch = d2.z;
-                    }
-                    if (phase > 0.f && max_stretch > 0.f) {  // particle_update.wgsl:98-116
-                        svd<D>(Fm, sv);
-                        have_svd = true;
-                        bool broken = false;
-    #pragma unroll
-                        for (int k = 0; k < D; k++) broken = broken || sv.s[k] > max_stretch;
-                        if (broken) phase = 0.f;
-                    }
-                    if (phase == 0.f && dp[4] != 0.f) {  // particle_update.wgsl:118-122, drucker_prager.wgsl:134
-                        if (!have_svd) svd<D>(Fm, sv);
-                        have_svd = true;
-                        drucker_prager_project<D>(dp, st, Fm, sv);  // sv.s follows the projected F
-                    }
-                    stq(out, npad, P::DP0, j, make_float4(dp[0], dp[1], dp[2], dp[3]));
-                    stq(out, npad, P::DP1, j, make_float4(dp[4], dp[5], st[0], st[1]));
-                    stq(out, npad, P::DP2, j, make_float4(st[2], phase, max_stretch, 0.f));
-                }
-                if constexpr (MODEL == 1) {
-                    kirchoff_neo_hookean<D>(lambda, mu, Fm, tau);
-                } else {
-                    if (!have_svd) svd<D>(Fm, sv);
-                    kirchoff_corotated<D>(lambda, mu, Fm, sv, tau);
-                }
-                // particle_update.wgsl:129-132: C' = grad * m - tau * (V0 * inv_d * dt)
-                const float coeff = vol0 * invd * dt;
-                float Cn[DD];
-    #pragma unroll
-                for (int k = 0; k < DD; k++) Cn[k] = grad[k] * mass - tau[k] * coeff;
-                if constexpr (D == 3) {
-                    stq(out, npad, P::XM, j, make_float4(xn[0], xn[1], xn[2], mass));
-                    stq(out, npad, P::CV0, j, make_float4(Cn[0], Cn[1], Cn[2], Cn[3]));
-                    stq(out, npad, P::CV1, j, make_float4(Cn[4], Cn[5], Cn[6], Cn[7]));
-                    stq(out, npad, P::CV2, j, make_float4(Cn[8], vel[0], vel[1], vel[2]));
-                    stq(out, npad, P::F0, j, make_float4(Fm[0], Fm[1], Fm[2], Fm[3]));
-                    stq(out, npad, P::F1, j, make_float4(Fm[4], Fm[5], Fm[6], Fm[7]));
-                    stq(out, npad, P::F2, j, make_float4(Fm[8], vol0, lambda, mu));
-                } else {
-                    stq(out, npad, P::XM, j, make_float4(xn[0], xn[1], mass, vol0));
-                    stq(out, npad, P::CV0, j, make_float4(Cn[0], Cn[1], Cn[2], Cn[3]));
-                    stq(out, npad, P::CV2, j, make_float4(vel[0], vel[1], lambda, mu));
-                    stq(out, npad, P::F0, j, make_float4(Fm[0], Fm[1], Fm[2], Fm[3]));
-                }
-                stpid<D>(out, npad, j, pid);
-                // CMODE 1 (no collider in reach): default_cdf() is implied by a stale stamp, nothing to store (layout.h)
-                if constexpr (CPIC) {
-                    if constexpr (D == 3) {
-                        stq(out, npad, P::CDF0, j, make_float4(nrm[0], nrm[1], nrm[2], sdist));
-                        stq(out, npad, P::CDF1, j, make_float4(rvel[0], rvel[1], rvel[2], __uint_as_float(paff)));
-                    } else {
-                        stq(out, npad, P::CDF0, j, make_float4(nrm[0], nrm[1], sdist, __uint_as_float(paff)));
-                        stq(out, npad, P::CDF1, j, make_float4(rvel[0], rvel[1], 0.f, 0.f));
-                    }
-                    ststamp<D>(out, npad, j, epoch);
-                }
-            }  // mine
-        }  // distinct blocks
-        if constexpr (CMODE != 2) break;
+// Collider simulations: the body of CMODE 2 (walk of the near-collider block list) and the body of CMODE 1 (blocks
+// away from colliders, one workgroup per 64 sorted particles) in ONE launch. The first 8 x `nlist` workgroups walk
+// the list — they start at once and run beside the others —, the `nmain` workgroups after them run the main body;
+// 8 * nlist and nmain are multiples of 8, so the XCD-aware chunk mapping of the main body is unchanged. Both bodies
+// are capped at the same register budget, so the main path keeps its occupancy; the launch saves the ~4.5 us a
+// dependent kernel boundary costs even when the list is empty. `nlist` follows the list length the host last saw
+// (wgs_sync), so an empty list costs a few hundred workgroups that exit at once.
+template <int D, int MODEL, bool PLASTIC>
+__global__ __launch_bounds__(G2P_THREADS, G2P_WAVES_PER_EU) void k_g2p_pair(Dev d, int side, uint32_t epoch, uint32_t nmain, uint32_t nlist) {
+    __shared__ float4 s_node[Dim<D>::TILE];
+    __shared__ NodeCdf s_cdf[Dim<D>::TILE];
+    if (blockIdx.x >= 8u * nlist) {
+        const uint32_t widx = blockIdx.x - 8u * nlist;
+#define G2P_CMODE 1
+#define G2P_BX widx
+#define G2P_BY 0u
+#define G2P_GX nmain
+#define G2P_GY 1u
+#include "g2p_body.inc"
+#undef G2P_CMODE
+#undef G2P_BX
+#undef G2P_BY
+#undef G2P_GX
+#undef G2P_GY
+    } else {
+#define G2P_CMODE 2
+#define G2P_BX (blockIdx.x & 7u)
+#define G2P_BY (blockIdx.x >> 3)
+#define G2P_GX 8u
+#define G2P_GY nlist
+#include "g2p_body.inc"
+#undef G2P_CMODE
+#undef G2P_BX
+#undef G2P_BY
+#undef G2P_GX
+#undef G2P_GY
     }
 }
 #undef G2P_DONE

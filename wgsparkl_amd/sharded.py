@@ -354,6 +354,22 @@ class RcclExchange:
                 raise RuntimeError("RCCL self send/recv returned wrong data")
         return True
 
+    def neighbour_test(self):
+        """One real exchange with both neighbours on each communicator: every rank sends its own rank and must receive
+        rank - 1 / rank + 1. Run once before the transport is trusted with particle data."""
+        torch = self.torch
+        mine = torch.full((256,), float(self.rank), dtype=torch.float32, device="cuda")
+        for use_side in (False, True):
+            if use_side:
+                got_lo, got_hi = self.start(mine, mine).finish()
+            else:
+                got_lo, got_hi = self(mine, mine)
+            torch.cuda.synchronize()
+            for got, peer in ((got_lo, self.lower), (got_hi, self.upper)):
+                if peer is not None and not bool((got == float(peer)).all()):
+                    raise RuntimeError(f"RCCL neighbour exchange with rank {peer} returned wrong data")
+        return True
+
     def close(self):
         for comm in self.comms:
             self.lib.ncclCommDestroy(comm)
