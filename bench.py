@@ -204,7 +204,7 @@ def main():
                                    f"h=1, dt=1/1200, 8 particles/cell, " + ("no collider" if args.no_floor else "floor cuboid (CPIC passes on)"),
                        "particles_per_gpu": n_total // world, "global_particles": n_total,
                        "active_blocks_rank0": stats["num_active_blocks"], "parallelism": parallelism},
-            "roofline": {"bound": "hbm", "kernel": "k_g2p_update (fused G2P + particle update)",
+            "roofline": {"bound": "hbm", "kernel": "k_g2p_pair (fused G2P + particle update; collider simulations run both bodies in this launch)" if not args.no_floor else "k_g2p_update (fused G2P + particle update)",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "algorithmic_bytes_per_launch": algo_bytes, "avg_launch_ms": g2p_ms, "event_interval_ms": g2p_interval_ms, "event_mark_ms": mark_ms},

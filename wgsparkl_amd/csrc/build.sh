@@ -10,7 +10,7 @@ pids=()
 for dim in 3 2; do
   out="libwgsparkl${dim}d_hip.so"
   if [[ "${1:-}" != "force" && -f "$out" ]]; then
-    newest=$(ls -t capi.hip *.h ../../include/wgsparkl_hip.h "$out" | head -1)
+    newest=$(ls -t capi.hip *.h *.inc ../../include/wgsparkl_hip.h "$out" | head -1)
     [[ "$newest" == "$out" ]] && continue
   fi
   $HIPCC $FLAGS -DWGS_DIM=$dim capi.hip -o "$out.tmp" && mv "$out.tmp" "$out" &

@@ -157,7 +157,6 @@ void fill_collider(ColliderDev &c, const wgs_collider &in) {
     for (int k = 0; k < 3; k++) c.com[k] = in.com[k];
 }
 
-constexpr uint32_t PCDF_LAUNCH_MIN_BLOCKS = 48;  // near-collider blocks from which the particle cdf gets its own launch
 int grid_for(const wgs_data *d, int blocks_per_cu) { return d->pipeline->num_cus * blocks_per_cu; }
 
 // ---- read-back kernels ---------------------------------------------------
@@ -387,7 +386,6 @@ wgs_status fetch_counters(wgs_data *d) {
     HIP_TRY(hipStreamSynchronize(d->stream));
     d->last_nblocks = host[CTR_NBLOCKS] < d->dev.cap ? host[CTR_NBLOCKS] : d->dev.cap;
     d->last_ncpic = host[CTR_NCPIC] < d->dev.cap ? host[CTR_NCPIC] : d->dev.cap;
-    if (d->dev.dbg & 16384u) fprintf(stderr, "[wgs] active blocks %u, near-collider blocks %u\n", d->last_nblocks, d->last_ncpic);
     d->sticky_errors |= host[CTR_ERRORS];
     if (host[CTR_NBLOCKS] > d->dev.cap) d->sticky_errors |= ERRBIT_OVERFLOW;
     return WGS_OK;
@@ -533,17 +531,9 @@ template <bool TS> wgs_status enqueue_substep(wgs_data *d, int ts_slot, int part
             const dim3 p2g_grid(grid_for(d, 5)), p2g_block(P2GCfg<D>::NW * 64);
             if (d->cpic) {
                 hipLaunchKernelGGL((k_p2g<D, false>), p2g_grid, p2g_block, 0, s, dev, side, 1, epoch);
-                // particle cdf of the near-collider blocks: in the prologue of the CPIC P2G launch while the list is
-                // short (one workgroup per block, no launch), as a chip-wide launch of its own once the host has seen
-                // a long list (kernels_transfer.h: k_particle_cdf)
-                const bool pcdf_launch = fused_cdf && d->last_ncpic != UINT32_MAX && d->last_ncpic >= PCDF_LAUNCH_MIN_BLOCKS && !(dev.dbg & 8192u);
-                if (pcdf_launch)
-                    hipLaunchKernelGGL(k_particle_cdf<D>, dim3(8, std::min((uint32_t)grid_for(d, 1) * 3u / 2u, std::max(32u, 2u * d->last_ncpic))),
-                                       dim3(64), 0, s, dev, side, epoch);
-                const bool pcdf_fused = fused_cdf && !pcdf_launch;
-                if (d->two_way && pcdf_fused) hipLaunchKernelGGL((k_p2g<D, true, true, true>), p2g_grid, p2g_block, 0, s, dev, side, 2, epoch);
+                if (d->two_way && fused_cdf) hipLaunchKernelGGL((k_p2g<D, true, true, true>), p2g_grid, p2g_block, 0, s, dev, side, 2, epoch);
                 else if (d->two_way) hipLaunchKernelGGL((k_p2g<D, true, true>), p2g_grid, p2g_block, 0, s, dev, side, 2, epoch);
-                else if (pcdf_fused) hipLaunchKernelGGL((k_p2g<D, true, false, true>), p2g_grid, p2g_block, 0, s, dev, side, 2, epoch);
+                else if (fused_cdf) hipLaunchKernelGGL((k_p2g<D, true, false, true>), p2g_grid, p2g_block, 0, s, dev, side, 2, epoch);
                 else hipLaunchKernelGGL((k_p2g<D, true>), p2g_grid, p2g_block, 0, s, dev, side, 2, epoch);
             } else {
                 hipLaunchKernelGGL((k_p2g<D, false>), p2g_grid, p2g_block, 0, s, dev, side, 0, epoch);

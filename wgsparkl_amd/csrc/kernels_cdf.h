@@ -187,6 +187,34 @@ template <int N> __device__ inline float det_small(const float *m) {
     }
 }
 
+// Node cdfs of block b's (BW+2)^D tile -> LDS (s_cdf[TILE]); NT = threads of the calling workgroup (whole waves, all
+// lanes active). The tile's nodes live in b and its 7 "+" neighbours: lanes 0..7 of every wave fetch the links once,
+// then ALL node loads of the thread are issued before the first LDS store — two dependent round trips per tile instead
+// of two per 64 / NT nodes.
+template <int D, int NT> __device__ __forceinline__ void stage_node_cdf_tile(const Dev &d, uint32_t b, NodeCdf *s_cdf, int tid) {
+    constexpr int BW = Dim<D>::BW, BS = Dim<D>::BSHIFT, TW = Dim<D>::TW, TILE = Dim<D>::TILE;
+    constexpr int K = (TILE + NT - 1) / NT;
+    const int lane = tid & 63;
+    uint32_t link = NONE;
+    if (lane < 8) link = d.nbr_plus[b * 8u + (uint32_t)lane];
+    NodeCdf c[K];
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+        const int n = tid + k * NT;
+        const int tt[3] = {n % TW, (n / TW) % TW, D == 3 ? n / (TW * TW) : 0};
+        const int o = (tt[0] >= BW ? 1 : 0) | (tt[1] >= BW ? 2 : 0) | (tt[2] >= BW ? 4 : 0);
+        const int ln = (tt[0] & (BW - 1)) + ((tt[1] & (BW - 1)) << BS) + (D == 3 ? ((tt[2] & (BW - 1)) << (2 * BS)) : 0);
+        const uint32_t nb = __shfl(link, o & 7);
+        c[k] = NodeCdf{0.f, 0u, NONE, 0u};
+        if (n < TILE && nb != NONE) c[k] = d.node_cdf[(size_t)nb * NPB + ln];
+    }
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+        const int n = tid + k * NT;
+        if (n < TILE) s_cdf[n] = c[k];
+    }
+}
+
 // g2p_cdf.wgsl:39-250 for one particle (`src` = its slot in the buffer): affinity / sign bits, distance and normal
 // from the node cdfs of its block's tile (LDS image s_cdf, tile origin = block coordinates bc). Writes the
 // particle's cdf quads and stamps them with the substep.

@@ -88,15 +88,7 @@ __global__ __launch_bounds__(P2GCfg<D>::NW * 64) void k_p2g(Dev d, int side, int
         const uint32_t cn = d.cell_cursor[b * NPB + cell] - cs;
         __syncthreads();  // previous block fully consumed
         if constexpr (PCDF) {
-            for (int n = tid; n < TILE; n += NT) {
-                const int tt[3] = {n % TW, (n / TW) % TW, D == 3 ? n / (TW * TW) : 0};
-                const int o = (tt[0] >= BW ? 1 : 0) | (tt[1] >= BW ? 2 : 0) | (tt[2] >= BW ? 4 : 0);
-                const int ln = (tt[0] & (BW - 1)) + ((tt[1] & (BW - 1)) << BS) + (D == 3 ? ((tt[2] & (BW - 1)) << (2 * BS)) : 0);
-                const uint32_t nb = d.nbr_plus[b * 8u + o];
-                NodeCdf c = {0.f, 0u, NONE, 0u};
-                if (nb != NONE) c = d.node_cdf[(size_t)nb * NPB + ln];
-                s_ncdf[n] = c;
-            }
+            stage_node_cdf_tile<D, NT>(d, b, s_ncdf, tid);
             __syncthreads();
             const uint32_t bstart = d.block_start[b];
             for (uint32_t j = bstart + tid; j < bstart + cnt; j += NT)
@@ -355,41 +347,6 @@ __global__ __launch_bounds__(P2GCfg<D>::NW * 64) void k_p2g(Dev d, int side, int
                     d.imp_slab[((size_t)b * TILE + n) * IMPQ + q] = is;
                 }
             }
-        }
-    }
-}
-
-// Particle cdf (g2p_cdf.wgsl:39-250) of the near-collider blocks as a launch of its own: one wave per 64 sorted
-// particles of a listed block (blockIdx.y strides the list, blockIdx.x the chunks a block spans), node cdfs of the
-// block's tile staged in LDS. The prologue of the CPIC P2G does the same work with ONE workgroup per block, which is the
-// right trade while the list is short (no launch); with hundreds of listed blocks that serial per-block loop is what
-// the substep waits for, and this launch spreads it over the chip (capi.hip chooses by the list length the host last saw).
-template <int D> __global__ __launch_bounds__(64) void k_particle_cdf(Dev d, int side, uint32_t epoch) {
-    constexpr int BW = Dim<D>::BW, BS = Dim<D>::BSHIFT, TW = Dim<D>::TW, TILE = Dim<D>::TILE;
-    __shared__ NodeCdf s_ncdf[TILE];
-    const int tid = threadIdx.x;
-    const uint32_t L = min(d.counters[CTR_NCPIC], d.cap);
-    for (uint32_t a = blockIdx.y; a < L; a += gridDim.y) {
-        const uint32_t b = d.cpic_list[a];
-        const uint32_t start = d.block_start[b], cnt = d.block_count[b];
-        const uint32_t first = start / 64u + blockIdx.x, last = (start + cnt - 1u) / 64u;
-        if (first > last) continue;  // (wave-uniform)
-        int bc[3] = {0, 0, 0};
-        unpack_key<D>(d.block_key[b], bc);
-        __syncthreads();  // single-wave workgroup: orders the reuse of the tile
-        for (int n = tid; n < TILE; n += 64) {
-            const int tt[3] = {n % TW, (n / TW) % TW, D == 3 ? n / (TW * TW) : 0};
-            const int o = (tt[0] >= BW ? 1 : 0) | (tt[1] >= BW ? 2 : 0) | (tt[2] >= BW ? 4 : 0);
-            const int ln = (tt[0] & (BW - 1)) + ((tt[1] & (BW - 1)) << BS) + (D == 3 ? ((tt[2] & (BW - 1)) << (2 * BS)) : 0);
-            const uint32_t nb = d.nbr_plus[b * 8u + o];
-            NodeCdf c = {0.f, 0u, NONE, 0u};
-            if (nb != NONE) c = d.node_cdf[(size_t)nb * NPB + ln];
-            s_ncdf[n] = c;
-        }
-        __syncthreads();
-        for (uint32_t chunk = first; chunk <= last; chunk += gridDim.x) {
-            const uint32_t j = chunk * 64u + (uint32_t)tid;
-            if (j >= start && j < start + cnt) particle_cdf_update<D>(d, d.buf[side], d.perm[j], s_ncdf, bc, epoch);
         }
     }
 }
