@@ -178,7 +178,9 @@ template <int D> struct Svd {
     float u[D * D], s[D], v[D * D];  // v = V (not transposed), column-major
 };
 
-template <int D> __device__ inline void jacobi_rotate(float *a, float *v, int p, int q) {
+// One rotation of the column pair (p, q). `live` = false leaves the lane untouched (it has converged). Returns whether
+// the rotation was more than round-off (|cos| of the column pair above 3e-7, ~5 ulp).
+template <int D> __device__ inline bool jacobi_rotate(float *a, float *v, int p, int q, bool live) {
     float alpha = 0.f, beta = 0.f, gamma = 0.f;
 #pragma unroll
     for (int r = 0; r < D; r++) {
@@ -186,22 +188,24 @@ template <int D> __device__ inline void jacobi_rotate(float *a, float *v, int p,
         beta += a[q * D + r] * a[q * D + r];
         gamma += a[p * D + r] * a[q * D + r];
     }
-    // rotation angle zeroing the (p,q) inner product; t = 0 when already orthogonal
+    // rotation angle zeroing the (p,q) inner product; nothing to do when already orthogonal
     float zeta = (beta - alpha) / (2.0f * gamma);
     float t = copysignf(1.0f, zeta) / (fabsf(zeta) + sqrtf(1.0f + zeta * zeta));
-    bool skip = !(fabsf(gamma) > 1.0e-30f) || !(gamma * gamma > 1.0e-15f * alpha * beta) || !(t == t);
-    t = skip ? 0.0f : t;
-    float c = 1.0f / sqrtf(1.0f + t * t);
-    float s = c * t;
+    const bool skip = !live || !(fabsf(gamma) > 1.0e-30f) || !(gamma * gamma > 1.0e-15f * alpha * beta) || !(t == t);
+    if (!skip) {
+        float c = 1.0f / sqrtf(1.0f + t * t);
+        float s = c * t;
 #pragma unroll
-    for (int r = 0; r < D; r++) {
-        float ap = a[p * D + r], aq = a[q * D + r];
-        a[p * D + r] = c * ap - s * aq;
-        a[q * D + r] = s * ap + c * aq;
-        float vp = v[p * D + r], vq = v[q * D + r];
-        v[p * D + r] = c * vp - s * vq;
-        v[q * D + r] = s * vp + c * vq;
+        for (int r = 0; r < D; r++) {
+            float ap = a[p * D + r], aq = a[q * D + r];
+            a[p * D + r] = c * ap - s * aq;
+            a[q * D + r] = s * ap + c * aq;
+            float vp = v[p * D + r], vq = v[q * D + r];
+            v[p * D + r] = c * vp - s * vq;
+            v[q * D + r] = s * vp + c * vq;
+        }
     }
+    return !skip && gamma * gamma > 1.0e-13f * alpha * beta;
 }
 
 template <int D> __device__ inline void svd(const float *F, Svd<D> &out) {
@@ -214,15 +218,20 @@ template <int D> __device__ inline void svd(const float *F, Svd<D> &out) {
 #pragma unroll
     for (int i = 0; i < D; i++) out.v[i * D + i] = 1.f;
     if constexpr (D == 2) {
-        jacobi_rotate<2>(a, out.v, 0, 1);  // one rotation is exact in 2D
-        jacobi_rotate<2>(a, out.v, 0, 1);  // second pass mops up fp32 residue
+        jacobi_rotate<2>(a, out.v, 0, 1, true);  // one rotation is exact in 2D
+        jacobi_rotate<2>(a, out.v, 0, 1, true);  // second pass mops up fp32 residue
     } else {
-        // Cyclic sweeps; fp32 converges quadratically, 4-5 sweeps reach round-off for
-        // any conditioning met in practice. Fixed trip count keeps the wave converged.
+        // Cyclic sweeps, at most 5 (fp32 converges quadratically). A lane whose sweep rotated by no more than
+        // round-off has converged and is frozen — what is left is below 1e-13 in the singular values and 3e-7 in
+        // the vectors, later sweeps would chase fp32 noise —, so its result depends on its own matrix only; the
+        // wave leaves the loop when all its lanes are frozen: 3 sweeps for the deformations met in practice.
+        bool live = true;
         for (int sweep = 0; sweep < 5; sweep++) {
-            jacobi_rotate<3>(a, out.v, 0, 1);
-            jacobi_rotate<3>(a, out.v, 0, 2);
-            jacobi_rotate<3>(a, out.v, 1, 2);
+            bool rotated = jacobi_rotate<3>(a, out.v, 0, 1, live);
+            rotated = jacobi_rotate<3>(a, out.v, 0, 2, live) || rotated;
+            rotated = jacobi_rotate<3>(a, out.v, 1, 2, live) || rotated;
+            live = live && rotated;
+            if (__ballot(live) == 0ull) break;
         }
     }
     float smax = 0.f;
