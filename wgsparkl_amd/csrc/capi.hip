@@ -521,7 +521,7 @@ template <bool TS> wgs_status enqueue_substep(wgs_data *d, int ts_slot, int part
         // ---- "grid_update_cdf" + "g2p_cdf" (collide.wgsl, grid_update_cdf.wgsl, g2p_cdf.wgsl): one launch
         // (kernels_cdf.h); the reference's two pass names share its time in wgs_read_timings
         if (dev.n_rigid > 0 && n > 0)  // "p2g_cdf": mesh primitives -> node cdf accumulators
-            hipLaunchKernelGGL(k_p2g_cdf<D>, dim3(grid_for(d, 1)), dim3(256), 0, s, dev, epoch);
+            hipLaunchKernelGGL(k_p2g_cdf<D>, dim3(std::min((dev.n_rigid * 32u + 255u) / 256u, (uint32_t)grid_for(d, 32))), dim3(256), 0, s, dev, epoch);
         if (d->cpic && n > 0 && !fused_cdf)
             hipLaunchKernelGGL(k_cdf<D>, dim3(grid_for(d, 16)), dim3(CDF_THREADS), 0, s, dev, side, epoch);
         mark(2);
@@ -531,10 +531,10 @@ template <bool TS> wgs_status enqueue_substep(wgs_data *d, int ts_slot, int part
             const dim3 p2g_grid(grid_for(d, 5)), p2g_block(P2GCfg<D>::NW * 64);
             if (d->cpic) {
                 hipLaunchKernelGGL((k_p2g<D, false>), p2g_grid, p2g_block, 0, s, dev, side, 1, epoch);
-                if (d->two_way && fused_cdf) hipLaunchKernelGGL((k_p2g<D, true, true, true>), p2g_grid, p2g_block, 0, s, dev, side, 2, epoch);
-                else if (d->two_way) hipLaunchKernelGGL((k_p2g<D, true, true>), p2g_grid, p2g_block, 0, s, dev, side, 2, epoch);
-                else if (fused_cdf) hipLaunchKernelGGL((k_p2g<D, true, false, true>), p2g_grid, p2g_block, 0, s, dev, side, 2, epoch);
-                else hipLaunchKernelGGL((k_p2g<D, true>), p2g_grid, p2g_block, 0, s, dev, side, 2, epoch);
+                // near-collider list: particle cdf in the prologue (the node cdfs are complete: k_setup_scatter<CDF>, or
+                // k_cdf after k_p2g_cdf with mesh colliders), then the CPIC transfer
+                if (d->two_way) hipLaunchKernelGGL((k_p2g<D, true, true, true>), p2g_grid, p2g_block, 0, s, dev, side, 2, epoch);
+                else hipLaunchKernelGGL((k_p2g<D, true, false, true>), p2g_grid, p2g_block, 0, s, dev, side, 2, epoch);
             } else {
                 hipLaunchKernelGGL((k_p2g<D, false>), p2g_grid, p2g_block, 0, s, dev, side, 0, epoch);
             }

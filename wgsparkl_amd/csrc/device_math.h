@@ -79,6 +79,41 @@ __device__ inline uint32_t hmap_find(const Dev &d, uint32_t key, uint32_t epoch)
     return NONE;
 }
 
+// K lookups at once, probing in lockstep: every round issues the loads of all unresolved keys together, then the values
+// of the hits, then their stamps — a few dependent round trips for the lot instead of up to three per key, one key
+// after the other.
+template <int K> __device__ inline void hmap_find_many(const Dev &d, const uint32_t *keys, const bool *wanted, uint32_t epoch, uint32_t *out) {
+    uint32_t slot[K], id[K];
+    bool pend[K], hit[K];
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+        slot[k] = hash_key(keys[k]) & d.hmask;
+        pend[k] = wanted[k];
+        hit[k] = false;
+    }
+    for (uint32_t probe = 0; probe <= d.hmask; ++probe) {
+        uint32_t st[K];
+#pragma unroll
+        for (int k = 0; k < K; k++) st[k] = pend[k] ? d.hkeys[slot[k]] : NONE;
+        bool more = false;
+#pragma unroll
+        for (int k = 0; k < K; k++) {
+            if (!pend[k]) continue;
+            if (st[k] == keys[k]) { hit[k] = true; pend[k] = false; }
+            else if (st[k] == NONE) pend[k] = false;
+            else { slot[k] = (slot[k] + 1u) & d.hmask; more = true; }
+        }
+        if (__ballot(more) == 0ull) break;
+    }
+#pragma unroll
+    for (int k = 0; k < K; k++) id[k] = hit[k] ? d.hvals[slot[k]] : NONE;
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+        out[k] = NONE;
+        if (id[k] < d.cap && d.block_stamp[id[k]] == epoch) out[k] = id[k];
+    }
+}
+
 // grid/grid.wgsl:121-164 insertion_index + :323-334 mark_block_as_active: make sure `key`
 // is in the table, stamp its block active for `epoch` and return the block's physical id.
 __device__ inline uint32_t activate_block(const Dev &d, uint32_t key, uint32_t epoch) {

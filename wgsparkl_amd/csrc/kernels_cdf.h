@@ -412,8 +412,7 @@ template <int D> __global__ __launch_bounds__(CDF_THREADS) void k_cdf(Dev d, int
             d.block_cpic[b] = any ? 1u : 0u;
             if (any && cnt > 0) d.cpic_list[atomicAdd(&d.counters[CTR_NCPIC], 1u)] = b;  // few blocks
         }
-        if (!any) continue;
-        for (uint32_t j = start + tid; j < start + cnt; j += CDF_THREADS) particle_cdf_update<D>(d, buf, d.perm[j], s_cdf, bc, epoch);
+        // (3: the particle cdf of the listed blocks runs in the prologue of the CPIC P2G launch, three waves per block)
     }
 }
 

@@ -46,11 +46,19 @@ template <int D> __global__ __launch_bounds__(256) void k_rigid_mark(Dev d, uint
 #pragma unroll
         for (int k = 0; k < D; k++) b[k] = c[k] >> BS;
         bool own = false, other = false, in_range = true;
+        uint32_t keys[NN], ids[NN];
+        bool wanted[NN];
 #pragma unroll
         for (int o = 0; o < NN; o++) {
             int nb[3] = {b[0] + (o & 1), b[1] + ((o >> 1) & 1), b[2] + ((o >> 2) & 1)};
-            if (!block_in_key_range<D>(nb)) { in_range = false; continue; }
-            const bool ex = hmap_find(d, pack_key<D>(nb), epoch) != NONE;
+            wanted[o] = block_in_key_range<D>(nb);
+            in_range = in_range && wanted[o];
+            keys[o] = wanted[o] ? pack_key<D>(nb) : 0u;
+        }
+        hmap_find_many<NN>(d, keys, wanted, epoch, ids);
+#pragma unroll
+        for (int o = 0; o < NN; o++) {
+            const bool ex = ids[o] != NONE;
             if (o == 0) own = ex; else other = other || ex;
         }
         d.rp_needs[i] = (!own && other && in_range) ? 1u : 0u;
@@ -117,39 +125,47 @@ template <int D> __device__ inline bool project_on_primitive(const Dev &d, const
     }
 }
 
+// One thread per (sample, node) pair — 32 lanes per sample, 3^D of them busy —, so a sample's nodes are projected and
+// merged side by side instead of one after the other (each costs a few dependent memory round trips).
 template <int D> __global__ __launch_bounds__(256) void k_p2g_cdf(Dev d, uint32_t epoch) {
     constexpr int BW = Dim<D>::BW, BS = Dim<D>::BSHIFT, NBH = Dim<D>::NBH;
-    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < d.n_rigid; i += gridDim.x * 256) {
+    const uint32_t total = d.n_rigid * 32u;
+    for (uint32_t t = blockIdx.x * 256 + threadIdx.x; t < total; t += gridDim.x * 256) {
+        const uint32_t i = t >> 5;
+        const int s = (int)(t & 31u);
+        if (s >= NBH) continue;
         int c[D], b[3] = {0, 0, 0};
         rigid_cell<D>(d, i, c);
 #pragma unroll
         for (int k = 0; k < D; k++) b[k] = c[k] >> BS;
-        // a sample whose own block does not exist is in no node list (sort.wgsl:149-151): ignored
-        if (!block_in_key_range<D>(b) || hmap_find(d, pack_key<D>(b), epoch) == NONE) continue;
         const uint4 ids = d.rp_ids[i];
         if (ids.w >= 16u) continue;
-        int last_nb[3] = {0x7fffffff, 0, 0};
-        uint32_t last_id = NONE;
-        for (int s = 0; s < NBH; s++) {
-            int nc[3] = {c[0] + s % 3, c[1] + (s / 3) % 3, D == 3 ? c[D - 1] + s / 9 : 0};
-            int nb[3] = {nc[0] >> BS, nc[1] >> BS, D == 3 ? nc[2] >> BS : 0};
-            if (nb[0] != last_nb[0] || nb[1] != last_nb[1] || nb[2] != last_nb[2]) {
-                last_nb[0] = nb[0]; last_nb[1] = nb[1]; last_nb[2] = nb[2];
-                last_id = block_in_key_range<D>(nb) ? hmap_find(d, pack_key<D>(nb), epoch) : NONE;
-            }
-            if (last_id == NONE) continue;  // the node does not exist
-            float cell[3] = {0.f, 0.f, 0.f};
+        int nc[3] = {c[0] + s % 3, c[1] + (s / 3) % 3, D == 3 ? c[D - 1] + s / 9 : 0};
+        int nb[3] = {nc[0] >> BS, nc[1] >> BS, D == 3 ? nc[2] >> BS : 0};
+        // a sample whose own block does not exist is in no node list (sort.wgsl:149-151): ignored; nodes of blocks that
+        // do not exist do not exist
+        uint32_t keys[2], blk[2];
+        const bool wanted[2] = {block_in_key_range<D>(b), block_in_key_range<D>(nb)};
+        keys[0] = wanted[0] ? pack_key<D>(b) : 0u;
+        keys[1] = wanted[1] ? pack_key<D>(nb) : 0u;
+        hmap_find_many<2>(d, keys, wanted, epoch, blk);
+        if (blk[0] == NONE || blk[1] == NONE) continue;
+        float cell[3] = {0.f, 0.f, 0.f};
 #pragma unroll
-            for (int k = 0; k < D; k++) cell[k] = (float)nc[k] * d.h;
-            float dist;
-            bool sign;
-            if (!project_on_primitive<D>(d, ids, cell, dist, sign)) continue;
-            const uint32_t ln = (uint32_t)(nc[0] & (BW - 1)) + ((uint32_t)(nc[1] & (BW - 1)) << BS) +
-                                (D == 3 ? ((uint32_t)(nc[2] & (BW - 1)) << (2 * BS)) : 0u);
-            const size_t node = (size_t)last_id * NPB + ln;
-            atomicOr(&d.mesh_aff[node], (1u << ids.w) | ((sign ? 1u : 0u) << (ids.w + 16u)));
-            atomicMin(&d.mesh_min[node], ((unsigned long long)__float_as_uint(dist) << 32) | (unsigned long long)ids.w);
-        }
+        for (int k = 0; k < D; k++) cell[k] = (float)nc[k] * d.h;
+        float dist;
+        bool sign;
+        if (!project_on_primitive<D>(d, ids, cell, dist, sign)) continue;
+        const uint32_t ln = (uint32_t)(nc[0] & (BW - 1)) + ((uint32_t)(nc[1] & (BW - 1)) << BS) +
+                            (D == 3 ? ((uint32_t)(nc[2] & (BW - 1)) << (2 * BS)) : 0u);
+        const size_t node = (size_t)blk[1] * NPB + ln;
+        // Hundreds of samples reach the same node and device-scope atomics execute at the memory side, so look first
+        // (coherent loads): the bits only ever get set and the minimum only ever shrinks within a substep, a stale
+        // view costs a redundant atomic, never a wrong result.
+        const uint32_t bits = (1u << ids.w) | ((sign ? 1u : 0u) << (ids.w + 16u));
+        const unsigned long long cand = ((unsigned long long)__float_as_uint(dist) << 32) | (unsigned long long)ids.w;
+        if ((__hip_atomic_load(&d.mesh_aff[node], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & bits) != bits) atomicOr(&d.mesh_aff[node], bits);
+        if (cand < __hip_atomic_load(&d.mesh_min[node], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMin(&d.mesh_min[node], cand);
     }
 }
 
