@@ -94,7 +94,7 @@ def main():
     else:
         # Weak scaling: `world` C2 cubes side by side along x form one elastic bar; x-slab domain
         # decomposition, one slab per GPU, halo + migration exchanges over RCCL point-to-point (sharded.py).
-        from wgsparkl_amd.sharded import FixedExchange, GpuShard, RcclExchange, finish_migration, pipelined_substep
+        from wgsparkl_amd.sharded import FixedExchange, GpuShard, RcclExchange, finish_migration, pipelined_substep, substep_phases
         scene = scenes.neo_hookean_bar(n_side=args.n_side, world=world, rank=rank)
         if args.no_floor:
             scene["colliders"] = []
@@ -129,7 +129,18 @@ def main():
             exch = FixedExchange(dist, rank, world)
         transport = "RCCL send/recv (direct)" if use_rccl else "torch.distributed p2p"
 
+        # Both messages of a substep are issued on the substep's own stream, in order (substep_phases). The pipelined
+        # order (migration on a side stream while the next substep re-bins its residents, WGS_SHARD_ORDER=pipelined) is
+        # SLOWER on this stack: measured with a rank that is its own two neighbours (every RCCL call of an interior
+        # rank issued, tests/gpu_host_cost.py), 206 us per substep in order against 230 us pipelined — the two
+        # cross-stream dependencies cost more than the overlap gains.
+        pipelined = os.environ.get("WGS_SHARD_ORDER", "inorder") == "pipelined"
+
         def run(k):
+            if not pipelined:
+                for _ in range(k):
+                    substep_phases(data, exch)
+                return
             pending = None       # the migration of a substep stays in flight while the next one re-bins its residents
             for _ in range(k):
                 pending = pipelined_substep(data, exch, pending)

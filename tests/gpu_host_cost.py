@@ -9,11 +9,16 @@ work = torch.cuda.Stream() if os.environ.get("OWN_STREAM") == "1" else torch.cud
 torch.cuda.set_stream(work)
 print("stream handle", work.cuda_stream)
 pipe = MpmPipeline(0, 3)
+# SELF_NEIGHBOURS=1: the single rank is its own lower and upper neighbour, so that every RCCL call of a real interior
+# rank is issued (host cost of the transport; the physics of the interface layers is meaningless)
+SELF = os.environ.get("SELF_NEIGHBOURS") == "1"
 sc = scenes.neo_hookean_bar(n_side=100, world=1, rank=0)
 lo, hi = sc["partition"].block_range(0)
 data = GpuShard(pipe, sc["params"], sc["particles"], sc["global_ids"], sc["colliders"], sc["cell_width"], sc["grid_capacity"], lo, hi,
-                False, False, particle_capacity=int(sc["particles"].n * 1.25) + 4096, model=sc["model"], halo_capacity_blocks=450, migrant_capacity=2048)
+                SELF, SELF, particle_capacity=int(sc["particles"].n * 1.25) + 4096, model=sc["model"], halo_capacity_blocks=450, migrant_capacity=2048)
 ex = FixedExchange(dist, 0, 1) if os.environ.get("EXCH") == "torch" else RcclExchange(dist, 0, 1)
+if SELF:
+    ex.lower = ex.upper = 0
 def run(k):
     if os.environ.get("PLAIN") == "1":
         for _ in range(k):
