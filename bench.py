@@ -105,9 +105,11 @@ def main():
         data = GpuShard(pipe, scene["params"], ps, scene["global_ids"], scene["colliders"], scene["cell_width"],
                         scene["grid_capacity"], lo, hi, rank > 0, rank < world - 1,
                         particle_capacity=int(n * 1.25) + 4096, model=scene["model"],
-                        # message capacities from the face area: (n_side / 8 + 3)^2 interface blocks, x2 margin;
-                        # a few hundred particles cross a face per substep at these velocities
-                        halo_capacity_blocks=max(256, 2 * (args.n_side // 8 + 3) ** 2), migrant_capacity=2048)
+                        # Messages travel at their full capacity (no size handshake), so the capacities are sized from
+                        # the workload: a face of the bar touches at most (n_side / 8 + 3)^2 blocks (+ margin), and the
+                        # bar falls along y — a handful of particles cross a cut per substep. An overflow is reported
+                        # by wgs_sync and by the particle count checked below.
+                        halo_capacity_blocks=(args.n_side // 8 + 3) ** 2 + 32, migrant_capacity=512)
         # transport: RCCL called directly (ctypes) unless WGS_EXCHANGE=torch or the process group is not RCCL (the
         # 1-GPU functional mode runs over gloo)
         use_rccl = os.environ.get("WGS_EXCHANGE", "rccl") == "rccl" and dist.get_backend() == "nccl"

@@ -15,7 +15,7 @@ SELF = os.environ.get("SELF_NEIGHBOURS") == "1"
 sc = scenes.neo_hookean_bar(n_side=100, world=1, rank=0)
 lo, hi = sc["partition"].block_range(0)
 data = GpuShard(pipe, sc["params"], sc["particles"], sc["global_ids"], sc["colliders"], sc["cell_width"], sc["grid_capacity"], lo, hi,
-                SELF, SELF, particle_capacity=int(sc["particles"].n * 1.25) + 4096, model=sc["model"], halo_capacity_blocks=450, migrant_capacity=2048)
+                SELF, SELF, particle_capacity=int(sc["particles"].n * 1.25) + 4096, model=sc["model"], halo_capacity_blocks=int(os.environ.get("HALO_CAP", "450")), migrant_capacity=int(os.environ.get("MIG_CAP", "2048")))
 ex = FixedExchange(dist, 0, 1) if os.environ.get("EXCH") == "torch" else RcclExchange(dist, 0, 1)
 if SELF:
     ex.lower = ex.upper = 0

@@ -112,7 +112,7 @@ def test_bench_slabs_at_full_size_fit_their_exchange_buffers(hip_libs):
         shards.append(GpuShard(pipe, sc["params"], ps, sc["global_ids"], sc["colliders"], sc["cell_width"],
                                sc["grid_capacity"], lo, hi, rank > 0, rank < world - 1,
                                particle_capacity=int(ps.n * 1.25) + 4096, model=sc["model"],
-                               halo_capacity_blocks=max(256, 2 * (n_side // 8 + 3) ** 2), migrant_capacity=2048))
+                               halo_capacity_blocks=(n_side // 8 + 3) ** 2 + 32, migrant_capacity=512))
     assert total == 2_000_000
     pending = None
     for _ in range(k):

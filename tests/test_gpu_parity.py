@@ -202,7 +202,7 @@ def test_bench_decomposition_eight_ranks_on_one_gpu(hip_libs):
         shards.append(GpuShard(pipe, sc["params"], ps, sc["global_ids"], sc["colliders"], sc["cell_width"],
                                sc["grid_capacity"], lo, hi, rank > 0, rank < world - 1,
                                particle_capacity=int(ps.n * 1.25) + 4096, model=sc["model"],
-                               halo_capacity_blocks=max(256, 2 * (n_side // 8 + 3) ** 2), migrant_capacity=2048))
+                               halo_capacity_blocks=(n_side // 8 + 3) ** 2 + 32, migrant_capacity=512))
     assert total == full["global_particles"] == full["particles"].n
     pending = None
     for _ in range(k):
