@@ -157,6 +157,7 @@ void fill_collider(ColliderDev &c, const wgs_collider &in) {
     for (int k = 0; k < 3; k++) c.com[k] = in.com[k];
 }
 
+constexpr uint32_t P2G_PAIR_MIN_BLOCKS = 128;  // near-collider blocks from which P2G runs both bodies in one launch
 int grid_for(const wgs_data *d, int blocks_per_cu) { return d->pipeline->num_cus * blocks_per_cu; }
 
 // ---- read-back kernels ---------------------------------------------------
@@ -529,7 +530,12 @@ template <bool TS> wgs_status enqueue_substep(wgs_data *d, int ts_slot, int part
         if (n > 0) {
             // ---- "p2g"
             const dim3 p2g_grid(grid_for(d, 5)), p2g_block(P2GCfg<D>::NW * 64);
-            if (d->cpic) {
+            if (d->cpic && d->last_ncpic != UINT32_MAX && d->last_ncpic >= P2G_PAIR_MIN_BLOCKS && !(dev.dbg & 8192u)) {
+                // many blocks near colliders (as of the last wgs_sync): both bodies in one launch (k_p2g_pair)
+                const dim3 pair_grid(2u * (uint32_t)grid_for(d, 5));
+                if (d->two_way) hipLaunchKernelGGL((k_p2g_pair<D, true>), pair_grid, p2g_block, 0, s, dev, side, epoch);
+                else hipLaunchKernelGGL((k_p2g_pair<D, false>), pair_grid, p2g_block, 0, s, dev, side, epoch);
+            } else if (d->cpic) {
                 hipLaunchKernelGGL((k_p2g<D, false>), p2g_grid, p2g_block, 0, s, dev, side, 1, epoch);
                 // near-collider list: particle cdf in the prologue (the node cdfs are complete: k_setup_scatter<CDF>, or
                 // k_cdf after k_p2g_cdf with mesh colliders), then the CPIC transfer

@@ -63,292 +63,68 @@ __global__ __launch_bounds__(P2GCfg<D>::NW * 64) void k_p2g(Dev d, int side, int
     __shared__ NodeCdf s_ncdf[PCDF ? TILE : 1];
     __shared__ float4 s_imp[TWOWAY ? Cfg::NW : 1][TWOWAY ? IMPQ : 1][TWOWAY ? TILE : 1];
 
-    const float *in = d.buf[side];
-    const uint32_t npad = d.npad;
-    const float h = d.h, inv_h = d.inv_h;
-    const int tid = threadIdx.x;
-    const int cell = tid & 63;
-    const int sz = D == 3 ? (tid >> 6) : 0;  // wave-uniform
-    int lc[3];
-    lc[0] = cell & (BW - 1);
-    lc[1] = (cell >> BS) & (BW - 1);
-    lc[2] = D == 3 ? (cell >> (2 * BS)) : 0;
-    const int tnode0 = lc[0] + TW * lc[1] + (D == 3 ? TW * TW * (lc[2] + sz) : 0);  // tile node of (sx,sy) = (0,0)
+#define P2G_CPIC CPIC
+#define P2G_TWOWAY TWOWAY
+#define P2G_PCDF PCDF
+#define P2G_BLK blockIdx.x
+#define P2G_NBLK gridDim.x
+#include "p2g_body.inc"
+#undef P2G_CPIC
+#undef P2G_TWOWAY
+#undef P2G_PCDF
+#undef P2G_BLK
+#undef P2G_NBLK
+}
 
-    // filter 2 walks the (short) list of blocks near a collider, the others the active list
-    const uint32_t B = min(d.counters[filter == 2 ? CTR_NCPIC : CTR_NBLOCKS], d.cap);
-    for (uint32_t a = blockIdx.x; a < B; a += gridDim.x) {
-        const uint32_t b = filter == 2 ? d.cpic_list[a] : d.active[a];
-        const uint32_t cnt = d.block_count[b];
-        if (cnt == 0) continue;  // no particles: its slab is never read
-        if (filter == 1 && d.block_cpic[b] != 0u) continue;
-        int bc[3] = {0, 0, 0};
-        unpack_key<D>(d.block_key[b], bc);
-        const uint32_t cs = d.cell_start[b * NPB + cell];
-        const uint32_t cn = d.cell_cursor[b * NPB + cell] - cs;
-        __syncthreads();  // previous block fully consumed
-        if constexpr (PCDF) {
-            stage_node_cdf_tile<D, NT>(d, b, s_ncdf, tid);
-            __syncthreads();
-            const uint32_t bstart = d.block_start[b];
-            for (uint32_t j = bstart + tid; j < bstart + cnt; j += NT)
-                particle_cdf_update<D>(d, d.buf[side], d.perm[j], s_ncdf, bc, epoch);
-            __threadfence_block();
-            __syncthreads();  // the affinities written above are fetched below by other threads of the workgroup
-        }
-        if (tid < NPB) {
-            s_cs[cell] = cs;
-            s_cn[cell] = cn;
-        }
-        for (int n = cell; n < TILE; n += 64) s_tile[sz][n] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if constexpr (TWOWAY) {
-            for (int n = cell; n < TILE; n += 64)
-                for (int q = 0; q < IMPQ; q++) s_imp[sz][q][n] = make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-        uint32_t maxc = cn;
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) maxc = max(maxc, (uint32_t)__shfl_xor((int)maxc, off));
-        float cpos[D];
-#pragma unroll
-        for (int k = 0; k < D; k++) cpos[k] = (float)(bc[k] * BW + lc[k]) * h;
-        uint32_t naff[Cfg::NSXY];
-        unsigned long long ncol = 0ull;  // closest collider of the nine nodes: 4 bits each + valid bit at 36 + s
-        if constexpr (CPIC) {  // affinities of this thread's nine target nodes (p2g.wgsl:100-103)
-#pragma unroll
-            for (int s = 0; s < 9; s++) {
-                int t[3] = {lc[0] + s % 3, lc[1] + s / 3, lc[2] + sz};
-                int o = (t[0] >= BW ? 1 : 0) | (t[1] >= BW ? 2 : 0) | (t[2] >= BW ? 4 : 0);
-                int ln = (t[0] & (BW - 1)) + ((t[1] & (BW - 1)) << BS) + (D == 3 ? ((t[2] & (BW - 1)) << (2 * BS)) : 0);
-                uint32_t nb = d.nbr_plus[b * 8u + o];
-                naff[s] = nb != NONE ? d.node_cdf[(size_t)nb * NPB + ln].affinities : 0u;
-                if constexpr (TWOWAY) {
-                    const uint32_t cl = nb != NONE ? d.node_cdf[(size_t)nb * NPB + ln].closest_id : NONE;
-                    if (cl < 16u) ncol |= ((unsigned long long)cl << (4 * s)) | (1ull << (36 + s));
-                }
-            }
-        }
-        float acc[Cfg::NSXY][D + 1];
-#pragma unroll
-        for (int s = 0; s < 9; s++)
-#pragma unroll
-            for (int k = 0; k <= D; k++) acc[s][k] = 0.f;
-
-        // Software-pipelined staging: the particle quads of round r+1 are fetched into registers while
-        // round r is being accumulated from LDS, so the HBM latency of a round hides behind the
-        // previous round's arithmetic instead of being paid at every barrier.
-        // Staging slot sl -> (cell c = sl / J, rank j = sl % J): a cell's J particles are one contiguous
-        // 64-byte run of each quad in HBM; in LDS they go to [j][c] (row padded to ROW).
-        float4 pre[KS][NQ];
-        float4 pre_nrm[TWOWAY ? KS : 1];
-        uint32_t pre_aff[KS];
-        bool pre_ok[KS];
-        __syncthreads();  // s_cs / s_cn visible
-        auto fetch_round = [&](uint32_t r0) {
-#pragma unroll
-            for (int k = 0; k < KS; k++) {
-                const int sl = tid + k * NT;
-                pre_ok[k] = false;
-                if (sl < SLOTS) {
-                    const int c = sl / P2G_J;
-                    const uint32_t rank = r0 + (uint32_t)(sl % P2G_J);
-                    if (rank < s_cn[c] && !(d.dbg & 512u)) {
-                        const uint32_t src = d.perm[s_cs[c] + rank];
-                        pre_ok[k] = true;
-                        if constexpr (D == 3) {
-                            pre[k][0] = ldq(in, npad, Pl<3>::XM, src);
-                            pre[k][1] = ldq(in, npad, Pl<3>::CV0, src);
-                            pre[k][2] = ldq(in, npad, Pl<3>::CV1, src);
-                            pre[k][3] = ldq(in, npad, Pl<3>::CV2, src);
-                        } else {
-                            pre[k][0] = ldq(in, npad, Pl<2>::XM, src);   // x, y, m, V0
-                            pre[k][1] = ldq(in, npad, Pl<2>::CV0, src);
-                            pre[k][2] = ldq(in, npad, Pl<2>::CV2, src);  // vx, vy, lambda, mu
-                        }
-                        if constexpr (CPIC) {
-                            const float4 cd = ldq(in, npad, D == 3 ? (int)Pl<D>::CDF1 : (int)Pl<D>::CDF0, src);
-                            pre_aff[k] = __float_as_uint(cd.w);
-                            if constexpr (TWOWAY) pre_nrm[k] = D == 3 ? ldq(in, npad, Pl<D>::CDF0, src) : cd;  // cdf normal
-                        }
-                    }
-                }
-            }
-        };
-        fetch_round(0);
-        for (uint32_t r0 = 0; r0 < maxc; r0 += P2G_J) {
-            __syncthreads();  // previous round consumed
-#pragma unroll
-            for (int k = 0; k < KS; k++) {
-                if (pre_ok[k]) {
-                    const int sl = tid + k * NT;
-                    const int dst = (sl % P2G_J) * ROW + sl / P2G_J;
-                    if constexpr (D == 3) {
-                        float4 c2 = pre[k][3];
-                        const float m = TWOWAY ? 1.f : pre[k][0].w;  // (the two-way path needs the raw velocity too)
-                        c2.y *= m; c2.z *= m; c2.w *= m;  // momentum m v
-                        s_q[0][dst] = pre[k][0]; s_q[1][dst] = pre[k][1]; s_q[2][dst] = pre[k][2]; s_q[3][dst] = c2;
-                    } else {
-                        float4 vl = pre[k][2];
-                        const float m = TWOWAY ? 1.f : pre[k][0].z;
-                        vl.x *= m; vl.y *= m;
-                        s_q[0][dst] = pre[k][0]; s_q[1][dst] = pre[k][1]; s_q[2][dst] = vl;
-                    }
-                    if constexpr (CPIC) s_aff[dst] = pre_aff[k];
-                    if constexpr (TWOWAY) s_nrm[dst] = pre_nrm[k];
-                }
-            }
-            __syncthreads();
-            if (r0 + P2G_J < maxc) fetch_round(r0 + P2G_J);  // in flight during the accumulation below
-            const uint32_t jn = (cn > r0 && !(d.dbg & 256u)) ? min((uint32_t)P2G_J, cn - r0) : 0u;
-            for (uint32_t j = 0; j < jn; j++) {
-                const int sl = j * ROW + cell;
-                float x[D], mv[D], c[D * D], mass;
-                if constexpr (D == 3) {
-                    const float4 xm = s_q[0][sl], c0 = s_q[1][sl], c1 = s_q[2][sl], c2 = s_q[3][sl];
-                    x[0] = xm.x; x[1] = xm.y; x[2] = xm.z; mass = xm.w;
-                    c[0] = c0.x; c[1] = c0.y; c[2] = c0.z; c[3] = c0.w;
-                    c[4] = c1.x; c[5] = c1.y; c[6] = c1.z; c[7] = c1.w; c[8] = c2.x;
-                    mv[0] = c2.y; mv[1] = c2.z; mv[2] = c2.w;
-                } else {
-                    const float4 xm = s_q[0][sl], c0 = s_q[1][sl], vl = s_q[2][sl];
-                    x[0] = xm.x; x[1] = xm.y; mass = xm.z;
-                    c[0] = c0.x; c[1] = c0.y; c[2] = c0.z; c[3] = c0.w;
-                    mv[0] = vl.x; mv[1] = vl.y;
-                }
-                uint32_t paff = 0u;
-                if constexpr (CPIC) paff = s_aff[sl];
-                float pv[D], pn[D];  // raw particle velocity and cdf normal (two-way coupling)
-                if constexpr (TWOWAY) {
-                    const float4 nq = s_nrm[sl];
-                    pn[0] = nq.x; pn[1] = nq.y;
-                    if constexpr (D == 3) pn[2] = nq.z;
-#pragma unroll
-                    for (int k = 0; k < D; k++) {
-                        pv[k] = mv[k];
-                        mv[k] = mv[k] * mass;
-                    }
-                }
-                // p2g.wgsl:176-198: ref = assoc_node - x ; w = eval_all(-ref / h) ; dpt = ref + shift * h
-                float ref[D], wx[3], wy[3];
-#pragma unroll
-                for (int k = 0; k < D; k++) ref[k] = cpos[k] - x[k];
-                eval_all(-ref[0] * inv_h, wx);
-                eval_all(-ref[1] * inv_h, wy);
-                float wzs = 1.f;
-                float base[D];  // C[:, 2] * dz + m v
-                if constexpr (D == 3) {
-                    float wz[3];
-                    eval_all(-ref[2] * inv_h, wz);
-                    wzs = sz == 0 ? wz[0] : (sz == 1 ? wz[1] : wz[2]);
-                    const float dz = ref[2] + (float)sz * h;
-#pragma unroll
-                    for (int k = 0; k < 3; k++) base[k] = c[6 + k] * dz + mv[k];
-                } else {
-#pragma unroll
-                    for (int k = 0; k < 2; k++) base[k] = mv[k];
-                }
-#pragma unroll
-                for (int sy = 0; sy < 3; sy++) {
-                    const float dy = ref[1] + (float)sy * h;
-                    const float wyz = wy[sy] * wzs;
-                    float py[D];
-#pragma unroll
-                    for (int k = 0; k < D; k++) py[k] = c[D + k] * dy + base[k];
-#pragma unroll
-                    for (int sx = 0; sx < 3; sx++) {
-                        const int s = sx + 3 * sy;
-                        if constexpr (CPIC) {
-                            // p2g.wgsl:200-228: incompatible pairs transfer nothing to the grid (their momentum
-                            // becomes an impulse on the rigid body: two-way coupling)
-                            if (!affinities_are_compatible(naff[s], paff)) {
-                                if constexpr (TWOWAY) {
-                                    if ((ncol >> (36 + s)) & 1ull) {  // p2g.wgsl:203-224
-                                        const ColliderDev &cl = d.colliders[(uint32_t)(ncol >> (4 * s)) & 15u];
-                                        const float wgt = wx[sx] * wyz;
-                                        float dpt[3] = {ref[0] + (float)sx * h, dy, 0.f}, cc[3] = {0.f, 0.f, 0.f};
-                                        if constexpr (D == 3) dpt[2] = ref[2] + (float)sz * h;
-#pragma unroll
-                                        for (int k = 0; k < D; k++) cc[k] = dpt[k] + x[k];  // cell_center
-                                        float bv[D], rel[D], prj[D], dimp[3] = {0.f, 0.f, 0.f}, lever[3] = {0.f, 0.f, 0.f};
-                                        velocity_at_point<D>(cl, cc, bv);
-#pragma unroll
-                                        for (int k = 0; k < D; k++) rel[k] = pv[k] - bv[k];
-                                        project_velocity<D>(rel, pn, prj);
-#pragma unroll
-                                        for (int k = 0; k < D; k++) {
-                                            const float ghost = bv[k] + prj[k];
-                                            dimp[k] = (pv[k] - ghost) * (wgt * mass);
-                                            lever[k] = cl.com[k] - cc[k];
-                                        }
-                                        const int node = tnode0 + sx + TW * sy;
-                                        if constexpr (D == 3) {
-                                            float4 a = s_imp[sz][0][node], bq = s_imp[sz][1][node];
-                                            a.x += dimp[0]; a.y += dimp[1]; a.z += dimp[2];
-                                            bq.x += dimp[1] * lever[2] - dimp[2] * lever[1];
-                                            bq.y += dimp[2] * lever[0] - dimp[0] * lever[2];
-                                            bq.z += dimp[0] * lever[1] - dimp[1] * lever[0];
-                                            s_imp[sz][0][node] = a;
-                                            s_imp[sz][1][node] = bq;
-                                        } else {
-                                            float4 a = s_imp[sz][0][node];
-                                            a.x += dimp[0]; a.y += dimp[1];
-                                            a.z += dimp[0] * lever[1] + dimp[1] * (-lever[0]);
-                                            s_imp[sz][0][node] = a;
-                                        }
-                                        // lanes own distinct nodes within one (sx, sy) phase; keep the phases in order
-                                        asm volatile("" ::: "memory");
-                                    }
-                                }
-                                continue;
-                            }
-                        }
-                        const float dx = ref[0] + (float)sx * h;
-                        const float w = wx[sx] * wyz;
-#pragma unroll
-                        for (int k = 0; k < D; k++) acc[s][k] += (c[k] * dx + py[k]) * w;
-                        acc[s][D] += mass * w;
-                    }
-                }
-            }
-        }
-        // Per-wave tile: in phase (sx, sy) every lane (cell) owns a distinct node, so a plain float4
-        // read-add-write is race-free inside the wave and the LDS executes a wave's accesses in order.
-        // The asm memory clobbers stop hipcc from hoisting a later phase's load above an earlier phase's
-        // store (legal for one thread, wrong across lanes).
-        {
-#pragma unroll
-            for (int s = 0; s < 9; s++) {
-                float4 *p = &s_tile[sz][tnode0 + (s % 3) + TW * (s / 3)];
-                float4 v = *p;
-                v.x += acc[s][0]; v.y += acc[s][1]; v.z += acc[s][2];
-                if constexpr (D == 3) v.w += acc[s][3];
-                *p = v;
-                asm volatile("" ::: "memory");
-            }
-        }
-        __syncthreads();
-        // combine the sz tiles in a fixed order; one coalesced slab store per node
-        for (int n = tid; n < TILE; n += NT) {
-            float4 sum = s_tile[0][n];
-#pragma unroll
-            for (int w = 1; w < Cfg::NW; w++) {
-                const float4 p = s_tile[w][n];
-                sum.x += p.x; sum.y += p.y; sum.z += p.z; sum.w += p.w;
-            }
-            d.slab[(size_t)b * TILE + n] = sum;
-            if constexpr (TWOWAY) {
-#pragma unroll
-                for (int q = 0; q < IMPQ; q++) {
-                    float4 is = s_imp[0][q][n];
-#pragma unroll
-                    for (int w = 1; w < Cfg::NW; w++) {
-                        const float4 p = s_imp[w][q][n];
-                        is.x += p.x; is.y += p.y; is.z += p.z;
-                    }
-                    d.imp_slab[((size_t)b * TILE + n) * IMPQ + q] = is;
-                }
-            }
-        }
+// Scenes with MANY blocks near colliders: the plain body (filter 1) and the CPIC body over the near-collider list
+// (filter 2, particle cdf prologue included) in ONE launch; the first half of the grid runs one, the second half the
+// other. The kernel takes the CPIC body's registers, so the plain body loses a third of its occupancy (36 -> 48 us at
+// C2): a loss while the list is short — the two launches then simply follow each other —, a gain once the CPIC launch
+// is the longer of the two, because a near-collider block costs ~3x a plain one in latency and the launches no longer
+// add up. capi.hip switches on the list length the host last saw.
+template <int D, bool TWOWAY>
+__global__ __launch_bounds__(P2GCfg<D>::NW * 64) void k_p2g_pair(Dev d, int side, uint32_t epoch) {
+    using Cfg = P2GCfg<D>;
+    constexpr int BW = Dim<D>::BW, BS = Dim<D>::BSHIFT, TW = Dim<D>::TW, TILE = Dim<D>::TILE;
+    constexpr int NT = Cfg::NW * 64;
+    constexpr int SLOTS = P2G_J * NPB;
+    constexpr int ROW = NPB + 4;
+    constexpr int KS = (SLOTS + NT - 1) / NT;
+    constexpr int NQ = Cfg::NQ;
+    __shared__ float4 s_q[NQ][P2G_J * ROW];
+    __shared__ uint32_t s_aff[P2G_J * ROW];
+    __shared__ float4 s_tile[Cfg::NW][TILE];
+    __shared__ uint32_t s_cs[NPB], s_cn[NPB];
+    constexpr int IMPQ = D == 3 ? 2 : 1;
+    __shared__ float4 s_nrm[TWOWAY ? P2G_J * ROW : 1];
+    __shared__ NodeCdf s_ncdf[TILE];
+    __shared__ float4 s_imp[TWOWAY ? Cfg::NW : 1][TWOWAY ? IMPQ : 1][TWOWAY ? TILE : 1];
+    const uint32_t half = gridDim.x >> 1;
+#define P2G_NBLK half
+    if (blockIdx.x >= half) {
+        const int filter = 1;
+#define P2G_CPIC false
+#define P2G_TWOWAY false
+#define P2G_PCDF false
+#define P2G_BLK (blockIdx.x - half)
+#include "p2g_body.inc"
+#undef P2G_CPIC
+#undef P2G_TWOWAY
+#undef P2G_PCDF
+#undef P2G_BLK
+    } else {  // the long bodies start first
+        const int filter = 2;
+#define P2G_CPIC true
+#define P2G_TWOWAY TWOWAY
+#define P2G_PCDF true
+#define P2G_BLK blockIdx.x
+#include "p2g_body.inc"
+#undef P2G_CPIC
+#undef P2G_TWOWAY
+#undef P2G_PCDF
+#undef P2G_BLK
     }
+#undef P2G_NBLK
 }
 
 // ------------------------------------------------------------ grid update
