@@ -352,6 +352,47 @@ def test_steady_state_rebinning_is_bit_identical_to_full_binning(hip_libs, seed,
         assert np.array_equal(getattr(a, f), getattr(b, f)), f
 
 
+def test_long_near_collider_list_paths_match_the_separate_launches_and_the_oracle(hip_libs, monkeypatch):
+    """Once wgs_sync has seen a long near-collider list, P2G runs its plain and its CPIC body in one launch (k_p2g_pair)
+    and G2P sizes the list half of k_g2p_pair from it. A 262 k-particle corotated cube resting on the floor under a
+    kinematic paddle (> 128 listed blocks, two-way impulses on): the paired P2G ends bit-identical to the two separate
+    launches (WGS_DEBUG = 8192) — which path runs depends on when the host last synchronised, so the result must not —,
+    the paired G2P agrees with the separate kernels (WGS_DEBUG = 4096, a debug path; another compilation of the same
+    source, one ulp apart), and the run matches the oracle."""
+    from helpers import pipeline
+    from wgsparkl_amd import MpmData
+    sc = scenes.corotated_cube_with_paddle(n_side=64)
+
+    def run():
+        pipe = pipeline(3)
+        data = MpmData.new(pipe, sc["params"], sc["particles"], sc["colliders"], sc["cell_width"], sc["grid_capacity"], sc["model"])
+        pipe.step(data, 4)
+        data.sync()                                            # the host sees the list here
+        pipe.step(data, 4)
+        data.sync()
+        return data.read_particles(), data.read_body_poses()
+    pa, ba = run()
+    assert int((pa.cdf_affinity != 0).sum()) > 128 * 64        # enough particles near colliders for > 128 listed blocks
+    monkeypatch.setenv("WGS_DEBUG", "8192")
+    pb, bb = run()
+    for f in ("pos", "vel", "def_grad", "affine", "cdf_affinity"):
+        assert np.array_equal(getattr(pa, f), getattr(pb, f)), f
+    for x, y in zip(ba, bb):
+        for key in ("translation", "rotation", "linvel", "angvel"):
+            assert np.array_equal(x[key], y[key]), key
+    monkeypatch.setenv("WGS_DEBUG", "4096")
+    pc, _ = run()
+    assert np.array_equal(pa.cdf_affinity, pc.cdf_affinity)
+    for f in ("pos", "vel", "def_grad"):
+        assert rel_rms(getattr(pc, f), getattr(pa, f)) < 1e-6, f
+    st, st64 = run_oracle(sc, 8, np.float32), run_oracle(sc, 8, np.float64)
+    same = pa.cdf_affinity == st.arr["cdf_affinity"]
+    assert same.mean() > 0.999
+    for f, tol in (("pos", 2e-6), ("vel", 2e-4)):
+        err, err32 = rel_rms(getattr(pa, f)[same], st64.arr[f][same]), rel_rms(st.arr[f][same], st64.arr[f][same])
+        assert err < max(tol, 10.0 * err32), (f, err, err32)
+
+
 @pytest.mark.parametrize("seed", [1, 2, 6, 8])
 def test_checkpoint_restart_random_scenes(hip_libs, seed):
     """Bit-exact restart on the fuzz scenes: dynamic and kinematic bodies, mesh colliders, plasticity."""
