@@ -355,7 +355,7 @@ def test_steady_state_rebinning_is_bit_identical_to_full_binning(hip_libs, seed,
 def test_long_near_collider_list_paths_match_the_separate_launches_and_the_oracle(hip_libs, monkeypatch):
     """Once wgs_sync has seen a long near-collider list, P2G runs its plain and its CPIC body in one launch (k_p2g_pair)
     and G2P sizes the list half of k_g2p_pair from it. A 262 k-particle corotated cube resting on the floor under a
-    kinematic paddle (> 128 listed blocks, two-way impulses on): the paired P2G ends bit-identical to the two separate
+    kinematic paddle (well over 8 listed blocks, two-way impulses on): the paired P2G ends bit-identical to the two separate
     launches (WGS_DEBUG = 8192) — which path runs depends on when the host last synchronised, so the result must not —,
     the paired G2P agrees with the separate kernels (WGS_DEBUG = 4096, a debug path; another compilation of the same
     source, one ulp apart), and the run matches the oracle."""
@@ -372,7 +372,7 @@ def test_long_near_collider_list_paths_match_the_separate_launches_and_the_oracl
         data.sync()
         return data.read_particles(), data.read_body_poses()
     pa, ba = run()
-    assert int((pa.cdf_affinity != 0).sum()) > 128 * 64        # enough particles near colliders for > 128 listed blocks
+    assert int((pa.cdf_affinity != 0).sum()) > 128 * 64        # many particles near colliders: a long list
     monkeypatch.setenv("WGS_DEBUG", "8192")
     pb, bb = run()
     for f in ("pos", "vel", "def_grad", "affine", "cdf_affinity"):

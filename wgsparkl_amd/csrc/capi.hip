@@ -157,7 +157,7 @@ void fill_collider(ColliderDev &c, const wgs_collider &in) {
     for (int k = 0; k < 3; k++) c.com[k] = in.com[k];
 }
 
-constexpr uint32_t P2G_PAIR_MIN_BLOCKS = 128;  // near-collider blocks from which P2G runs both bodies in one launch
+constexpr uint32_t P2G_PAIR_MIN_BLOCKS = 8;  // near-collider blocks from which P2G runs both bodies in one launch
 int grid_for(const wgs_data *d, int blocks_per_cu) { return d->pipeline->num_cus * blocks_per_cu; }
 
 // ---- read-back kernels ---------------------------------------------------
