@@ -184,6 +184,18 @@ __device__ inline void stq(float *base, uint32_t npad, int q, uint32_t i, float4
     asm volatile("" : "+v"(off));
     *reinterpret_cast<float4 *>(reinterpret_cast<char *>(base) + off) = v;
 }
+// Streaming load (non-temporal hint) for data a kernel touches exactly once: the fused G2P reads every particle's state
+// once and nothing else reads it in that launch, so the lines need not displace the node tiles and sort indices in L2.
+// Measured at C2 on one box: G2P 46-52 -> 41-44 us, the substep 150-155 -> 143-146 us. The same hint on G2P's STORES
+// gives that back (P2G of the next substep finds less in the caches), and on P2G's loads it costs 24 us: the staging
+// rounds of a block touch a line several times.
+__device__ inline float4 ldq_stream(const float *base, uint32_t npad, int q, uint32_t i) {
+    typedef float v4f __attribute__((ext_vector_type(4)));
+    uint32_t off = ((uint32_t)q * npad + i) * 16u;
+    asm volatile("" : "+v"(off));
+    const v4f nv = __builtin_nontemporal_load(reinterpret_cast<const v4f *>(reinterpret_cast<const char *>(base) + off));
+    return make_float4(nv.x, nv.y, nv.z, nv.w);
+}
 // persistent particle id (the caller's index) lives after the quads
 template <int D> __device__ inline uint32_t ldpid(const float *base, uint32_t npad, uint32_t i) {
     uint32_t off = ((uint32_t)Pl<D>::NQ * 4u * npad + i) * 4u;
