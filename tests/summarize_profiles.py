@@ -41,5 +41,8 @@ if g2p:
               open(f"profiles/{R}_pmc_g2p.json", "w"), indent=1)
 if os.path.exists(f"{src}/bench.json"):
     line = [l for l in open(f"{src}/bench.json") if l.startswith("{")]
-    if line: open(f"profiles/{R}_bench.json", "w").write(line[-1])
+    if line:
+        line.sort(key=lambda l: json.loads(l)["value"])
+        open(f"profiles/{R}_bench.json", "w").write(line[len(line) // 2])      # the median run
+        open(f"profiles/{R}_bench_runs.jsonl", "w").write("".join(line))         # all of them
 print(open(f"profiles/{R}_kernel_stats.csv").read()[:1800])
