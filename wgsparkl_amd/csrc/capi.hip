@@ -684,6 +684,10 @@ static wgs_status create_impl(wgs_pipeline *pipeline, const wgs_sim_params *para
         dev.h_pow2 = (frexpf(cell_width, &e) == 0.5f) ? 1u : 0u;
     }
     dev.model = WGS_MODEL_COROTATED;
+    // Developer switches (read once, here; 0 in production). Ablations change the RESULTS: 64 = G2P moves bytes only,
+    // 256 = P2G without its accumulation loop, 512 = P2G without its particle loads. A/B of launch shapes, same results:
+    // 128 = full k_bin on every substep (no k_rebin), 1024 = node cdf in a launch of its own (k_cdf) instead of
+    // k_setup_scatter<CDF>, 4096 = the two G2P bodies as two launches, 8192 = the two P2G bodies always as two launches.
     dev.dbg = getenv("WGS_DEBUG") ? (uint32_t)strtoul(getenv("WGS_DEBUG"), nullptr, 0) : 0u;
     dev.n_colliders = (uint32_t)num_colliders;
     d->cpic = num_colliders > 0;
