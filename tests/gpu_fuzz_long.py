@@ -9,7 +9,17 @@ for seed in range(lo, hi):
     try:
         sc = T._random_scene(seed)
         k = int(sys.argv[3]) if len(sys.argv) > 3 else 12
-        data = run_gpu(sc, k)
+        chunk = int(sys.argv[4]) if len(sys.argv) > 4 else 0
+        if chunk:      # the same substeps in several calls with a wgs_sync between them: the launch shapes that follow the
+            from helpers import pipeline                     # near-collider list the host last saw get exercised
+            from wgsparkl_amd import MpmData
+            pipe = pipeline(sc["particles"].dim)
+            data = MpmData.new(pipe, sc["params"], sc["particles"], sc["colliders"], sc["cell_width"], sc["grid_capacity"], sc.get("model", 0))
+            done = 0
+            while done < k:
+                pipe.step(data, min(chunk, k - done)); data.sync(); done += chunk
+        else:
+            data = run_gpu(sc, k)
         st, st64 = run_oracle(sc, k, np.float32), run_oracle(sc, k, np.float64)
         cells, vm, dist, aff, closest = data.read_grid()
         oc, omv, odist, oaff, oclosest = st.grid_records()
