@@ -164,6 +164,8 @@ typedef struct {
     uint32_t overflow;            /* sticky: WGS_ERR_GRID_OVERFLOW / WGS_ERR_KEY_RANGE seen on device */
     uint64_t substeps_done;
     uint64_t device_bytes;        /* HBM held by this wgs_data */
+    uint32_t num_near_collider_blocks; /* particle-bearing blocks whose tile sees a collider (the CPIC passes' list), last substep */
+    uint32_t reserved;
 } wgs_stats;
 
 typedef struct wgs_pipeline wgs_pipeline;

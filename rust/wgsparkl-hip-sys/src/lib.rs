@@ -127,6 +127,8 @@ pub struct wgs_stats {
     pub overflow: u32,
     pub substeps_done: u64,
     pub device_bytes: u64,
+    pub num_near_collider_blocks: u32,
+    pub reserved: u32,
 }
 
 extern "C" {

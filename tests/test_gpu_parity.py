@@ -370,9 +370,9 @@ def test_long_near_collider_list_paths_match_the_separate_launches_and_the_oracl
         data.sync()                                            # the host sees the list here
         pipe.step(data, 4)
         data.sync()
+        assert data.stats()["num_near_collider_blocks"] > 100  # a long list: the paired P2G launch is the one that ran
         return data.read_particles(), data.read_body_poses()
     pa, ba = run()
-    assert int((pa.cdf_affinity != 0).sum()) > 128 * 64        # many particles near colliders: a long list
     monkeypatch.setenv("WGS_DEBUG", "8192")
     pb, bb = run()
     for f in ("pos", "vel", "def_grad", "affine", "cdf_affinity"):

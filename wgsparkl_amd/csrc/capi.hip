@@ -1416,6 +1416,8 @@ wgs_status wgs_get_stats(wgs_data *d, wgs_stats *out) {
     out->overflow = d->sticky_errors;
     out->substeps_done = d->substeps;
     out->device_bytes = d->device_bytes;
+    out->num_near_collider_blocks = d->cpic && d->last_ncpic != UINT32_MAX ? d->last_ncpic : 0u;
+    out->reserved = 0u;
     return WGS_OK;
 }
 
