@@ -36,4 +36,9 @@ run(20); data.sync()
 for k in (100, 300, 100):
     t0 = time.perf_counter(); run(k); t1 = time.perf_counter(); data.sync(); t2 = time.perf_counter()
     print(f"{k} substeps: host enqueue {1e6 * (t1 - t0) / k:.1f} us/substep, total {1e6 * (t2 - t0) / k:.1f} us/substep")
+if os.environ.get("LONG"):
+    n0 = data.num_particles()
+    run(int(os.environ["LONG"])); data.sync()
+    print(f"after {os.environ['LONG']} more substeps: {data.num_particles()} particles (was {n0})")
+    assert data.num_particles() == n0
 dist.destroy_process_group()
