@@ -60,16 +60,30 @@ def test_c2_with_floor_collides_and_stays_finite(hip_libs):
 
 
 def test_c3_sand_column_four_million(hip_libs):
-    """configs[2]: Drucker-Prager sand, 4M particles, 256^3 domain (sand3.rs material)."""
-    sc = scenes.sand_column(nx=100, ny=400, nz=100)
+    """configs[2]: Drucker-Prager sand, 4M particles, 256^3 domain (sand3.rs material), floor + four walls (five
+    colliders in reach of the column's skin: the sign vote of the particle cdf runs over several colliders per wave)."""
+    sc = scenes.sand_column(nx=100, ny=400, nz=100, with_walls=True)
+    sc["particles"].pos[:, 1] -= 5.8                       # standing on the floor
     n = sc["particles"].n
-    assert n == 4_000_000
-    data = run_gpu(sc, 5)
+    assert n == 4_000_000 and len(sc["colliders"]) == 5
+    pipe_steps = (3, 3)                                    # a sync in between: the long-list launch shapes run too
+    from helpers import pipeline
+    from wgsparkl_amd import MpmData
+    pipe = pipeline(3)
+    data = MpmData.new(pipe, sc["params"], sc["particles"], sc["colliders"], sc["cell_width"], sc["grid_capacity"], sc["model"])
+    for k in pipe_steps:
+        pipe.step(data, k)
+        data.sync()
     check_sort_structure(data, n)
-    pos = data.read_positions()
-    assert np.isfinite(pos).all()
+    got = data.read_particles()
+    assert np.isfinite(got.pos).all() and np.isfinite(got.def_grad).all()
     s = data.stats()
-    assert s["overflow"] == 0 and s["num_active_blocks"] > 10_000
+    assert s["overflow"] == 0 and s["num_active_blocks"] > 10_000 and s["num_near_collider_blocks"] > 1_000
+    for c in range(5):                                     # every collider has particles with an affinity to it
+        assert ((got.cdf_affinity >> c) & 1).sum() > 1_000, c
+    # nothing went through the floor (top face at y = 2) or a wall
+    x0, x1 = 20.0 - 1.5, 20.0 + 50.0 + 1.5
+    assert got.pos[:, 1].min() > 1.9 and got.pos[:, 0].min() > x0 - 0.1 and got.pos[:, 0].max() < x1 + 0.1
 
 
 def test_c4_eight_million_corotated_with_kinematic_paddle(hip_libs):

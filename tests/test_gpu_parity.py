@@ -403,6 +403,36 @@ def test_long_near_collider_list_paths_match_the_separate_launches_and_the_oracl
         assert err < max(tol, 10.0 * err32), (f, err, err32)
 
 
+def test_plastic_pair_register_budgets_are_bit_identical(hip_libs, monkeypatch):
+    """Drucker-Prager sand between a floor and four walls, half of the blocks near a collider: after the first wgs_sync
+    the fused G2P runs the variant compiled for 2 waves per SIMD (no spills in the CPIC body). Same source, another
+    register budget: the results must be the bits of the 3-waves variant (WGS_DEBUG = 16384 keeps that one), because
+    which of the two runs depends on when the host synchronised."""
+    from helpers import pipeline
+    from wgsparkl_amd import MpmData
+    sc = scenes.sand_column(nx=40, ny=60, nz=40, with_walls=True)
+    sc["particles"].pos[:, 1] -= 5.8
+
+    def run():
+        pipe = pipeline(3)
+        data = MpmData.new(pipe, sc["params"], sc["particles"], sc["colliders"], sc["cell_width"], sc["grid_capacity"], sc["model"])
+        pipe.step(data, 4)
+        data.sync()
+        st = data.stats()
+        assert st["num_near_collider_blocks"] * 5 >= st["num_active_blocks"]     # the switch condition of capi.hip
+        pipe.step(data, 8)
+        data.sync()
+        return data.read_particles()
+    a = run()
+    monkeypatch.setenv("WGS_DEBUG", "16384")
+    b = run()
+    for f in ("pos", "vel", "def_grad", "affine", "cdf_affinity", "dp_state"):
+        assert np.array_equal(getattr(a, f), getattr(b, f)), f
+    assert np.isfinite(a.pos).all() and len(sc["colliders"]) == 5
+    for c in range(5):
+        assert ((a.cdf_affinity >> c) & 1).sum() > 100, c
+
+
 @pytest.mark.parametrize("seed", [1, 2, 6, 8])
 def test_checkpoint_restart_random_scenes(hip_libs, seed):
     """Bit-exact restart on the fuzz scenes: dynamic and kinematic bodies, mesh colliders, plasticity."""

@@ -573,8 +573,13 @@ template <bool TS> wgs_status enqueue_substep(wgs_data *d, int ts_slot, int part
             /* list workgroups: 2 x the list length the host last saw (unknown: the whole chip) */                 \
             const uint32_t full = (uint32_t)grid_for(d, 1) * 3u / 2u;                                             \
             const uint32_t nlist = d->last_ncpic == UINT32_MAX ? full : std::min(full, std::max(32u, 2u * d->last_ncpic)); \
-            hipLaunchKernelGGL((k_g2p_pair<D, MODEL, PL>), dim3((uint32_t)g + 8u * nlist), dim3(G2P_THREADS), 0, s, \
-                               dev, side, epoch, (uint32_t)g, nlist);                                             \
+            /* plastic scenes with a large share of listed blocks: the spill-free variant (kernels_transfer.h) */  \
+            if (PL && d->last_ncpic != UINT32_MAX && d->last_ncpic * 5u >= std::max(1u, d->last_nblocks) && !(dev.dbg & 16384u)) \
+                hipLaunchKernelGGL((k_g2p_pair<D, MODEL, PL, (PL) ? 2 : G2P_WAVES_PER_EU>), dim3((uint32_t)g + 8u * nlist), \
+                                   dim3(G2P_THREADS), 0, s, dev, side, epoch, (uint32_t)g, nlist);                \
+            else                                                                                                  \
+                hipLaunchKernelGGL((k_g2p_pair<D, MODEL, PL>), dim3((uint32_t)g + 8u * nlist), dim3(G2P_THREADS), 0, s, \
+                                   dev, side, epoch, (uint32_t)g, nlist);                                         \
             mark(6);                                                                                              \
         } else if (d->cpic) {               \
             WGS_LAUNCH_G2P(MODEL, PL, 1);   \
@@ -687,7 +692,8 @@ static wgs_status create_impl(wgs_pipeline *pipeline, const wgs_sim_params *para
     // Developer switches (read once, here; 0 in production). Ablations change the RESULTS: 64 = G2P moves bytes only,
     // 256 = P2G without its accumulation loop, 512 = P2G without its particle loads. A/B of launch shapes, same results:
     // 128 = full k_bin on every substep (no k_rebin), 1024 = node cdf in a launch of its own (k_cdf) instead of
-    // k_setup_scatter<CDF>, 4096 = the two G2P bodies as two launches, 8192 = the two P2G bodies always as two launches.
+    // k_setup_scatter<CDF>, 4096 = the two G2P bodies as two launches, 8192 = the two P2G bodies always as two launches, 16384 = never the
+    // spill-free variant of the plastic G2P pair.
     dev.dbg = getenv("WGS_DEBUG") ? (uint32_t)strtoul(getenv("WGS_DEBUG"), nullptr, 0) : 0u;
     dev.n_colliders = (uint32_t)num_colliders;
     d->cpic = num_colliders > 0;

@@ -316,8 +316,12 @@ __global__ __launch_bounds__(G2P_THREADS, G2P_WAVES_PER_EU) void k_g2p_update(De
 // are capped at the same register budget, so the main path keeps its occupancy; the launch saves the ~4.5 us a
 // dependent kernel boundary costs even when the list is empty. `nlist` follows the list length the host last saw
 // (wgs_sync), so an empty list costs a few hundred workgroups that exit at once.
-template <int D, int MODEL, bool PLASTIC>
-__global__ __launch_bounds__(G2P_THREADS, G2P_WAVES_PER_EU) void k_g2p_pair(Dev d, int side, uint32_t epoch, uint32_t nmain, uint32_t nlist) {
+// WPE (waves per SIMD the register budget is cut for): 3 everywhere, except that the Drucker-Prager CPIC body spills
+// ~350 B per lane under that cap; with 2 (256 VGPRs, no spills) a scene whose near-collider blocks are a third of all
+// blocks (4 M sand between a floor and four walls) runs its G2P 16 % faster, while scenes with few such blocks lose
+// 5-12 % to the lower occupancy of the main body: capi.hip picks by the share of listed blocks the host last saw.
+template <int D, int MODEL, bool PLASTIC, int WPE = G2P_WAVES_PER_EU>
+__global__ __launch_bounds__(G2P_THREADS, WPE) void k_g2p_pair(Dev d, int side, uint32_t epoch, uint32_t nmain, uint32_t nlist) {
     __shared__ float4 s_node[Dim<D>::TILE];
     __shared__ NodeCdf s_cdf[Dim<D>::TILE];
     if (blockIdx.x >= 8u * nlist) {

@@ -87,14 +87,21 @@ def corotated_cube_with_paddle(n_side=200, jitter=0.05, cell_width=1.0, paddle_s
     return sc
 
 
-def sand_column(nx=100, ny=400, nz=100, with_floor=False, jitter=0.05, grid_capacity=None):
-    """C3: Drucker-Prager sand column (sand3.rs:45-46 material), corotated stress, phase None."""
+def sand_column(nx=100, ny=400, nz=100, with_floor=False, jitter=0.05, grid_capacity=None, with_walls=False):
+    """C3: Drucker-Prager sand column (sand3.rs:45-46 material), corotated stress, phase None. `with_walls`: the floor
+    and four walls of SURVEY 8d C3 (five cuboid colliders; the walls stand 1.5 cells off the column's faces)."""
     h = 1.0
     origin = (20.0, 8.0, 20.0)
     pos = lattice((nx, ny, nz), origin, h, jitter)
     ps = ParticleSet.uniform(pos, h / 4.0, 2700.0, ElasticCoefficients.from_young_modulus(2.0e9, 0.2),
                              plasticity=DruckerPrager.new(2.0e9, 0.2), phase=None)
-    colliders = [Collider.cuboid((1000.0, 2.0, 1000.0), (0.0, 0.0, 0.0))] if with_floor else []
+    colliders = [Collider.cuboid((1000.0, 2.0, 1000.0), (0.0, 0.0, 0.0))] if (with_floor or with_walls) else []
+    if with_walls:
+        x0, x1 = origin[0] - 1.5 * h, origin[0] + nx * h / 2.0 + 1.5 * h
+        z0, z1 = origin[2] - 1.5 * h, origin[2] + nz * h / 2.0 + 1.5 * h
+        t = 2.0 * h                                                # wall half thickness
+        colliders += [Collider.cuboid((t, 1000.0, 1000.0), (x0 - t, 0.0, 0.0)), Collider.cuboid((t, 1000.0, 1000.0), (x1 + t, 0.0, 0.0)),
+                      Collider.cuboid((1000.0, 1000.0, t), (0.0, 0.0, z0 - t)), Collider.cuboid((1000.0, 1000.0, t), (0.0, 0.0, z1 + t))]
     params = SimulationParams(gravity=(0.0, -9.81, 0.0), dt=1.0 / 1200.0)
     if grid_capacity is None:
         nb = (nx // 8 + 3) * (ny // 8 + 3) * (nz // 8 + 3)
