@@ -508,7 +508,7 @@ template <bool TS> wgs_status enqueue_substep(wgs_data *d, int ts_slot, int part
             // collider simulations without mesh colliders: node cdf + block classes ride in this launch, the particle
             // cdf in the CPIC P2G launch (no CDF launch at all)
             {
-                const uint32_t nsetup = (uint32_t)grid_for(d, 4);
+                const uint32_t nsetup = (uint32_t)grid_for(d, 4);  // (more setup workgroups for more blocks was measured: slower)
                 const dim3 g(nsetup + (uint32_t)pgrid);
                 if (fused_cdf) hipLaunchKernelGGL((k_setup_scatter<D, true>), g, dim3(SORT_THREADS), 0, s, dev, side, epoch, nsetup);
                 else hipLaunchKernelGGL((k_setup_scatter<D, false>), g, dim3(SORT_THREADS), 0, s, dev, side, epoch, nsetup);

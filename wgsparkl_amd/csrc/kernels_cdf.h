@@ -123,10 +123,12 @@ template <int D> __device__ inline bool project_local_on_boundary(const Collider
 
 // grid_update_cdf.wgsl:16-39 + collide.wgsl:23-56 for one node at world position pt: a pure function of
 // the node position and the collider poses.
-template <int D> __device__ inline NodeCdf node_cdf_eval(const Dev &d, const float *pt) {
+// `which`: bit i clear = collider i is known to be out of reach of this node (its vote would be empty): skipped.
+template <int D> __device__ inline NodeCdf node_cdf_eval(const Dev &d, const float *pt, uint32_t which = 0xffffu) {
     const float cap = d.h * 1.5f;
     NodeCdf cdf = {1.0e10f, 0u, NONE, 0u};
     for (uint32_t i = 0; i < d.n_colliders && i < 16u; i++) {
+        if (!((which >> i) & 1u)) continue;  // (wave-uniform in k_setup_scatter)
         const ColliderDev &c = d.colliders[i];
         if (c.shape_type >= 3u) continue;  // mesh shapes have no analytic projection (collide.wgsl:36-38)
         float pl[D], projl[D], proj[D];

@@ -362,7 +362,7 @@ template <int D, bool CDF> __device__ __forceinline__ void block_setup_body(cons
             // Quick reject, wave-uniform: a collider whose boundary is farther from the tile's centre than the tile's
             // half diagonal plus the affinity reach (1.5 h per axis) touches none of its nodes, and a centre outside
             // the shape then means every node is outside. One projection per collider instead of (BW+2)^D.
-            bool near = false;
+            uint32_t near = 0u;  // bit i: collider i can reach a node of this tile
             {
                 float ctr[D];
 #pragma unroll
@@ -378,7 +378,7 @@ template <int D, bool CDF> __device__ __forceinline__ void block_setup_body(cons
                     float n2 = 0.f;
 #pragma unroll
                     for (int k = 0; k < D; k++) n2 += (proj[k] - ctr[k]) * (proj[k] - ctr[k]);
-                    near = near || inside || !(n2 > reach * reach);
+                    near |= (inside || !(n2 > reach * reach)) ? (1u << i) : 0u;
                 }
             }
             for (int n = lane; n < ((TILE + 63) / 64) * 64; n += 64) {
@@ -390,7 +390,7 @@ template <int D, bool CDF> __device__ __forceinline__ void block_setup_body(cons
 #pragma unroll
                     for (int k = 0; k < D; k++) pt[k] = (float)(b[k] * BW + t[k]) * d.h;
                     const NodeCdf far_cdf = {1.0e10f, 0u, NONE, 0u};
-                    const NodeCdf c = near ? node_cdf_eval<D>(d, pt) : far_cdf;
+                    const NodeCdf c = near ? node_cdf_eval<D>(d, pt, near) : far_cdf;
                     if (o == 0) d.node_cdf[(size_t)id * NPB + (t[0] + (t[1] << BS) + (D == 3 ? (t[2] << (2 * BS)) : 0))] = c;
                     mine |= c.affinities;
                 }
