@@ -429,8 +429,45 @@ def test_plastic_pair_register_budgets_are_bit_identical(hip_libs, monkeypatch):
     for f in ("pos", "vel", "def_grad", "affine", "cdf_affinity", "dp_state"):
         assert np.array_equal(getattr(a, f), getattr(b, f)), f
     assert np.isfinite(a.pos).all() and len(sc["colliders"]) == 5
+    # the one-way P2G pair has two register budgets too (chosen from the particle count and the list length): force the
+    # small one by making the scene "large" is not possible at this size, so compare the large budget (this scene's
+    # choice) with the separate launches, and the small budget at a size that selects it below
+    monkeypatch.setenv("WGS_DEBUG", "8192")
+    c = run()
+    for f in ("pos", "vel", "def_grad", "affine", "cdf_affinity", "dp_state"):
+        assert np.array_equal(getattr(a, f), getattr(c, f)), f
     for c in range(5):
         assert ((a.cdf_affinity >> c) & 1).sum() > 100, c
+
+
+def test_large_one_way_scenes_do_not_depend_on_when_the_host_synchronised(hip_libs, monkeypatch):
+    """From 600 k particles on, one-way collider simulations always run the paired P2G launch with the CPIC body cut to
+    168 VGPRs — a budget that differs from the unconstrained one in the last bit here and there, so it must not follow
+    the near-collider list the host last saw. 640 k neo-Hookean particles lying on the floor: eight substeps in one call
+    and the same eight with a wgs_sync after the third end bit-identical; the unconstrained budget (WGS_DEBUG = 32768)
+    agrees to round-off."""
+    from helpers import pipeline
+    from wgsparkl_amd import MpmData
+    sc = scenes.neo_hookean_cube(n_side=86, with_floor=True)
+    sc["particles"].pos[:, 1] -= 5.7
+    assert sc["particles"].n >= 600_000
+
+    def run(chunks):
+        pipe = pipeline(3)
+        data = MpmData.new(pipe, sc["params"], sc["particles"], sc["colliders"], sc["cell_width"], sc["grid_capacity"], sc["model"])
+        for k in chunks:
+            pipe.step(data, k)
+            data.sync()
+        assert data.stats()["num_near_collider_blocks"] >= 8
+        return data.read_particles()
+    a, b = run((8,)), run((3, 5))
+    for f in ("pos", "vel", "def_grad", "affine", "cdf_affinity"):
+        assert np.array_equal(getattr(a, f), getattr(b, f)), f
+    monkeypatch.setenv("WGS_DEBUG", "32768")
+    c = run((3, 5))
+    assert np.array_equal(a.cdf_affinity, c.cdf_affinity)
+    for f in ("pos", "vel", "def_grad"):
+        assert rel_rms(getattr(c, f), getattr(a, f)) < 1e-6, f
 
 
 @pytest.mark.parametrize("seed", [1, 2, 6, 8])

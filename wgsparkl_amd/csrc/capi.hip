@@ -157,6 +157,7 @@ void fill_collider(ColliderDev &c, const wgs_collider &in) {
     for (int k = 0; k < 3; k++) c.com[k] = in.com[k];
 }
 
+constexpr uint32_t P2G_SMALL_BUDGET_MIN_PARTICLES = 600000;  // one-way CPIC P2G body at 168 VGPRs from this size on
 constexpr uint32_t P2G_PAIR_MIN_BLOCKS = 8;  // near-collider blocks from which P2G runs both bodies in one launch
 int grid_for(const wgs_data *d, int blocks_per_cu) { return d->pipeline->num_cus * blocks_per_cu; }
 
@@ -530,10 +531,15 @@ template <bool TS> wgs_status enqueue_substep(wgs_data *d, int ts_slot, int part
         if (n > 0) {
             // ---- "p2g"
             const dim3 p2g_grid(grid_for(d, 5)), p2g_block(P2GCfg<D>::NW * 64);
-            if (d->cpic && d->last_ncpic != UINT32_MAX && d->last_ncpic >= P2G_PAIR_MIN_BLOCKS && !(dev.dbg & 8192u)) {
+            // Large one-way collider simulations ALWAYS run the paired launch, with the CPIC body cut to 168 VGPRs: the
+            // plain body then keeps its occupancy, so the pair costs nothing while the list is empty, and the choice
+            // does not follow the host's syncs (the two budgets differ in the last bit here and there).
+            const bool big_one_way = !d->two_way && n >= P2G_SMALL_BUDGET_MIN_PARTICLES && !(dev.dbg & 32768u);
+            if (d->cpic && (big_one_way || (d->last_ncpic != UINT32_MAX && d->last_ncpic >= P2G_PAIR_MIN_BLOCKS)) && !(dev.dbg & 8192u)) {
                 // many blocks near colliders (as of the last wgs_sync): both bodies in one launch (k_p2g_pair)
                 const dim3 pair_grid(2u * (uint32_t)grid_for(d, 5));
                 if (d->two_way) hipLaunchKernelGGL((k_p2g_pair<D, true>), pair_grid, p2g_block, 0, s, dev, side, epoch);
+                else if (big_one_way) hipLaunchKernelGGL((k_p2g_pair<D, false, 3>), pair_grid, p2g_block, 0, s, dev, side, epoch);
                 else hipLaunchKernelGGL((k_p2g_pair<D, false>), pair_grid, p2g_block, 0, s, dev, side, epoch);
             } else if (d->cpic) {
                 hipLaunchKernelGGL((k_p2g<D, false>), p2g_grid, p2g_block, 0, s, dev, side, 1, epoch);
@@ -693,7 +699,7 @@ static wgs_status create_impl(wgs_pipeline *pipeline, const wgs_sim_params *para
     // 256 = P2G without its accumulation loop, 512 = P2G without its particle loads. A/B of launch shapes, same results:
     // 128 = full k_bin on every substep (no k_rebin), 1024 = node cdf in a launch of its own (k_cdf) instead of
     // k_setup_scatter<CDF>, 4096 = the two G2P bodies as two launches, 8192 = the two P2G bodies always as two launches, 16384 = never the
-    // spill-free variant of the plastic G2P pair.
+    // spill-free variant of the plastic G2P pair, 32768 = never the small register budget of the one-way P2G pair.
     dev.dbg = getenv("WGS_DEBUG") ? (uint32_t)strtoul(getenv("WGS_DEBUG"), nullptr, 0) : 0u;
     dev.n_colliders = (uint32_t)num_colliders;
     d->cpic = num_colliders > 0;

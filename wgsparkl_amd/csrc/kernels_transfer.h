@@ -82,8 +82,18 @@ __global__ __launch_bounds__(P2GCfg<D>::NW * 64) void k_p2g(Dev d, int side, int
 // C2): a loss while the list is short — the two launches then simply follow each other —, a gain once the CPIC launch
 // is the longer of the two, because a near-collider block costs ~3x a plain one in latency and the launches no longer
 // add up. capi.hip switches on the list length the host last saw.
-template <int D, bool TWOWAY>
-__global__ __launch_bounds__(P2GCfg<D>::NW * 64) void k_p2g_pair(Dev d, int side, uint32_t epoch) {
+// WPE = waves per SIMD the register budget is cut for. 1 = whatever the CPIC body wants (203 VGPRs one-way: fastest
+// per near-collider block, but the plain body then runs at 2 waves per SIMD); 3 = 168 VGPRs: the CPIC body spills
+// 116 B and each of its blocks takes ~20 % longer, the plain body keeps its occupancy. The second wins when the plain
+// half is the long one or the list is long enough to be a throughput problem (1 M sand on the floor: P2G 54 -> 44 us,
+// 4 M sand between walls 259 -> 207 us), the first on small scenes with a short list (262 k cube on a heightfield:
+// 26 vs 31 us). The two budgets differ in the last bit here and there (another instruction selection), so the small
+// one is not chosen from the moment's list length: capi.hip runs it ALWAYS for one-way simulations from 600 k particles
+// on — with the plain body at full occupancy the pair costs nothing while the list is empty —, and smaller ones keep
+// the unconstrained body, whose paired and separate forms are bit-identical. The two-way body (256 VGPRs) is not
+// offered the small budget.
+template <int D, bool TWOWAY, int WPE = 1>
+__global__ __launch_bounds__(P2GCfg<D>::NW * 64, WPE) void k_p2g_pair(Dev d, int side, uint32_t epoch) {
     using Cfg = P2GCfg<D>;
     constexpr int BW = Dim<D>::BW, BS = Dim<D>::BSHIFT, TW = Dim<D>::TW, TILE = Dim<D>::TILE;
     constexpr int NT = Cfg::NW * 64;
