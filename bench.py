@@ -1,21 +1,28 @@
 #!/usr/bin/env python3
 """bench.py — particle-steps/s of the MLS-MPM substep on MI355X.
 
-Workload (BASELINE.json configs[1]): wgsparkl3d neo-Hookean elastic
-cube, 100^3 = 1M particles (8 per cell) in a 128^3-cell domain, fp32, synthetic
-lattice + jitter. One "step" = one substep of MpmPipeline::queue_step
-(sort -> P2G -> grid update -> fused G2P + particle update), inputs resident in HBM.
+Default workload (BASELINE.json configs[1]): wgsparkl3d neo-Hookean elastic cube, 100^3 = 1M
+particles (8 per cell) in a 128^3-cell domain, floor cuboid, fp32, synthetic lattice + jitter. One "step" = one
+substep of MpmPipeline::queue_step (sort -> P2G -> grid update -> fused G2P + particle update), inputs resident in HBM.
 
-  python bench.py --gpus N --steps K --warmup W
+  python bench.py --gpus N --steps K --warmup W [--config c2|c3|c5] [--scaling weak|strong]
 
-N > 1: one process per GPU (torch.distributed, backend nccl = RCCL). Weak scaling: N cubes side
-by side form one bar, cut into x-slabs; per substep each rank swaps the partial node sums of
-the interface layers and the migrating particles with its two neighbours (point-to-point over
-xGMI, no collective on the data path; wgsparkl_amd/sharded.py).
+--config: c2 (default, the headline), c3 = Drucker-Prager sand column, 4M, standing between the floor and four walls,
+c5 = pressure-only neo-Hookean fluid block, 16M (BASELINE.json configs[2], configs[4]).
+N > 1: one process per GPU, x-slab domain decomposition; per substep each rank swaps the partial node sums of the
+interface layers and the migrating particles with its two neighbours — RCCL point-to-point issued from inside the
+library (wgs_sharded_step, include/wgsparkl_hip.h), no collective on the data path. --scaling weak (default): N
+copies of the config side by side along x (fixed work per GPU); strong: the named size cut into N slabs (north_star's
+16M target: --config c5 --scaling strong). Without flags, the line also carries `extra` legs: the same cube after it
+landed on the floor, c3, and c5 (strong over the N GPUs), each with its own G2P roofline figure.
+`python bench.py --gpus N` outside a launcher starts the N ranks itself (torch.distributed.run as a child process).
 """
 import argparse
+import ctypes as C
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -23,11 +30,39 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable)
+KERNEL_ELASTIC = "k_g2p_pair (fused G2P + particle update; collider simulations run both bodies in this launch)"
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--config", choices=("c2", "c3", "c5"), default="c2")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak")
+    ap.add_argument("--n-side", type=int, default=None, help="particles per cube edge (c2: 100 -> 1M, the named config)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="skip the extra legs (landed cube, c3, c5)")
+    ap.add_argument("--no-floor", action="store_true", help="c2 without the floor cuboid of SURVEY 8d (no CPIC passes)")
+    ap.add_argument("--allow-debug-switches", action="store_true", help="run although WGS_DEBUG is set (A/B of launch shapes)")
+    return ap.parse_args()
+
+
+def spawn_ranks(args):
+    """`--gpus N` without a launcher: start the N ranks as a CHILD torch.distributed.run (never exec) and relay its exit
+    code; rank 0 of the child prints the JSON line on the shared stdout."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.run(cmd).returncode
 
 
 def cpu_baseline(scene, substeps):
     """The oracle (CPU restatement of the reference algorithm, C + OpenMP over the per-node / per-particle loops,
-    the sort stays serial) timed on the GPU box's host cores, on a bounded sample of the same workload."""
+    the sort stays serial) timed on the GPU box's host cores, on a bounded sample of the same workload. Returns the
+    oracle's final state too: bench.py checks the HIP path against it on the very bench data."""
     import numpy as np
     from oracle.orc import Oracle
     ps = scene["particles"]
@@ -37,31 +72,147 @@ def cpu_baseline(scene, substeps):
     t0 = time.perf_counter()
     st.step(substeps)
     dt = time.perf_counter() - t0
-    return ps.n * substeps / dt, dt, orc.num_threads
+    return ps.n * substeps / dt, dt, orc.num_threads, st
+
+
+def g2p_roofline(timings, k_ts, mark_ms, n, n_nodes, bytes_per_particle, kernel):
+    # one launch between the two marks of the "g2p" pass: event interval minus the cost of the closing mark (two marks
+    # recorded back to back in the same substeps); rocprofv3's average duration of the kernel (profiles/) agrees
+    interval = timings["g2p"] / k_ts
+    ms = max(interval - mark_ms, 1e-9)
+    algo = bytes_per_particle * n + 16.0 * n_nodes     # 160 B (elastic) / 216 B (Drucker-Prager) per particle + 16 B per node
+    achieved = algo / (ms * 1e-3) / 1e9
+    return {"bound": "hbm", "kernel": kernel, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+            "traffic": None, "traffic_source": None, "algorithmic_bytes_per_launch": algo, "avg_launch_ms": ms,
+            "event_interval_ms": interval, "event_mark_ms": mark_ms}
+
+
+class Leg:
+    """One timed workload on this rank: single-domain data (world == 1) or one slab of the decomposition."""
+
+    def __init__(self, env, scene, world, rank):
+        from wgsparkl_amd import MpmData
+        self.env, self.scene, self.world, self.rank = env, scene, world, rank
+        pipe = env["pipe"]
+        ps = scene["particles"]
+        self.n = ps.n
+        self.sharded = world > 1 or env["force_sharded"]
+        self.n_total = scene.get("global_particles", ps.n) if self.sharded else ps.n
+        self.bytes_per_particle = scene.get("bytes_per_particle", 160.0)
+        if not self.sharded:
+            self.data = MpmData.new(pipe, scene["params"], ps, scene["colliders"], scene["cell_width"], scene["grid_capacity"], scene["model"])
+            self.handle = self.data._h
+            self.parallelism = "1 GPU"
+            return
+        from wgsparkl_amd.sharded import GpuShard, NativeShard
+        lo, hi = scene["partition"].block_range(rank)
+        ny = int(round((float(ps.pos[:, 1].max()) - float(ps.pos[:, 1].min())) * 2.0 / scene["cell_width"])) + 1 if ps.n else 1
+        nz = int(round((float(ps.pos[:, 2].max()) - float(ps.pos[:, 2].min())) * 2.0 / scene["cell_width"])) + 1 if ps.n else 1
+        # Messages travel at their full capacity (no size handshake), so the capacities are sized from the workload: a
+        # face touches at most (ny / 8 + 3) x (nz / 8 + 3) blocks (+ margin); a handful of particles cross a cut per
+        # substep while the body falls along y. An overflow is reported by wgs_sync and by the particle count below.
+        kw = dict(particle_capacity=int(ps.n * 1.25) + 4096, model=scene["model"], halo_capacity_blocks=(ny // 8 + 3) * (nz // 8 + 3) + 32,
+                  migrant_capacity=max(512, (ny * nz) // 16))
+        args = (pipe, scene["params"], ps, scene["global_ids"], scene["colliders"], scene["cell_width"], scene["grid_capacity"], lo, hi,
+                rank > 0, rank < world - 1)
+        if env["native"]:
+            self.data = NativeShard(*args, comm=env["comm"], **kw)
+            self.parallelism = f"{world} x-slabs, halo + migration over RCCL send/recv inside wgs_sharded_step"
+        else:
+            self.data = GpuShard(*args, **kw)
+            self.parallelism = f"{world} x-slabs, halo + migration over torch.distributed p2p (python-driven protocol)"
+        self.handle = self.data._h
+
+    def run(self, k):
+        if not self.sharded:
+            self.env["pipe"].step(self.data, k)
+        elif self.env["native"]:
+            self.data.step(k)
+        else:
+            from wgsparkl_amd.sharded import substep_phases
+            for _ in range(k):
+                substep_phases(self.data, self.env["exchange"])
+
+    def timed(self, steps, warmup):
+        env = self.env
+        torch, dist = env["torch"], env["dist"]
+        self.run(warmup)
+        self.data.sync()
+        env["barrier"]()
+        t0 = time.perf_counter()
+        self.run(steps)                      # exactly K substeps
+        self.data.sync()
+        env["barrier"]()
+        elapsed = time.perf_counter() - t0
+        if dist is not None:
+            t = torch.tensor([elapsed], device=env["device"], dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+            cnt = torch.tensor([self.data.num_particles()], device=env["device"], dtype=torch.int64)
+            dist.all_reduce(cnt)
+            assert int(cnt.item()) == self.n_total, f"particles lost in the exchange: {int(cnt.item())} != {self.n_total}"
+        return elapsed
+
+    def result(self, steps, elapsed, kernel_name):
+        """Throughput + per-pass device times (HIP events on the data's own stream) of up to 64 more substeps of the local
+        data (a slab steps without its neighbours here: kernel timing only, after the timed region)."""
+        from wgsparkl_amd import _ffi
+        pipe = self.env["pipe"]
+        k_ts = min(steps, 64)
+        _ffi.check(pipe.lib, pipe.lib.wgs_step(pipe._h, self.handle, k_ts, 1))
+        self.data.sync()
+        ms = (C.c_float * _ffi.WGS_NUM_PASSES)()
+        _ffi.check(pipe.lib, pipe.lib.wgs_read_timings(self.handle, ms))
+        timings = dict(zip(_ffi.PASS_NAMES, [float(x) for x in ms]))
+        st = pipe.T.Stats()
+        _ffi.check(pipe.lib, pipe.lib.wgs_get_stats(self.handle, C.byref(st)))
+        ovh = C.c_float(0.0)
+        pipe.lib.wgs_read_timing_overhead(self.handle, C.byref(ovh))   # cost of one timing mark, measured in the same substeps
+        nblocks = int(st.num_active_blocks)
+        return {"value": self.n_total * steps / elapsed, "ms_per_step": elapsed / steps * 1e3, "steps": steps,
+                "global_particles": self.n_total, "active_blocks_rank0": nblocks, "near_collider_blocks_rank0": int(st.num_near_collider_blocks),
+                "parallelism": self.parallelism,
+                "roofline": g2p_roofline(timings, k_ts, float(ovh.value), self.n, nblocks * 64, self.bytes_per_particle, kernel_name),
+                "pass_ms_per_step": {k: v / k_ts for k, v in timings.items()}}
+
+    def close(self):
+        self.data.close()
+
+
+def measure(env, scene, world, rank, steps, warmup, kernel_name, settle=0):
+    leg = Leg(env, scene, world, rank)
+    if settle:
+        leg.run(settle)
+    res = leg.result(steps, leg.timed(steps, warmup), kernel_name)
+    leg.close()
+    return res
 
 
 def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=100)
-    ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--n-side", type=int, default=100, help="particles per cube edge (100 -> 1M, the named config)")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-floor", action="store_true", help="drop the floor cuboid of SURVEY 8d C2 (no CPIC passes)")
-    args = ap.parse_args()
-
+    args = parse_args()
+    env_world = os.environ.get("WORLD_SIZE")
+    if env_world is None and args.gpus > 1:
+        sys.exit(spawn_ranks(args))                      # before anything touches the GPU
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    world = int(env_world or "1")
+    force_sharded = os.environ.get("WGS_BENCH_FORCE_SHARDED") == "1"
+    if world != args.gpus and not force_sharded:
+        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch with --nproc-per-node {args.gpus}", file=sys.stderr)
+        sys.exit(2)
+    dbg_env = os.environ.get("WGS_DEBUG")
+    if dbg_env not in (None, "", "0") and not args.allow_debug_switches:
+        print(f"bench.py: WGS_DEBUG={dbg_env} is set (developer launch-shape switches); unset it or pass --allow-debug-switches", file=sys.stderr)
+        sys.exit(2)
+
     import torch
     dist = None
-    # WGS_BENCH_FORCE_SHARDED=1: the N > 1 code path (RCCL process group, sharded data, collectives of the harness)
-    # with however many ranks were launched, even one — a functional check for 1-GPU boxes
-    sharded_path = world > 1 or os.environ.get("WGS_BENCH_FORCE_SHARDED") == "1"
+    # WGS_BENCH_FORCE_SHARDED=1: the N > 1 code path (process group, sharded data, wgs_sharded_step) with however many
+    # ranks were launched, even one — a functional check for 1-GPU boxes
+    sharded_path = world > 1 or force_sharded
+    one_gpu = os.environ.get("WGS_BENCH_ONE_GPU") == "1"   # all ranks on cuda:0 over gloo: functional test of the exchanges
     if sharded_path:
         import torch.distributed as dist
-        # WGS_BENCH_ONE_GPU=1: functional test of the N > 1 path on a 1-GPU box (all ranks on cuda:0, gloo)
-        one_gpu = os.environ.get("WGS_BENCH_ONE_GPU") == "1"
         if one_gpu:
             local_rank = 0
         torch.cuda.set_device(local_rank)
@@ -70,9 +221,10 @@ def main():
         else:
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     dev_index = local_rank if sharded_path else 0
+    device = f"cuda:{dev_index}"
 
     import numpy as np
-    from wgsparkl_amd import MpmData, MpmPipeline, scenes
+    from wgsparkl_amd import MpmPipeline, scenes
 
     def barrier():
         torch.cuda.synchronize()
@@ -81,156 +233,134 @@ def main():
         torch.cuda.synchronize()
 
     pipe = MpmPipeline(dev_index, 3)
-    if not sharded_path:
-        scene = scenes.neo_hookean_cube(n_side=args.n_side, with_floor=not args.no_floor)
-        ps = scene["particles"]
-        n = ps.n
-        n_total = n
-        data = MpmData.new(pipe, scene["params"], ps, scene["colliders"], scene["cell_width"],
-                           scene["grid_capacity"], scene["model"])
-        run = lambda k: pipe.step(data, k)          # K substeps enqueued asynchronously
-        sync = data.sync
-        parallelism = "1 GPU"
+    build_info = pipe.lib.wgs_build_info().decode()
+    if "WGS_ABLATE" in build_info:
+        print("bench.py: the library was built with -DWGS_ABLATE (ablation switches compiled in): not a product build", file=sys.stderr)
+        sys.exit(2)
+    env = dict(torch=torch, dist=dist, pipe=pipe, barrier=barrier, device=device, force_sharded=force_sharded, native=False, comm=None,
+               exchange=None)
+    transport_note = None
+    if sharded_path:
+        # The substep protocol runs inside the library over RCCL (wgs_sharded_step). WGS_EXCHANGE=torch, a gloo process
+        # group (one-GPU functional mode) or a failing communicator fall back to the python-driven protocol over
+        # torch.distributed point-to-point — on every rank or none.
+        want_native = os.environ.get("WGS_EXCHANGE", "rccl") == "rccl" and dist.get_backend() == "nccl"
+        comm = None
+        if want_native:
+            try:
+                from wgsparkl_amd.sharded import NativeComm
+                comm = NativeComm(pipe, dist, rank, world)
+            except Exception as e:  # noqa: BLE001 — any failure here means "use the torch transport", on every rank
+                transport_note = f"wgs_comm_create failed ({e}); python-driven protocol over torch.distributed"
+                print(f"[bench rank {rank}] {transport_note}", file=sys.stderr)
+                comm = None
+        ok = torch.tensor([1 if comm is not None else 0], device=device if dist.get_backend() == "nccl" else "cpu", dtype=torch.int32)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)      # all ranks or none
+        if int(ok.item()) == 1:
+            env["native"], env["comm"] = True, comm
+        else:
+            from wgsparkl_amd.sharded import FixedExchange
+            env["exchange"] = FixedExchange(dist, rank, world)
+
+    # ---- the headline workload
+    default_workload = args.config == "c2" and args.n_side in (None, 100) and args.scaling == "weak" and not args.no_floor
+    if not sharded_path and args.config == "c2":
+        scene = scenes.neo_hookean_cube(n_side=args.n_side or 100, with_floor=not args.no_floor)
+        scene["name"] = (f"wgsparkl3d neo-Hookean elastic cube, {scene['particles'].n} particles, 128^3-cell domain, h=1, dt=1/1200, "
+                         "8 particles/cell, " + ("no collider" if args.no_floor else "floor cuboid (CPIC passes on)") + ", free fall")
+        scene["bytes_per_particle"] = 160.0
+    elif default_workload:
+        scene = scenes.neo_hookean_bar(n_side=100, world=world, rank=rank)          # N C2 cubes side by side = one elastic bar
+        scene["name"] = f"wgsparkl3d neo-Hookean elastic cube x {world} side by side (one bar), 1000000 particles/GPU, floor cuboid"
+        scene["bytes_per_particle"] = 160.0
     else:
-        # Weak scaling: `world` C2 cubes side by side along x form one elastic bar; x-slab domain
-        # decomposition, one slab per GPU, halo + migration exchanges over RCCL point-to-point (sharded.py).
-        from wgsparkl_amd.sharded import FixedExchange, GpuShard, RcclExchange, finish_migration, pipelined_substep, substep_phases
-        scene = scenes.neo_hookean_bar(n_side=args.n_side, world=world, rank=rank)
+        scene = scenes.config_scene(args.config, world, rank if sharded_path else None, args.scaling, n_side=args.n_side)
         if args.no_floor:
             scene["colliders"] = []
-        ps = scene["particles"]
-        n = ps.n
-        n_total = scene["global_particles"]
-        lo, hi = scene["partition"].block_range(rank)
-        data = GpuShard(pipe, scene["params"], ps, scene["global_ids"], scene["colliders"], scene["cell_width"],
-                        scene["grid_capacity"], lo, hi, rank > 0, rank < world - 1,
-                        particle_capacity=int(n * 1.25) + 4096, model=scene["model"],
-                        # Messages travel at their full capacity (no size handshake), so the capacities are sized from
-                        # the workload: a face of the bar touches at most (n_side / 8 + 3)^2 blocks (+ margin), and the
-                        # bar falls along y — a handful of particles cross a cut per substep. An overflow is reported
-                        # by wgs_sync and by the particle count checked below.
-                        halo_capacity_blocks=(args.n_side // 8 + 3) ** 2 + 32, migrant_capacity=512)
-        # transport: RCCL called directly (ctypes) unless WGS_EXCHANGE=torch or the process group is not RCCL (the
-        # 1-GPU functional mode runs over gloo)
-        use_rccl = os.environ.get("WGS_EXCHANGE", "rccl") == "rccl" and dist.get_backend() == "nccl"
-        exch = None
-        if use_rccl:
-            try:
-                exch = RcclExchange(dist, rank, world)
-                if os.environ.get("WGS_BENCH_FORCE_SHARDED") == "1":
-                    exch.selftest()
-                exch.neighbour_test()
-            except Exception as e:  # noqa: BLE001 — any failure here means "use the torch transport", on every rank
-                print(f"[bench rank {rank}] direct RCCL transport unavailable ({e}); using torch.distributed p2p", file=sys.stderr)
-                exch = None
-            ok = torch.tensor([1 if exch is not None else 0], device=f"cuda:{local_rank}", dtype=torch.int32)
-            dist.all_reduce(ok, op=dist.ReduceOp.MIN)      # all ranks or none
-            if int(ok.item()) == 0:
-                exch, use_rccl = None, False
-        if exch is None:
-            exch = FixedExchange(dist, rank, world)
-        transport = "RCCL send/recv (direct)" if use_rccl else "torch.distributed p2p"
+    main_res = measure(env, scene, world, rank, args.steps, args.warmup,
+                       ("k_g2p_pair<plastic>" if args.config == "c3" else KERNEL_ELASTIC) if scene["colliders"] else "k_g2p_update (fused G2P + particle update)")
 
-        # Both messages of a substep are issued on the substep's own stream, in order (substep_phases). The pipelined
-        # order (migration on a side stream while the next substep re-bins its residents, WGS_SHARD_ORDER=pipelined) is
-        # SLOWER on this stack: measured with a rank that is its own two neighbours (every RCCL call of an interior
-        # rank issued, tests/gpu_host_cost.py), 206 us per substep in order against 230 us pipelined — the two
-        # cross-stream dependencies cost more than the overlap gains.
-        pipelined = os.environ.get("WGS_SHARD_ORDER", "inorder") == "pipelined"
+    out = None
+    if rank == 0:
+        rl = main_res["roofline"]
+        prof = sorted(__import__("glob").glob(os.path.join(ROOT, "profiles", "r*_pmc_g2p.json")))[-1:]
+        if prof and default_workload and world == 1:
+            try:   # PMC byte counters of this very command, collected by rocprofv3 in its own passes and committed
+                rl["traffic"] = json.load(open(prof[0])).get("hbm_bytes_per_launch")
+                rl["traffic_source"] = os.path.relpath(prof[0], ROOT) + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, committed; not measured in this run)"
+            except Exception:
+                pass
+        out = {
+            "metric": "particle-steps/sec", "value": main_res["value"], "unit": "particle-steps/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": main_res["ms_per_step"],
+            "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": scene["name"], "config": args.config, "particles_per_gpu": main_res["global_particles"] // world,
+                       "global_particles": main_res["global_particles"], "active_blocks_rank0": main_res["active_blocks_rank0"],
+                       "parallelism": main_res["parallelism"]},
+            "roofline": rl,
+            "pass_ms_per_step": main_res["pass_ms_per_step"],
+            "build": {"info": build_info, "WGS_DEBUG": dbg_env, "transport_note": transport_note},
+            "notes": "the every-64-substeps hash-table rebuild (k_bin instead of k_rebin, +0.06-0.26 ms once) falls inside the timed region "
+                     "whenever warmup + steps cross a multiple of 64; amortised ~1 us per substep",
+        }
 
-        def run(k):
-            if not pipelined:
-                for _ in range(k):
-                    substep_phases(data, exch)
-                return
-            pending = None       # the migration of a substep stays in flight while the next one re-bins its residents
-            for _ in range(k):
-                pending = pipelined_substep(data, exch, pending)
-            finish_migration(data, pending)
-        sync = data.sync
-        parallelism = f"{world} x-slabs, halo + migration over {transport}"
+    # ---- CPU baseline + validation of the HIP path on the bench data itself (rank 0, N = 1)
+    if rank == 0 and not args.no_cpu_baseline and not sharded_path:
+        from wgsparkl_amd import MpmData
+        sub = 20 if scene["particles"].n <= 2_000_000 else 4
+        v, secs, threads, st = cpu_baseline(scene, sub)
+        out["cpu_baseline"] = {"value": v, "unit": "particle-steps/s", "cores": threads, "kind": "port",
+                               "sample": f"{sub} substeps of the same {scene['particles'].n}-particle workload, C + OpenMP oracle "
+                                         f"(CPU restatement of the reference WGSL algorithm, {threads} threads; the "
+                                         f"hash-grid sort is serial), {secs:.1f} s; "
+                                         "reference WGSL via wgpu+lavapipe: unavailable (no cargo/rustc/Vulkan ICD)"}
+        chk = MpmData.new(pipe, scene["params"], scene["particles"], scene["colliders"], scene["cell_width"], scene["grid_capacity"], scene["model"])
+        pipe.step(chk, sub + 1)               # the oracle did 1 + sub substeps
+        chk.sync()
+        got = chk.read_particles()
+        rel = lambda a, b: float(np.sqrt(np.mean((a.astype(np.float64) - b) ** 2)) / max(np.sqrt(np.mean(np.asarray(b, np.float64) ** 2)), 1e-30))
+        gc, oc = chk.read_grid()[0], st.grid_records()[0]
+        val = {"substeps": sub + 1, "against": "fp32 oracle (the reference's arithmetic) on the bench data",
+               "pos_rel_rms": rel(got.pos, st.arr["pos"]), "vel_rel_rms": rel(got.vel, st.arr["vel"]),
+               "def_grad_rel_rms": rel(got.def_grad, st.arr["def_grad"]),
+               "active_cells_identical": bool(gc.shape == oc.shape and np.array_equal(gc, oc))}
+        val["ok"] = bool(val["active_cells_identical"] and val["pos_rel_rms"] < 1e-5 and val["vel_rel_rms"] < 1e-4 and val["def_grad_rel_rms"] < 1e-5)
+        out["validation"] = val
+        chk.close()
+        del st, got, chk
+        if not val["ok"]:
+            print(json.dumps(out))
+            print("bench.py: the HIP path disagrees with the oracle on the bench data", file=sys.stderr)
+            sys.exit(3)
 
-    run(args.warmup)
-    sync()
-    barrier()
-    t0 = time.perf_counter()
-    run(args.steps)                      # exactly K substeps
-    sync()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], device=f"cuda:{local_rank}", dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-        cnt = torch.tensor([data.num_particles()], device=f"cuda:{local_rank}", dtype=torch.int64)
-        dist.all_reduce(cnt)
-        assert int(cnt.item()) == n_total, f"particles lost in the exchange: {int(cnt.item())} != {n_total}"
-
-    # Per-pass device times (HIP events on the data's own stream) of K more substeps of the local slab.
-    k_ts = min(args.steps, 64)
-    if not sharded_path:
-        pipe.step(data, k_ts, timestamps=True)
-        data.sync()
-        timings = data.read_timings()
-        stats = data.stats()
-    else:
-        from wgsparkl_amd import _ffi
-        import ctypes as C
-        _ffi.check(pipe.lib, pipe.lib.wgs_step(pipe._h, data._h, k_ts, 1))   # local slab only (no halo): kernel timing
-        data.sync()
-        ms = (C.c_float * _ffi.WGS_NUM_PASSES)()
-        _ffi.check(pipe.lib, pipe.lib.wgs_read_timings(data._h, ms))
-        timings = dict(zip(_ffi.PASS_NAMES, [float(x) for x in ms]))
-        st = pipe.T.Stats()
-        _ffi.check(pipe.lib, pipe.lib.wgs_get_stats(data._h, C.byref(st)))
-        stats = {"num_active_blocks": int(st.num_active_blocks)}
-    n_nodes = stats["num_active_blocks"] * 64
-    import ctypes as _C
-    _ovh = _C.c_float(0.0)
-    pipe.lib.wgs_read_timing_overhead(data._h, _C.byref(_ovh))   # cost of one timing mark, measured in the same substeps
-    mark_ms = float(_ovh.value)
+    # ---- extra legs (default command only): other states of the solver, each with its own G2P roofline figure
+    if not args.no_extra and default_workload and not one_gpu:
+        extra = {}
+        k, w = min(args.steps, 50), 5
+        slim = lambda r, name: {"workload": name, "value": r["value"], "unit": "particle-steps/s", "ms_per_step": r["ms_per_step"],
+                                "global_particles": r["global_particles"], "active_blocks_rank0": r["active_blocks_rank0"],
+                                "near_collider_blocks_rank0": r["near_collider_blocks_rank0"], "steps": r["steps"],
+                                "roofline_g2p": {x: r["roofline"][x] for x in ("achieved", "frac", "avg_launch_ms", "algorithmic_bytes_per_launch")},
+                                "pass_ms_per_step": r["pass_ms_per_step"], "parallelism": r["parallelism"]}
+        if not sharded_path:
+            sc = scenes.neo_hookean_cube(n_side=100, with_floor=True)
+            sc["particles"].pos[:, 1] -= 5.7          # lowered onto the floor, impact at -3 cells/s: contact state after 200 substeps
+            sc["particles"].vel[:, 1] = -3.0
+            sc["bytes_per_particle"] = 160.0
+            extra["c2_landed"] = slim(measure(env, sc, 1, 0, k, w, KERNEL_ELASTIC, settle=200 - w),
+                                      "the C2 cube after it landed: lowered onto the floor with a -3 cells/s impact, 200 substeps before the timed region")
+            sc = scenes.config_scene("c3")
+            extra["c3"] = slim(measure(env, sc, 1, 0, k, w, "k_g2p_pair<plastic>"), sc["name"])
+            del sc
+        sc = scenes.config_scene("c5", world, rank if sharded_path else None, "strong")
+        r = measure(env, sc, world, rank, k, w, KERNEL_ELASTIC)
+        if rank == 0:
+            extra["c5_strong"] = slim(r, sc["name"] + (f", cut into {world} x-slabs (strong scaling: fixed 16 M global)" if world > 1 else ", one GPU"))
+            out["extra"] = extra
+        del sc
 
     if rank == 0:
-        value = n_total * args.steps / elapsed
-        # one launch between the two marks of the "g2p" pass: event interval minus the cost of the closing mark
-        # (two marks recorded back to back in the same substeps); rocprofv3's average duration of k_g2p_update
-        # (profiles/) agrees with this, the raw interval is ~5 us longer
-        g2p_interval_ms = timings["g2p"] / k_ts
-        g2p_ms = max(g2p_interval_ms - mark_ms, 1e-9)
-        # fused G2P + particle update, elastic: 160 B per particle + 16 B per active node
-        algo_bytes = 160.0 * n + 16.0 * n_nodes
-        achieved = algo_bytes / (g2p_ms * 1e-3) / 1e9 if g2p_ms > 0 else 0.0
-        traffic = None
-        prof = sorted(__import__("glob").glob(os.path.join(ROOT, "profiles", "r*_pmc_g2p.json")))[-1:] or [""]
-        prof = prof[0]
-        if os.path.exists(prof) and args.n_side == 100:
-            try:
-                traffic = json.load(open(prof)).get("hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
-        out = {
-            "metric": "particle-steps/sec", "value": value, "unit": "particle-steps/s", "n_gpus": world,
-            "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
-            "data": "synthetic",
-            "config": {"workload": f"wgsparkl3d neo-Hookean elastic cube, {n} particles/GPU, 128^3-cell domain, "
-                                   f"h=1, dt=1/1200, 8 particles/cell, " + ("no collider" if args.no_floor else "floor cuboid (CPIC passes on)"),
-                       "particles_per_gpu": n_total // world, "global_particles": n_total,
-                       "active_blocks_rank0": stats["num_active_blocks"], "parallelism": parallelism},
-            "roofline": {"bound": "hbm", "kernel": "k_g2p_pair (fused G2P + particle update; collider simulations run both bodies in this launch)" if not args.no_floor else "k_g2p_update (fused G2P + particle update)",
-                         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "algorithmic_bytes_per_launch": algo_bytes, "avg_launch_ms": g2p_ms, "event_interval_ms": g2p_interval_ms, "event_mark_ms": mark_ms},
-            "pass_ms_per_step": {k: v / k_ts for k, v in timings.items()},
-        }
-        if not args.no_cpu_baseline and world == 1:
-            sub = 20
-            v, secs, threads = cpu_baseline(scene, sub)
-            out["cpu_baseline"] = {"value": v, "unit": "particle-steps/s", "cores": threads, "kind": "port",
-                                   "sample": f"{sub} substeps of the same {n}-particle workload, C + OpenMP oracle "
-                                             f"(CPU restatement of the reference WGSL algorithm, {threads} threads; the "
-                                             f"hash-grid sort is serial), {secs:.1f} s; "
-                                             "reference WGSL via wgpu+lavapipe: unavailable (no cargo/rustc/Vulkan ICD)"}
         print(json.dumps(out))
     if dist is not None:
         dist.barrier()

@@ -175,6 +175,9 @@ typedef struct wgs_data wgs_data;
 const char *wgs_last_error(void);
 /* 2 or 3: the dimension this library was built for (cargo features dim2/dim3, src/lib.rs:4-15). */
 int32_t wgs_dim(void);
+/* Build identification: dimension, target arch and — never in a shipped library — "WGS_ABLATE" when the kernels were
+ * compiled with their ablation switches (bench.py refuses such a build). */
+const char *wgs_build_info(void);
 
 /* MpmPipeline::new(&Device) -> Result<Self, ComposerError>  (src/pipeline.rs:176-193).
  * Binds to HIP device `hip_device`; fails with WGS_ERR_NO_DEVICE when there is none
@@ -208,7 +211,7 @@ wgs_status wgs_set_collider_poses(wgs_data *data, const wgs_pose *poses, const f
 /* queue.write_buffer(bodies.vels()) (src_testbed/step.rs:98-119) */
 wgs_status wgs_set_body_velocities(wgs_data *data, const wgs_velocity *vels, size_t n);
 /* GpuBodySet::from_rapier's local mass properties (src/pipeline.rs:145, wgrapier): which bodies are dynamic.
- * Stream-ordered like the other setters. Not available on sharded data (WGS_ERR_UNSUPPORTED). */
+ * Stream-ordered like the other setters. On sharded data the impulses are reduced over the ranks (wgs_sharded_step). */
 wgs_status wgs_set_body_mass_properties(wgs_data *data, const wgs_mass_properties *mprops, size_t n);
 /* Rigid particles of the mesh colliders = the buffers GpuRigidParticles::from_rapier builds on the host
  * (src/solver/particle3d.rs:100-150, 2D src/solver/particle2d.rs:75-125; sampling step = cell width,
@@ -319,6 +322,38 @@ wgs_status wgs_shard_add_migrants(wgs_data *data, const void *in_lo, const void 
                                   const void *out_hi, uint32_t capacity_records);
 /* full records of every particle currently owned (read-back of a sharded run; BLOCKING) */
 wgs_status wgs_shard_export(wgs_data *data, void *device_buf, uint32_t capacity_records, uint32_t *count);
+
+
+/* ---- One call per frame on sharded data (what src_testbed/step.rs:122-128 does on one device) --------------------
+ * The whole substep protocol above — step_begin, pack_halos, exchange, add_halos, step_end, pack_migrants, exchange,
+ * add_migrants — driven from inside the library, RCCL point-to-point as the transport (bound at run time with
+ * dlopen("librccl.so.1"): the library has no link-time dependency on RCCL). One process per GPU:
+ *   rank 0: wgs_comm_get_unique_id(id) -> the host broadcasts the 128 bytes (MPI, torch.distributed, a file ...)
+ *   every rank: wgs_comm_create(pipeline, id, rank, world, 0, &comm)      (ncclCommInitRank; rank r talks to r-1, r+1)
+ *               wgs_data_create_sharded(...); wgs_shard_attach(data, comm, 0, 0, halo_cap, mig_cap)
+ *   per frame:  wgs_sharded_step(pipeline, data, num_substeps); ... wgs_sync(data)
+ * Message buffers are owned by the wgs_data, fixed capacity (records per face), sent whole (no size handshake); an
+ * overflow is reported by the next wgs_sync. Two-way coupled (dynamic) bodies: every rank accumulates the fixed-point
+ * impulses of its own particles (src/solver/p2g.wgsl:142-155) and the 16 x 8 int32 sums are all-reduced before
+ * integrate_bodies (src/solver/rigid_impulses.wgsl:94-137) — integers, so the result does not depend on the order. */
+#define WGS_COMM_ID_BYTES 128          /* ncclUniqueId */
+#define WGS_COMM_SELF_NEIGHBOURS 1     /* flag: the rank is its own lower and upper neighbour (one-GPU timing proxy of an interior rank) */
+typedef struct wgs_comm wgs_comm;
+wgs_status wgs_comm_get_unique_id(uint8_t id[WGS_COMM_ID_BYTES]);
+wgs_status wgs_comm_create(wgs_pipeline *pipeline, const uint8_t id[WGS_COMM_ID_BYTES], int32_t rank, int32_t world,
+                           int32_t flags, wgs_comm **out);
+void wgs_comm_destroy(wgs_comm *comm);
+/* Allocates and registers the four outgoing and four incoming message buffers of this slab. With a communicator the
+ * neighbours are the ranks next to comm's (has_lower / has_upper are ignored); comm == NULL = a slab of a lockstep
+ * group inside one process (wgs_sharded_step_lockstep), or a slab without neighbours. */
+wgs_status wgs_shard_attach(wgs_data *data, wgs_comm *comm, int32_t has_lower, int32_t has_upper,
+                            uint32_t halo_capacity_blocks, uint32_t migrant_capacity);
+/* `num_substeps` whole substeps of this rank's slab, asynchronous (MpmPipeline::queue_step + encode x N + submit,
+ * src/pipeline.rs:195-281, for one slab of the decomposition). Every rank must call it with the same count. */
+wgs_status wgs_sharded_step(wgs_pipeline *pipeline, wgs_data *data, uint32_t num_substeps);
+/* The same phases for `num_slabs` slabs that live in ONE process on ONE device (passed in x order, attached with
+ * comm == NULL), device-to-device copies as the transport: decomposition tests on a single GPU. */
+wgs_status wgs_sharded_step_lockstep(wgs_pipeline *pipeline, wgs_data **slabs, uint32_t num_slabs, uint32_t num_substeps);
 
 #ifdef __cplusplus
 }

@@ -109,6 +109,73 @@ def test_c4_eight_million_corotated_with_kinematic_paddle(hip_libs):
     assert body["translation"][0] < sc["colliders"][1].translation[0]
 
 
+def test_c5_sixteen_million_fluid(hip_libs):
+    """configs[4] at full size on ONE GPU (16 M particles fit one wgs_data: the limit is ~21 M): 256 x 250 x 250
+    pressure-only neo-Hookean particles in free fall over the floor. Size-independent properties: the sort is a
+    permutation grouped by block, P2G conserves mass, total momentum follows M g t, a uniform field keeps F = I."""
+    sc = scenes.fluid_block()
+    ps = sc["particles"]
+    n = ps.n
+    assert n == 16_000_000 and np.all(ps.mu == 0.0)
+    k = 6
+    data = run_gpu(sc, k)
+    check_sort_structure(data, n)
+    s = data.stats()
+    assert s["overflow"] == 0 and s["num_active_blocks"] >= 32 * 32 * 32
+    cells, vm, *_ = data.read_grid()
+    m = float(ps.mass[0]) * n
+    assert abs(vm[:, 3].astype(np.float64).sum() - m) < 1e-5 * m
+    got = data.read_particles()
+    g, dt = np.array([0.0, -9.81, 0.0]), sc["params"].dt
+    assert np.allclose(got.vel, (g * dt * k).astype(np.float32), atol=1e-5)
+    assert np.abs(got.def_grad - np.eye(3, dtype=np.float32).reshape(-1)).max() < 1e-5
+    assert np.array_equal(got.mass, ps.mass)
+    del got
+    # and the block must react as a fluid once compressed: F = 0.98 I => pressure pushes the free faces outwards
+    sc2 = scenes.fluid_block(64, 64, 64, with_floor=False)
+    sc2["particles"].def_grad[:, [0, 4, 8]] = np.float32(0.98)
+    sc2["params"] = SimulationParams(gravity=(0.0, 0.0, 0.0), dt=sc2["params"].dt)
+    got2 = run_gpu(sc2, 20).read_particles()
+    x = got2.pos[:, 0]
+    assert got2.vel[x < x.min() + 1.0, 0].mean() < -1e-3 and got2.vel[x > x.max() - 1.0, 0].mean() > 1e-3
+    p = (got2.mass[:, None].astype(np.float64) * got2.vel).sum(0)
+    assert np.abs(p).max() < 1e-4 * (got2.mass[:, None].astype(np.float64) * np.abs(got2.vel)).sum() + 1e-6
+
+
+def test_c5_strong_scaling_slabs_on_one_gpu(hip_libs):
+    """The decomposition bench.py --config c5 --scaling strong uses, 8 x-slabs of the fluid block advanced in
+    lockstep on one GPU at a reduced y/z extent: nobody is lost, the slabs reproduce the single-domain run."""
+    from helpers import pipeline
+    from wgsparkl_amd import MpmData
+    from wgsparkl_amd.sharded import GpuShard, lockstep_substep
+    world, dims, k = 8, (256, 24, 24), 12
+    pipe = pipeline(3)
+    full = scenes.fluid_block(*dims)
+    vel = lambda gid: np.stack([1.5 * np.sin(0.37 * gid), 0.3 * np.cos(0.11 * gid), 0.2 * np.sin(0.05 * gid)], 1).astype(np.float32)
+    full["particles"].vel[:] = vel(np.arange(full["particles"].n, dtype=np.float64))
+    ref = run_gpu(full, k).read_particles()
+    shards = []
+    for rank in range(world):
+        sc = scenes.fluid_block(*dims, world=world, rank=rank)
+        ps = sc["particles"]
+        ps.vel[:] = vel(sc["global_ids"].astype(np.float64))
+        lo, hi = sc["partition"].block_range(rank)
+        shards.append(GpuShard(pipe, sc["params"], ps, sc["global_ids"], sc["colliders"], sc["cell_width"],
+                               sc["grid_capacity"], lo, hi, rank > 0, rank < world - 1,
+                               particle_capacity=int(ps.n * 1.5) + 4096, model=sc["model"],
+                               halo_capacity_blocks=256, migrant_capacity=2048))
+    for _ in range(k):
+        lockstep_substep(shards)
+    ids, pos, velo = [], [], []
+    for s in shards:
+        s.sync()
+        e = s.export()
+        ids.append(e["ids"]); pos.append(e["pos"]); velo.append(e["vel"])
+    ids = np.concatenate(ids); pos = np.concatenate(pos); velo = np.concatenate(velo)
+    assert len(ids) == full["particles"].n and len(np.unique(ids)) == len(ids)
+    assert np.abs(pos - ref.pos[ids]).max() < 1e-5 and np.abs(velo - ref.vel[ids]).max() < 2e-4
+
+
 def test_bench_slabs_at_full_size_fit_their_exchange_buffers(hip_libs):
     """bench.py's N > 1 workload at its real size per rank (1M particles, two neighbouring slabs of the bar on one
     GPU): the halo / migration buffers sized from the face area do not overflow and nobody is lost."""

@@ -154,3 +154,40 @@ def test_particles_rest_on_floor(oracle_libs):
     assert np.isfinite(st.arr["pos"]).all()
     assert st.arr["pos"][:, 1].min() > 1.5           # floor top at y = 2, penalty keeps particles near/above it
     assert (st.arr["cdf_affinity"] & 1).any()
+
+
+def test_fluid_is_the_pressure_only_neo_hookean(oracle_libs):
+    """configs[4] (C5): the "weakly-compressible fluid" is src/models/neo_hookean_elasticity.wgsl:14-25 with mu = 0,
+    i.e. tau = lambda * ln(max(det F, 1e-10)) * I whatever the shear in F (fp64 restatement)."""
+    from oracle.orc import Oracle
+    orc = Oracle(3, np.float64)
+    rng = np.random.default_rng(17)
+    lam = 1.0e7
+    for _ in range(20):
+        F = np.eye(3) + rng.normal(0, 0.2, (3, 3))
+        if np.linalg.det(F) <= 0:
+            continue
+        tau = orc.kirchoff_stress(1, lam, 0.0, F.T.reshape(-1))          # column-major
+        want = lam * np.log(np.linalg.det(F)) * np.eye(3)
+        assert np.allclose(np.asarray(tau).reshape(3, 3), want, rtol=1e-12, atol=1e-9 * lam)
+
+
+def test_fluid_block_scene_is_config_5():
+    """BASELINE.json configs[4] / SURVEY 8d C5: 256 x 250 x 250 = 16 M particles, mu = 0, every decomposition generates
+    the same particles (checked at a reduced y/z extent: the generator is separable)."""
+    from wgsparkl_amd import scenes
+    full = scenes.fluid_block(256, 6, 6)
+    assert full["global_particles"] == 256 * 36 and full["particles"].n == 256 * 36
+    assert 256 * 250 * 250 == 16_000_000
+    ps = full["particles"]
+    assert np.all(ps.mu == 0.0) and np.all(ps.lambda_ == np.float32(1.0e7)) and full["model"] == 1
+    for world in (2, 4, 8):
+        seen, counts = [], []
+        for r in range(world):
+            sc = scenes.fluid_block(256, 6, 6, world=world, rank=r)
+            assert np.array_equal(ps.pos[sc["global_ids"]], sc["particles"].pos)
+            seen.append(sc["global_ids"])
+            counts.append(sc["particles"].n)
+        seen = np.concatenate(seen)
+        assert len(seen) == ps.n and len(np.unique(seen)) == ps.n
+        assert max(counts) == min(counts)                                # slabs balanced by particle count

@@ -1,4 +1,4 @@
-# usage: VARS="name:ENV=val,ENV2=val ..." ABLK=regex bash tests/gpu_ablate2.sh   (developer utility)
+# usage: VARS="name:ENV=val,ENV2=val ..." ABLK=regex bash tools/gpu_ablate2.sh   (developer utility)
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 for spec in ${VARS:-base:}; do
   name=${spec%%:*}; envs=${spec#*:}

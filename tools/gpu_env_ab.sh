@@ -1,4 +1,4 @@
-# Developer utility: A/B of environment switches on one box.  usage: ENVS="A=1 B=2|A=0" bash tests/gpu_env_ab.sh
+# Developer utility: A/B of environment switches on one box.  usage: ENVS="A=1 B=2|A=0" bash tools/gpu_env_ab.sh
 cd $GRAFT_REPO_ROOT
 IFS='|' read -ra SETS <<< "${ENVS:-|}"
 for rep in 1 2; do

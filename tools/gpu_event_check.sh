@@ -8,4 +8,4 @@ d = json.loads([l for l in open("gpurun_out/ev/bench.log") if l.startswith("{")]
 print("ms/step", d["ms_per_step"], "frac", d["roofline"]["frac"])
 print({k: round(v * 1e3, 1) for k, v in d["pass_ms_per_step"].items()})
 PY
-python3 tests/show_stats.py gpurun_out/ev | head -12
+python3 tools/show_stats.py gpurun_out/ev | head -12

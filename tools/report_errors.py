@@ -1,7 +1,7 @@
 """Prints the HIP-vs-oracle error table (not a test; used for DESIGN.md numbers).
-Usage on the GPU box: python tests/report_errors.py"""
+Usage on the GPU box: python tools/report_errors.py"""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from helpers import *

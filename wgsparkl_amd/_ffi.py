@@ -26,6 +26,9 @@ EXPORTS = (
     "wgs_shard_step_begin", "wgs_shard_bin_residents", "wgs_shard_register_buffers", "wgs_shard_pack_halos",
     "wgs_shard_add_halos", "wgs_shard_pack_halo", "wgs_shard_add_halo", "wgs_shard_step_end",
     "wgs_shard_pack_migrants", "wgs_shard_add_migrants", "wgs_shard_export",
+    # one call per frame on sharded data (RCCL inside the library) + build identification
+    "wgs_comm_get_unique_id", "wgs_comm_create", "wgs_comm_destroy", "wgs_shard_attach", "wgs_sharded_step",
+    "wgs_sharded_step_lockstep", "wgs_build_info",
 )
 
 
@@ -176,6 +179,14 @@ def load(dim: int):
     lib.wgs_shard_pack_migrants.argtypes = [vp, vp, vp, C.c_uint32]
     lib.wgs_shard_add_migrants.argtypes = [vp, vp, vp, vp, vp, C.c_uint32]
     lib.wgs_shard_export.argtypes = [vp, vp, C.c_uint32, u32p]
+    lib.wgs_build_info.restype = C.c_char_p
+    lib.wgs_comm_get_unique_id.argtypes = [C.c_char_p]
+    lib.wgs_comm_create.argtypes = [vp, C.c_char_p, C.c_int32, C.c_int32, C.c_int32, C.POINTER(vp)]
+    lib.wgs_comm_destroy.argtypes = [vp]
+    lib.wgs_comm_destroy.restype = None
+    lib.wgs_shard_attach.argtypes = [vp, vp, C.c_int32, C.c_int32, C.c_uint32, C.c_uint32]
+    lib.wgs_sharded_step.argtypes = [vp, vp, C.c_uint32]
+    lib.wgs_sharded_step_lockstep.argtypes = [vp, C.POINTER(vp), C.c_uint32, C.c_uint32]
     for name in EXPORTS:
         fn = getattr(lib, name)
         if fn.restype is C.c_int:  # default restype -> wgs_status

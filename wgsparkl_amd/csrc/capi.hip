@@ -36,6 +36,9 @@ constexpr int D = WGS_DIM;
 constexpr int DD = D * D;
 using P = Pl<D>;
 
+#define WGS_STR2(x) #x
+#define WGS_STR(x) WGS_STR2(x)
+
 thread_local std::string g_last_error;
 
 wgs_status fail(wgs_status code, const std::string &msg) {
@@ -65,6 +68,23 @@ struct wgs_pipeline {
     int device = 0;
     int num_cus = 256;
     hipDeviceProp_t props;
+};
+
+// Multi-GPU (capi_sharded.inc): one RCCL communicator of the x-slab chain, and the message buffers of one slab.
+struct wgs_comm {
+    void *comm = nullptr;
+    int rank = 0, world = 1;
+    int lower = -1, upper = -1;   // peer ranks, -1 = none
+    int device = 0;
+};
+struct ShardLink {                // device memory owned by the wgs_data: [count, -, -, -] + capacity records each
+    bool attached = false;
+    wgs_comm *comm = nullptr;     // null: lockstep transport (device-to-device copies inside one process)
+    bool has_lower = false, has_upper = false;
+    uint32_t halo_cap = 0, mig_cap = 0;
+    size_t halo_floats = 0, mig_floats = 0;
+    float *halo_out[2] = {nullptr, nullptr}, *halo_in[2] = {nullptr, nullptr};   // [lower, upper]
+    float *mig_out[2] = {nullptr, nullptr}, *mig_in[2] = {nullptr, nullptr};
 };
 
 struct wgs_data {
@@ -110,6 +130,11 @@ struct wgs_data {
     float timings[WGS_NUM_PASSES] = {0};
     float mark_overhead_ms = 0.f;   // average distance of two adjacent timing marks in the last timestamped step
     bool timings_pending = false;
+    ShardLink *link = nullptr;          // wgs_shard_attach
+    int reduce_impulses = 0;            // sharded two-way coupling: 1 = ncclAllReduce of the body impulses before
+                                        // integrate_bodies, 2 = the caller sums them and integrates (lockstep group)
+    int32_t **lockstep_imp_ptrs = nullptr;
+    uint32_t lockstep_imp_n = 0;
 };
 
 namespace {
@@ -126,11 +151,11 @@ template <typename T> wgs_status dev_alloc(wgs_data *d, T **out, size_t count, b
     return WGS_OK;
 }
 
-// Bodies that move need the impulse accumulation of P2G (rigid_impulses.wgsl reads it every substep). Sharded data
-// cannot provide it (the impulses of all ranks would have to be reduced): kinematic bodies then move without the
-// contact caps, dynamic ones are refused by the caller.
+// Bodies that move need the impulse accumulation of P2G (rigid_impulses.wgsl reads it every substep). On sharded data
+// every rank accumulates the impulses of its own particles and the fixed-point sums are reduced over the ranks before
+// integrate_bodies (wgs_sharded_step: ncclAllReduce of 16 x 8 int32; integers, so the order does not matter).
 wgs_status enable_impulses(wgs_data *d) {
-    if (d->dev.sharded || d->two_way) return WGS_OK;
+    if (d->two_way) return WGS_OK;
     if (!d->dev.imp_slab) {  // per-block partial node impulses
         const size_t count = (size_t)d->dev.cap * Dim<D>::TILE * (D == 3 ? 2 : 1);
         wgs_status st = dev_alloc(d, &d->dev.imp_slab, count);
@@ -157,6 +182,7 @@ void fill_collider(ColliderDev &c, const wgs_collider &in) {
     for (int k = 0; k < 3; k++) c.com[k] = in.com[k];
 }
 
+constexpr uint32_t WGS_LAUNCH_SHAPE_SWITCHES = 128u | 1024u | 4096u | 8192u | 16384u | 32768u;  // WGS_DEBUG bits the shipped library honours
 constexpr uint32_t P2G_SMALL_BUDGET_MIN_PARTICLES = 600000;  // one-way CPIC P2G body at 168 VGPRs from this size on
 constexpr uint32_t P2G_PAIR_MIN_BLOCKS = 8;  // near-collider blocks from which P2G runs both bodies in one launch
 int grid_for(const wgs_data *d, int blocks_per_cu) { return d->pipeline->num_cus * blocks_per_cu; }
@@ -377,6 +403,7 @@ __global__ void k_export_blocks(Dev d, uint32_t nblocks, wgs_block_record *out) 
 }
 
 wgs_status flush_append(wgs_data *d);
+wgs_status allreduce_impulses(wgs_data *d);  // capi_sharded.inc
 
 wgs_status fetch_counters(wgs_data *d) {
     {
@@ -562,7 +589,9 @@ template <bool TS> wgs_status enqueue_substep(wgs_data *d, int ts_slot, int part
             if (part == 0 && d->two_way)
                 hipLaunchKernelGGL((k_grid_update<D, 0, true>), dim3(grid_for(d, 4)), dim3(256), 0, s, dev);
             else if (part == 0) hipLaunchKernelGGL((k_grid_update<D, 0>), dim3(grid_for(d, 4)), dim3(256), 0, s, dev);
+            else if (d->fused_halo && d->two_way) hipLaunchKernelGGL((k_grid_update<D, 3, true>), dim3(grid_for(d, 4)), dim3(256), 0, s, dev);
             else if (d->fused_halo) hipLaunchKernelGGL((k_grid_update<D, 3>), dim3(grid_for(d, 4)), dim3(256), 0, s, dev);
+            else if (d->two_way) return fail(WGS_ERR_UNSUPPORTED, "two-way coupling on sharded data needs the fused halo protocol (wgs_shard_register_buffers / wgs_shard_attach)");
             else hipLaunchKernelGGL((k_grid_update<D, 2>), dim3(grid_for(d, 4)), dim3(256), 0, s, dev);
         }
         mark(5);
@@ -609,8 +638,13 @@ template <bool TS> wgs_status enqueue_substep(wgs_data *d, int ts_slot, int part
         mark(7);
         // ---- "integrate_bodies" (rigid_impulses.wgsl:95-136) + the world mass properties of the next substep
         // (pipeline.rs:204-205). Skipped while no body has a velocity or a mass: it would be the identity.
-        if (d->bodies_move && dev.n_colliders > 0)
+        if (d->bodies_move && dev.n_colliders > 0 && !(part == 2 && d->reduce_impulses == 2)) {
+            if (part == 2 && d->reduce_impulses == 1) {
+                wgs_status rst = allreduce_impulses(d);
+                if (rst != WGS_OK) return rst;
+            }
             hipLaunchKernelGGL(k_bodies_integrate<D>, dim3(1), dim3(16), 0, s, dev);
+        }
         mark(8);
         d->side ^= 1;
         d->substeps++;
@@ -618,7 +652,17 @@ template <bool TS> wgs_status enqueue_substep(wgs_data *d, int ts_slot, int part
         d->tail_known = false;
         d->residents_binned = false;
         dev.n = dev.nv;  // the buffer just written holds the valid particles only, in sorted order
+        // sharded: CTR_N / CTR_NPREV := CTR_NV before anything bins this buffer — done by the next
+        // wgs_shard_pack_migrants, or by k_shard_compacted at the head of the next substep (wgs_step on sharded data)
+        if (dev.sharded) d->needs_compact = true;
     }
+    HIP_TRY(hipGetLastError());
+    return WGS_OK;
+}
+
+// integrate_bodies of a lockstep group (the group summed the impulses of its slabs after every slab's grid update)
+wgs_status enqueue_bodies(wgs_data *d) {
+    if (d->bodies_move && d->dev.n_colliders > 0) hipLaunchKernelGGL(k_bodies_integrate<D>, dim3(1), dim3(16), 0, d->stream, d->dev);
     HIP_TRY(hipGetLastError());
     return WGS_OK;
 }
@@ -629,6 +673,13 @@ extern "C" {
 
 const char *wgs_last_error(void) { return g_last_error.c_str(); }
 int32_t wgs_dim(void) { return D; }
+const char *wgs_build_info(void) {
+    return "wgsparkl_hip dim=" WGS_STR(WGS_DIM) " arch=gfx950"
+#ifdef WGS_ABLATE
+           " WGS_ABLATE"
+#endif
+        ;
+}
 
 wgs_status wgs_pipeline_create(int32_t hip_device, wgs_pipeline **out) {
     if (!out) return fail(WGS_ERR_INVALID_ARGUMENT, "out is NULL");
@@ -638,10 +689,16 @@ wgs_status wgs_pipeline_create(int32_t hip_device, wgs_pipeline **out) {
     if (e != hipSuccess || count <= 0)
         return fail(WGS_ERR_NO_DEVICE, std::string("no HIP device: ") + (e != hipSuccess ? hipGetErrorString(e) : "device count is 0"));
     if (hip_device < 0 || hip_device >= count) return fail(WGS_ERR_INVALID_ARGUMENT, "hip_device out of range");
+    HIP_TRY(hipSetDevice(hip_device));
     wgs_pipeline *p = new wgs_pipeline();
     p->device = hip_device;
-    HIP_TRY(hipSetDevice(hip_device));
-    HIP_TRY(hipGetDeviceProperties(&p->props, hip_device));
+    {
+        const hipError_t pe = hipGetDeviceProperties(&p->props, hip_device);
+        if (pe != hipSuccess) {
+            delete p;
+            return fail(WGS_ERR_HIP, std::string("hipGetDeviceProperties: ") + hipGetErrorString(pe));
+        }
+    }
     p->num_cus = p->props.multiProcessorCount > 0 ? p->props.multiProcessorCount : 256;
     *out = p;
     return WGS_OK;
@@ -695,12 +752,16 @@ static wgs_status create_impl(wgs_pipeline *pipeline, const wgs_sim_params *para
         dev.h_pow2 = (frexpf(cell_width, &e) == 0.5f) ? 1u : 0u;
     }
     dev.model = WGS_MODEL_COROTATED;
-    // Developer switches (read once, here; 0 in production). Ablations change the RESULTS: 64 = G2P moves bytes only,
-    // 256 = P2G without its accumulation loop, 512 = P2G without its particle loads. A/B of launch shapes, same results:
-    // 128 = full k_bin on every substep (no k_rebin), 1024 = node cdf in a launch of its own (k_cdf) instead of
-    // k_setup_scatter<CDF>, 4096 = the two G2P bodies as two launches, 8192 = the two P2G bodies always as two launches, 16384 = never the
+    // Developer switches (read once, here; 0 in production): A/B of launch shapes, SAME results — 128 = full k_bin on
+    // every substep (no k_rebin), 1024 = node cdf in a launch of its own (k_cdf) instead of k_setup_scatter<CDF>,
+    // 4096 = the two G2P bodies as two launches, 8192 = the two P2G bodies always as two launches, 16384 = never the
     // spill-free variant of the plastic G2P pair, 32768 = never the small register budget of the one-way P2G pair.
+    // The ablations that change the RESULTS (64 = G2P moves bytes only, 256 = P2G without its accumulation loop,
+    // 512 = P2G without its particle loads) exist only in builds with -DWGS_ABLATE; the shipped library ignores them.
     dev.dbg = getenv("WGS_DEBUG") ? (uint32_t)strtoul(getenv("WGS_DEBUG"), nullptr, 0) : 0u;
+#ifndef WGS_ABLATE
+    dev.dbg &= WGS_LAUNCH_SHAPE_SWITCHES;
+#endif
     dev.n_colliders = (uint32_t)num_colliders;
     d->cpic = num_colliders > 0;
 
@@ -895,9 +956,7 @@ wgs_status wgs_shard_step_end(wgs_pipeline *pipeline, wgs_data *d) {
     if (!d->dev.sharded) return fail(WGS_ERR_INVALID_ARGUMENT, "not a sharded wgs_data");
     HIP_TRY(hipSetDevice(pipeline->device));
     wgs_status st = enqueue_substep<false>(d, 0, 2);
-    if (st != WGS_OK) return st;
-    d->needs_compact = true;  // CTR_N / CTR_NPREV := CTR_NV: done by the next wgs_shard_pack_migrants (or the fallbacks)
-    return WGS_OK;
+    return st;  // (CTR_N / CTR_NPREV := CTR_NV is pending: needs_compact, see enqueue_substep)
 }
 
 namespace {
@@ -1031,6 +1090,7 @@ void wgs_data_destroy(wgs_data *d) {
             for (int m = 0; m < Events::MARKS; m++) hipEventDestroy(d->events.ev[s][m]);
     for (void *p : d->allocs) hipFree(p);
     if (d->stream && d->owns_stream) hipStreamDestroy(d->stream);
+    delete d->link;
     delete d;
 }
 
@@ -1148,8 +1208,6 @@ wgs_status wgs_set_body_mass_properties(wgs_data *d, const wgs_mass_properties *
         for (int k = 0; k < 3; k++) dynamic = dynamic || b.inv_mass[k] != 0.f;
         for (int k = 0; k < 9; k++) dynamic = dynamic || b.inv_inertia_local[k] != 0.f;
     }
-    if (dynamic && d->dev.sharded)
-        return fail(WGS_ERR_UNSUPPORTED, "dynamic bodies on sharded data: the impulses would need a reduction over ranks");
     d->bodies_move = d->bodies_move || dynamic;
     if (d->bodies_move) {
         wgs_status st = enable_impulses(d);
@@ -1434,3 +1492,5 @@ wgs_status wgs_get_stats(wgs_data *d, wgs_stats *out) {
 }
 
 }  // extern "C"
+
+#include "capi_sharded.inc"

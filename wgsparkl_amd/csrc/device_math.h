@@ -151,6 +151,10 @@ __device__ inline uint32_t activate_block(const Dev &d, uint32_t key, uint32_t e
             if (id < d.cap) {
                 d.block_stamp[id] = epoch;  // every writer stores the same value
                 result = id;
+            } else if (id == NONE) {
+                // the bounded wait expired with the insert still in flight: the caller's particles would vanish from
+                // the sort without a trace. Never seen; reported like every other loss path.
+                atomicOr(&d.counters[CTR_ERRORS], ERRBIT_OVERFLOW);
             }
             done = true;
         }

@@ -211,15 +211,17 @@ template <int D, int PHASE, bool TWOWAY = false> __global__ __launch_bounds__(25
             if (PHASE != 2 && !(PHASE == 3 && from_nodes)) {
                 float4 p = d.slab[(size_t)src * TILE + ti];
                 sum.x += p.x; sum.y += p.y; sum.z += p.z; sum.w += p.w;
-                if constexpr (TWOWAY) {
-                    if (d.block_cpic[src] != 0u) {  // only the CPIC launch of P2G writes impulse partials
-                        constexpr int IMPQ = D == 3 ? 2 : 1;
-                        const float4 a = d.imp_slab[((size_t)src * TILE + ti) * IMPQ];
-                        isum[0] += a.x; isum[1] += a.y; isum[2] += a.z;
-                        if constexpr (D == 3) {
-                            const float4 bq = d.imp_slab[((size_t)src * TILE + ti) * IMPQ + 1];
-                            isum[3] += bq.x; isum[4] += bq.y; isum[5] += bq.z;
-                        }
+            }
+            if constexpr (TWOWAY) {
+                // (sharded runs: also for the interface nodes — the impulses of a rank's OWN particles; the ranks'
+                // fixed-point sums are reduced before integrate_bodies)
+                if (PHASE != 2 && d.block_cpic[src] != 0u) {  // only the CPIC launch of P2G writes impulse partials
+                    constexpr int IMPQ = D == 3 ? 2 : 1;
+                    const float4 a = d.imp_slab[((size_t)src * TILE + ti) * IMPQ];
+                    isum[0] += a.x; isum[1] += a.y; isum[2] += a.z;
+                    if constexpr (D == 3) {
+                        const float4 bq = d.imp_slab[((size_t)src * TILE + ti) * IMPQ + 1];
+                        isum[3] += bq.x; isum[4] += bq.y; isum[5] += bq.z;
                     }
                 }
             }

@@ -13,6 +13,13 @@
 #define WGS_DIM 3
 #endif
 
+// Ablation switches (kernels that skip their maths or loads on request) are compiled in only with -DWGS_ABLATE.
+#ifdef WGS_ABLATE
+#define WGS_ABLATE_AND(cond) &&(cond)
+#else
+#define WGS_ABLATE_AND(cond)
+#endif
+
 namespace wgs {
 
 constexpr uint32_t NONE = 0xffffffffu;
@@ -162,7 +169,8 @@ struct Dev {
     float inv_h;
     uint32_t h_pow2;     // cell width is a power of two: x * inv_h == x / h bit for bit
     int model;           // WGS_MODEL_*
-    uint32_t dbg;        // debug/ablation switches (env WGS_DEBUG), 0 in production
+    uint32_t dbg;        // launch-shape A/B switches (env WGS_DEBUG; same results, see capi.hip), 0 in production. The
+                         // result-changing ablations only exist in builds with -DWGS_ABLATE (never the shipped library)
 };
 
 __device__ inline uint32_t num_slots(const Dev &d) { return d.sharded ? d.counters[CTR_N] : d.n; }

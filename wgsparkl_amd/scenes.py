@@ -177,3 +177,112 @@ def neo_hookean_bar(n_side=100, world=1, rank=None, jitter=0.05, cell_width=1.0)
                 colliders=[Collider.cuboid((100000.0 * h, 2.0 * h, 1000.0 * h), (0.0, 0.0, 0.0))],
                 cell_width=h, grid_capacity=max(1024, 1 << int(np.ceil(np.log2(nb * 1.5)))), model=MODEL_NEO_HOOKEAN,
                 global_particles=nx * n_side * n_side)
+
+
+def _slab_block(counts, origin, h, jitter, world, rank, cuts=None):
+    """Lattice block of counts[0] x counts[1] x counts[2] particles (spacing h/2, hashed jitter by GLOBAL id) cut into
+    `world` x-slabs of (nearly) equal particle count, cuts on block boundaries. With `rank` given only that slab is
+    generated. Returns (pos, global ids, SlabPartition)."""
+    from .sharded import SlabPartition, associated_block_x
+    nx, ny, nz = counts
+    ox = origin[0]
+    if cuts is None:
+        # the block column of lattice plane i is floor((round((ox + (i + .5) h/2) / h) - 1) / 4); cut r sits at the
+        # block boundary closest to the plane that splits the particle count evenly
+        cuts = [int(np.floor((ox / h - 1.0) / 4.0))]
+        for r in range(1, world):
+            cuts.append(int(np.round((ox / h + (nx * r / world) / 2.0 - 1.0) / 4.0)))
+        cuts.append(int(np.floor((ox / h + nx / 2.0) / 4.0)) + 2)
+        for i in range(1, len(cuts)):
+            cuts[i] = max(cuts[i], cuts[i - 1] + 1)
+    part = SlabPartition(cuts)
+    if rank is None:
+        i0, i1 = 0, nx
+    else:
+        # lattice planes that can fall into this rank's block range (+ a margin for the jitter)
+        lo_b, hi_b = part.cuts[rank], part.cuts[rank + 1]
+        i0 = 0 if rank == 0 else max(0, int(np.floor(((lo_b * 4 + 0.5) * h - ox) * 2.0 / h)) - 3)
+        i1 = nx if rank == world - 1 else min(nx, int(np.ceil(((hi_b * 4 + 1.5) * h - ox) * 2.0 / h)) + 3)
+    i, j, k = np.meshgrid(np.arange(i0, i1, dtype=np.int32), np.arange(ny, dtype=np.int32), np.arange(nz, dtype=np.int32), indexing="ij")
+    gid = (i.ravel().astype(np.int64) * ny + j.ravel()) * nz + k.ravel()
+    pos = np.stack([i.ravel(), j.ravel(), k.ravel()], 1).astype(np.float64)
+    del i, j, k
+    pos = (pos + 0.5) * (h / 2.0) + np.asarray(origin, np.float64)
+    if jitter:
+        pos += _hash_jitter(gid, 3, jitter * h)
+    pos = pos.astype(F32)
+    if rank is not None:
+        own = part.owner_of_blocks(associated_block_x(pos, h, 3)) == rank
+        pos, gid = pos[own], gid[own]
+    return pos, gid.astype(np.uint32), part
+
+
+def fluid_block(nx=256, ny=250, nz=250, world=1, rank=None, jitter=0.05, cell_width=1.0, with_floor=True,
+                density=1000.0, bulk_modulus=1.0e7, grid_capacity=None):
+    """C5 (BASELINE.json configs[4]): weakly-compressible "fluid" = pressure-only neo-Hookean
+    (mu = 0 in src/models/neo_hookean_elasticity.wgsl:14-25 => tau = lambda * ln(J) * I; the reference has no fluid
+    model of its own), nx x ny x nz = 16 M particles at 8 per cell inside a 512^3-cell domain, over the floor cuboid.
+    lambda = bulk modulus 1e7 (sound speed 100 cells/s against h/dt = 1200), rho = 1000, dt = 1/1200, phase = 1.
+    `world` / `rank`: the x-slab of one rank of a strong-scaling run (global ids = index in the full lattice, jitter
+    hashed from the id, so every decomposition generates the very same particles)."""
+    h = cell_width
+    # x origin 16.5 h: lattice planes 2i, 2i + 1 sit at (16.75 + i) h and (17.25 + i) h, both inside cell 16 + i, so
+    # 8 planes fill a block column exactly and equal block ranges are equal particle counts
+    origin = (16.5 * h, 8.0 * h, 20.0 * h)
+    pos, gid, part = _slab_block((nx, ny, nz), origin, h, jitter, world, rank)
+    ps = ParticleSet.uniform(pos, h / 4.0, density, ElasticCoefficients(bulk_modulus, 0.0),
+                             phase=ParticlePhase(1.0, FLT_MAX))
+    colliders = [Collider.cuboid((100000.0 * h, 2.0 * h, 100000.0 * h), (0.0, 0.0, 0.0))] if with_floor else []
+    if grid_capacity is None:
+        slab_nx = nx if rank is None else -(-nx // world) + 16
+        nb = (slab_nx // 8 + 4) * (ny // 8 + 4) * (nz // 8 + 4)
+        grid_capacity = max(1024, 1 << int(np.ceil(np.log2(nb * 1.5))))
+    return dict(particles=ps, global_ids=gid, partition=part,
+                params=SimulationParams(gravity=(0.0, -9.81, 0.0), dt=1.0 / 1200.0), colliders=colliders,
+                cell_width=h, grid_capacity=grid_capacity, model=MODEL_NEO_HOOKEAN, global_particles=nx * ny * nz)
+
+
+def config_scene(config="c2", world=1, rank=None, scaling="weak", n_side=None, jitter=0.05):
+    """The BASELINE.json configs as (possibly sharded) scenes for bench.py: `c2` neo-Hookean cube (1 M), `c3`
+    Drucker-Prager sand column standing between the floor and four walls (4 M), `c5` pressure-only neo-Hookean fluid
+    block (16 M). world > 1: "strong" cuts the named size into `world` x-slabs, "weak" puts `world` copies side by
+    side along x (fixed work per GPU). With `rank` given only that rank's slab is generated. Particles are identified
+    by their index in the global lattice and jittered by a hash of it, so every decomposition simulates the same scene."""
+    h = 1.0
+    mult = world if scaling == "weak" else 1
+    if config == "c5":
+        nx, ny, nz = (256, 250, 250) if n_side is None else (n_side, n_side, n_side)
+        sc = fluid_block(nx * mult, ny, nz, world=world, rank=rank, jitter=jitter)
+        sc["name"] = f"wgsparkl3d weakly-compressible fluid (pressure-only neo-Hookean, mu = 0), {nx * mult}x{ny}x{nz} particles, 512^3-cell domain, floor cuboid"
+        sc["bytes_per_particle"] = 160.0
+        return sc
+    if config == "c2":
+        n = 100 if n_side is None else n_side
+        counts, origin = (n * mult, n, n), (20.0 * h, 8.0 * h, 20.0 * h)
+        model, elastic = MODEL_NEO_HOOKEAN, ElasticCoefficients.from_young_modulus(1.0e7, 0.2)
+        plast, phase = None, ParticlePhase(1.0, FLT_MAX)
+        colliders = [Collider.cuboid((100000.0 * h, 2.0 * h, 1000.0 * h), (0.0, 0.0, 0.0))]
+        name = f"wgsparkl3d neo-Hookean elastic cube, {n * mult}x{n}x{n} particles, 128^3-cell domain, floor cuboid"
+        bpp = 160.0
+    elif config == "c3":
+        nx, ny, nz = (100, 400, 100) if n_side is None else (n_side, 4 * n_side, n_side)
+        counts, origin = (nx * mult, ny, nz), (20.0 * h, 2.2 * h, 20.0 * h)      # standing on the floor (top face y = 2)
+        model, elastic = MODEL_COROTATED, ElasticCoefficients.from_young_modulus(2.0e9, 0.2)
+        plast, phase = DruckerPrager.new(2.0e9, 0.2), None
+        x0, x1 = origin[0] - 1.5 * h, origin[0] + counts[0] * h / 2.0 + 1.5 * h
+        z0, z1 = origin[2] - 1.5 * h, origin[2] + nz * h / 2.0 + 1.5 * h
+        t = 2.0 * h
+        colliders = [Collider.cuboid((100000.0, 2.0, 1000.0), (0.0, 0.0, 0.0)),
+                     Collider.cuboid((t, 1000.0, 1000.0), (x0 - t, 0.0, 0.0)), Collider.cuboid((t, 1000.0, 1000.0), (x1 + t, 0.0, 0.0)),
+                     Collider.cuboid((100000.0, 1000.0, t), (0.0, 0.0, z0 - t)), Collider.cuboid((100000.0, 1000.0, t), (0.0, 0.0, z1 + t))]
+        name = f"wgsparkl3d Drucker-Prager sand column, {nx * mult}x{ny}x{nz} particles, 256^3-cell domain, standing between the floor and four walls"
+        bpp = 216.0
+    else:
+        raise ValueError(f"unknown config {config!r}")
+    pos, gid, part = _slab_block(counts, origin, h, jitter, world, rank)
+    ps = ParticleSet.uniform(pos, h / 4.0, 2700.0, elastic, plasticity=plast, phase=phase)
+    slab_nx = counts[0] if rank is None else -(-counts[0] // world) + 16
+    nb = (slab_nx // 8 + 4) * (counts[1] // 8 + 4) * (counts[2] // 8 + 4)
+    return dict(particles=ps, global_ids=gid, partition=part, params=SimulationParams(gravity=(0.0, -9.81, 0.0), dt=1.0 / 1200.0),
+                colliders=colliders, cell_width=h, grid_capacity=max(1024, 1 << int(np.ceil(np.log2(nb * 1.5)))), model=model,
+                global_particles=counts[0] * counts[1] * counts[2], name=name, bytes_per_particle=bpp)

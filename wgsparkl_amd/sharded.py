@@ -558,6 +558,131 @@ class GpuShard:
             pass
 
 
+# ------------------------------------------------------------------------------------------------
+# The substep driven from inside the library (include/wgsparkl_hip.h: wgs_comm_*, wgs_shard_attach,
+# wgs_sharded_step): what bench.py --gpus N and a Rust caller use. The classes above remain as the
+# protocol checker (gloo / CPU backends in tests/) and as the per-phase view of the same entry points.
+# ------------------------------------------------------------------------------------------------
+class NativeComm:
+    """RCCL communicator owned by the library (`wgs_comm_create`). The 128-byte unique id is made by rank 0 and
+    handed around with whatever the host has — here torch.distributed's broadcast."""
+
+    def __init__(self, pipeline: MpmPipeline, dist, rank: int, world: int, flags: int = 0):
+        import torch
+        self.lib, self.rank, self.world = pipeline.lib, rank, world
+        uid = C.create_string_buffer(128)
+        if rank == 0:
+            _ffi.check(self.lib, self.lib.wgs_comm_get_unique_id(uid))
+        if world > 1:
+            t = torch.tensor(list(uid.raw), dtype=torch.uint8)
+            if dist.get_backend() == "nccl":
+                t = t.to(torch.device("cuda", pipeline.device))
+            dist.broadcast(t, 0)
+            uid = C.create_string_buffer(bytes(t.cpu().numpy().tobytes()), 128)
+        h = C.c_void_p()
+        _ffi.check(self.lib, self.lib.wgs_comm_create(pipeline._h, uid, rank, world, int(flags), C.byref(h)))
+        self._h = h
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self.lib.wgs_comm_destroy(self._h)
+            self._h = None
+
+
+class NativeShard:
+    """One slab as a Rust caller would hold it: a sharded `wgs_data` whose message buffers and substep protocol live
+    in the library. `comm` = NativeComm (one process per GPU) or None (a slab of a lockstep group / no neighbours)."""
+
+    def __init__(self, pipeline: MpmPipeline, params: SimulationParams, particles: ParticleSet, global_ids: np.ndarray,
+                 colliders, cell_width: float, grid_capacity: int, block_lo: int, block_hi: int, has_lower: bool,
+                 has_upper: bool, particle_capacity: int, model: int = MODEL_COROTATED, force_plastic: bool = False,
+                 halo_capacity_blocks: int = 4096, migrant_capacity: int = 4096, comm: Optional[NativeComm] = None):
+        self.pipeline, self.lib, self.T = pipeline, pipeline.lib, pipeline.T
+        T, D = self.T, pipeline.dim
+        self.dim = D
+        self.n_colliders = len(colliders)
+        sp = T.SimParams()
+        sp.gravity = (C.c_float * D)(*params.gravity)
+        sp.dt = params.dt
+        raw = _pack_particles(T, particles)
+        gids = np.ascontiguousarray(global_ids, np.uint32)
+        cols = (T.Collider * max(1, len(colliders)))()
+        for i, c in enumerate(colliders):
+            _fill_collider(T, cols[i], c, D)
+        h = C.c_void_p()
+        cap = max(int(particle_capacity), particles.n)
+        _ffi.check(self.lib, self.lib.wgs_data_create_sharded(
+            pipeline._h, C.byref(sp), raw.ctypes.data_as(C.POINTER(T.Particle)), particles.n,
+            gids.ctypes.data_as(C.POINTER(C.c_uint32)), cols, len(colliders), float(cell_width), int(grid_capacity),
+            cap, max(int(block_lo), INT_MIN), min(int(block_hi), INT_MAX), 1 if force_plastic else 0, C.byref(h)))
+        self._h = h
+        self.capacity = cap
+        if model != MODEL_COROTATED:
+            _ffi.check(self.lib, self.lib.wgs_set_constitutive_model(self._h, int(model)))
+        if any(any(c.inv_mass) or any(c.inv_inertia_local) for c in colliders):   # dynamic bodies: two-way coupling
+            arr = (T.MassProperties * len(colliders))()
+            for i, c in enumerate(colliders):
+                arr[i].inv_mass = tuple(c.inv_mass)
+                arr[i].inv_inertia_local = tuple(c.inv_inertia_local)
+            _ffi.check(self.lib, self.lib.wgs_set_body_mass_properties(self._h, arr, len(colliders)))
+        _ffi.check(self.lib, self.lib.wgs_shard_attach(self._h, comm._h if comm is not None else None, 1 if has_lower else 0,
+                                                         1 if has_upper else 0, int(halo_capacity_blocks), int(migrant_capacity)))
+        self.part_rec = self.lib.wgs_shard_particle_record_bytes() // 4
+        self.hdr = self.lib.wgs_shard_buffer_header_bytes() // 4
+
+    def step(self, num_substeps: int):
+        """`wgs_sharded_step`: whole substeps incl. both neighbour exchanges, asynchronous."""
+        _ffi.check(self.lib, self.lib.wgs_sharded_step(self.pipeline._h, self._h, int(num_substeps)))
+
+    def sync(self):
+        _ffi.check(self.lib, self.lib.wgs_sync(self._h))
+
+    def stats(self):
+        s = self.T.Stats()
+        _ffi.check(self.lib, self.lib.wgs_get_stats(self._h, C.byref(s)))
+        return {k: int(getattr(s, k)) for k, _ in s._fields_}
+
+    def num_particles(self) -> int:
+        return self.stats()["num_particles"]
+
+    def read_body_poses(self):
+        """Like MpmData.read_body_poses: every rank integrates the same bodies, any rank can be asked."""
+        n, D = self.n_colliders, self.dim
+        poses, vels = (self.T.Pose * max(1, n))(), (self.T.Velocity * max(1, n))()
+        coms = (C.c_float * (3 * max(1, n)))()
+        _ffi.check(self.lib, self.lib.wgs_read_body_poses(self._h, poses, vels, coms, n))
+        return [dict(rotation=np.array(list(poses[i].rotation)[:(2 if D == 2 else 4)], np.float64),
+                     translation=np.array(list(poses[i].translation)[:D], np.float64),
+                     linvel=np.array(list(vels[i].linear)[:D], np.float64),
+                     angvel=np.array(list(vels[i].angular)[:(1 if D == 2 else 3)], np.float64)) for i in range(n)]
+
+    def export(self):
+        """(global ids, pos, vel, def_grad, affine, mass) of the particles this rank owns now (blocking)."""
+        import torch
+        buf = torch.zeros(self.hdr + self.capacity * self.part_rec, dtype=torch.float32, device=torch.device("cuda", self.pipeline.device))
+        cnt = C.c_uint32(0)
+        _ffi.check(self.lib, self.lib.wgs_shard_export(self._h, C.c_void_p(buf.data_ptr()), self.capacity, C.byref(cnt)))
+        rec = buf[self.hdr: self.hdr + cnt.value * self.part_rec].cpu().numpy().reshape(cnt.value, self.part_rec)
+        return unpack_records(rec, self.dim)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self.lib.wgs_data_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def native_lockstep(pipeline: MpmPipeline, shards: List[NativeShard], num_substeps: int):
+    """`wgs_sharded_step_lockstep`: all slabs of one process on one device, in x order."""
+    arr = (C.c_void_p * len(shards))(*[s._h for s in shards])
+    _ffi.check(pipeline.lib, pipeline.lib.wgs_sharded_step_lockstep(pipeline._h, arr, len(shards), int(num_substeps)))
+
+
 def unpack_records(rec: np.ndarray, dim: int):
     """Particle records (quad layout of csrc/layout.h) -> dict of arrays."""
     ids = rec[:, -2].copy().view(np.uint32)     # [..quads.., pid, cdf epoch]
