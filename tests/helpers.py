@@ -111,3 +111,42 @@ def assert_close_to_truth(name, got, ref32, truth, rel_tol, k32=10.0):
     assert np.isfinite(e_gpu) and e_gpu <= bound, (
         f"{name}: rms err {e_gpu:.3e} > bound {bound:.3e} (scale {scale:.3e}, fp32-oracle err {e_32:.3e})")
     return e_gpu / scale if scale > 0 else e_gpu
+
+
+def compare_cpic(data, st32, st64, dim, grid_tol, part_tol, min_same=0.995, fields=("pos", "vel", "def_grad", "affine"), h=1.0,
+                 truth=None):
+    """Parity of a collider (CPIC) scene. `truth` = (dict of fp64 particle arrays, fp64 grid velocity|mass array) may
+    replace the fp64 oracle state (golden vectors). Integer results first — active cells, node affinity / sign bits, closest
+    collider ids: exact. CPIC has discrete per-particle decisions sitting on fp32 thresholds (sign votes, det M > 1e-8),
+    so a few particles may carry other affinity bits than the oracle's; they, and the grid nodes inside their 3^D
+    stencil (a node inside a collider can hold 1e-6 of a particle's mass: one such particle moves its velocity by
+    O(1)), are left out of the floating-point comparison, and their NUMBER is reported and bounded. Everything else is
+    compared against the fp64 oracle with `grid_tol` / `part_tol` (relative RMS)."""
+    cells, vm, dist, aff, closest = data.read_grid()
+    oc, omv, odist, oaff, oclosest = st32.grid_records()
+    assert np.array_equal(cells, oc), "active node cells differ"
+    assert np.array_equal(aff, oaff), "node affinity / sign bits differ"
+    assert np.array_equal(closest, oclosest), "closest collider ids differ"
+    got = data.read_particles()
+    same = got.cdf_affinity == st32.arr["cdf_affinity"]
+    report_margin("particle affinity mismatch fraction", 1.0 - float(same.mean()), 1.0 - min_same, count=int((~same).sum()))
+    assert same.mean() >= min_same, f"affinity bits agree for only {same.mean():.5f} of the particles"
+    keep = np.ones(len(cells), bool)
+    if not same.all():
+        h = np.float32(h)
+        bad = []
+        for pos in (st32.arr["pos"][~same], got.pos[~same]):          # stencils at either position (they agree to 1e-6)
+            base = (np.rint(pos.astype(np.float32) / h) - 1).astype(np.int64)
+            for off in np.ndindex(*([3] * dim)):
+                bad.append(base + np.array(off))
+        bad = np.unique(np.concatenate(bad), axis=0)
+        key = lambda c: (c[:, 0] * 4099 + c[:, 1]) * 4099 + (c[:, 2] if dim == 3 else 0)
+        keep = ~np.isin(key(cells.astype(np.int64)), key(bad))
+        report_margin("grid nodes left out (stencils of mismatching particles)", float((~keep).mean()), 0.02, count=int((~keep).sum()))
+        assert (~keep).mean() < 0.02
+    t_arr, o64 = truth if truth is not None else (st64.arr, grid_of(st64)[1])
+    assert_close_to_truth("grid velocity (CPIC)", vm[keep][:, :dim], omv[keep][:, :dim], o64[keep][:, :dim], grid_tol)
+    assert_close_to_truth("grid mass (CPIC)", vm[keep][:, dim], omv[keep][:, dim], o64[keep][:, dim], grid_tol)
+    for f in fields:
+        assert_close_to_truth(f + " (CPIC)", getattr(got, f)[same], st32.arr[f][same], t_arr[f][same], part_tol)
+    return got, same

@@ -10,7 +10,7 @@ from wgsparkl_amd.models import (MODEL_COROTATED, MODEL_NEO_HOOKEAN, DruckerPrag
                                  ParticlePhase)
 from wgsparkl_amd.solver import Collider, ParticleSet, SimulationParams
 
-from helpers import assert_close_to_truth, compare_grids, grid_of, max_abs, rel_rms, report_margin, run_gpu, run_oracle
+from helpers import assert_close_to_truth, compare_cpic, compare_grids, grid_of, max_abs, rel_rms, report_margin, run_gpu, run_oracle
 
 pytestmark = pytest.mark.gpu
 
@@ -118,18 +118,8 @@ def test_c5_fluid_block_small(hip_libs, oracle_libs, with_floor):
         check_grid(data, st32, st64)
         check_fields(data, st32, st64)
     else:
-        cells, vm, dist, aff, closest = data.read_grid()
-        oc, omv, odist, oaff, oclosest = st32.grid_records()
-        assert np.array_equal(cells, oc) and np.array_equal(aff, oaff) and np.array_equal(closest, oclosest)
-        got = data.read_particles()
-        same = got.cdf_affinity == st32.arr["cdf_affinity"]
-        report_margin("particle affinity mismatch fraction", 1.0 - same.mean(), 0.002)
-        assert same.mean() > 0.998
+        got, same = compare_cpic(data, st32, st64, 3, CPIC_GRID_V_TOL, CPIC_PART_TOL, min_same=0.998)
         assert (got.cdf_affinity & 1).sum() > 500                        # the floor is felt
-        o64 = grid_of(st64)[1]
-        assert_close_to_truth("grid velocity (CPIC)", vm[:, :3], omv[:, :3], o64[:, :3], CPIC_GRID_V_TOL)
-        for f in ("pos", "vel", "def_grad", "affine"):
-            assert_close_to_truth(f + " (CPIC)", getattr(got, f)[same], st32.arr[f][same], st64.arr[f][same], CPIC_PART_TOL)
 
 
 def test_drucker_prager_sand(hip_libs, oracle_libs):
@@ -949,24 +939,21 @@ def test_against_committed_golden_vectors(hip_libs, oracle_libs, name):
     dim = sc["particles"].dim
     data = run_gpu(sc, k)
     st32 = run_oracle(sc, k, np.float32)
-    got = data.read_particles()
     cpic = len(sc["colliders"]) > 0
-    # CPIC has discrete decisions (affinity / sign bits, det > 1e-8): allow a handful of particles
-    # to sit on the other side of a threshold in fp32, and compare the rest.
-    ok = np.ones(got.n, bool)
     if cpic:
-        same = got.cdf_affinity == _GOLD[f"{name}/cdf_affinity"]
-        assert same.mean() > 0.995, f"affinity bits agree for only {same.mean():.4f} of the particles"
-        ok = same
-    tol = 5e-4 if cpic else PART_TOL
-    for f in ("pos", "vel", "def_grad", "affine"):
-        assert_close_to_truth(f, getattr(got, f)[ok], st32.arr[f][ok], _GOLD[f"{name}/{f}"][ok], tol)
-    cells, vm, _, aff, _ = data.read_grid()
-    assert np.array_equal(cells, _GOLD[f"{name}/grid_cells"])            # active nodes: bit-exact
-    assert np.array_equal(aff, _GOLD[f"{name}/grid_aff"])                # node affinity / sign bits: bit-exact
-    o32 = grid_of(st32)[1]
-    assert_close_to_truth("grid velocity", vm[:, :dim], o32[:, :dim], _GOLD[f"{name}/grid_vm"][:, :dim],
-                          5e-4 if cpic else GRID_V_TOL)
+        truth = ({f: _GOLD[f"{name}/{f}"] for f in ("pos", "vel", "def_grad", "affine")}, _GOLD[f"{name}/grid_vm"])
+        assert np.array_equal(st32.grid_records()[0], _GOLD[f"{name}/grid_cells"])
+        assert np.array_equal(st32.grid_records()[3], _GOLD[f"{name}/grid_aff"])          # node affinity / sign bits: bit-exact
+        compare_cpic(data, st32, None, dim, CPIC_GRID_V_TOL, CPIC_PART_TOL, min_same=0.995, h=sc["cell_width"], truth=truth)
+    else:
+        got = data.read_particles()
+        for f in ("pos", "vel", "def_grad", "affine"):
+            assert_close_to_truth(f, getattr(got, f), st32.arr[f], _GOLD[f"{name}/{f}"], PART_TOL)
+        cells, vm, _, aff, _ = data.read_grid()
+        assert np.array_equal(cells, _GOLD[f"{name}/grid_cells"])            # active nodes: bit-exact
+        assert np.array_equal(aff, _GOLD[f"{name}/grid_aff"])
+        o32 = grid_of(st32)[1]
+        assert_close_to_truth("grid velocity", vm[:, :dim], o32[:, :dim], _GOLD[f"{name}/grid_vm"][:, :dim], GRID_V_TOL)
     if cpic:
         # rigid bodies, integrated on the device every substep (rigid_impulses.wgsl:95-136); the dynamic ones
         # are pushed by the particles (two-way coupling, p2g.wgsl:200-228). Absolute tolerance: positions are
