@@ -94,12 +94,15 @@ def report_margin(name, value, bound, **extra):
             f.write(json.dumps(rec) + "\n")
 
 
-def assert_close_to_truth(name, got, ref32, truth, rel_tol, k32=10.0):
+def assert_close_to_truth(name, got, ref32, truth, rel_tol, k32=None):
     """fp32 tolerance rule used by every floating-point parity check:
-    the HIP result must be within `rel_tol` (relative RMS) of the fp64 oracle, OR — on
-    inputs where fp32 itself is ill-conditioned (e.g. stress of a rigid free fall, where
-    tau is round-off times E) — within `k32` times the error the fp32 restatement of the
-    reference's own arithmetic makes against the same fp64 truth."""
+    the HIP result must be within `rel_tol` (relative RMS) of the fp64 oracle. One field has an escape: `affine`
+    (C' = APIC matrix minus the stress term) is round-off times E wherever the body moves rigidly — its fp64 value is
+    ~0 and a relative bound means nothing —, so there the HIP result may instead be within `k32` = 4 times the error
+    the fp32 restatement of the reference's own arithmetic makes against the same fp64 truth (measured: 1.0-2.6 x,
+    profiles/r02_parity_margins.json). No other field needs it, and none gets it."""
+    if k32 is None:
+        k32 = 4.0 if name.startswith("affine") else 0.0
     got = np.asarray(got, np.float64)
     truth = np.asarray(truth, np.float64)
     e_gpu = rms(got - truth)

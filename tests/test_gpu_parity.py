@@ -21,6 +21,11 @@ PART_TOL = 2e-5        # relative RMS of particle x, v, F, C' vs the fp64 oracle
 # affinity bits agree, and the measured margins are reported (helpers.report_margin -> profiles/rNN_parity_margins.json)
 CPIC_GRID_V_TOL = 5e-5
 CPIC_PART_TOL = 5e-5
+# fuzz scenes (random colliders of every kind, some dynamic, 12 substeps, against the fp32 oracle)
+FUZZ_NODE_MISMATCH = 0.005
+FUZZ_PART_MISMATCH = 0.01
+FUZZ_VEL_TOL = 2e-3
+FUZZ_BODY_ATOL = 2e-3
 
 
 def cloud_scene(n=20000, dim=3, model=MODEL_COROTATED, seed=7, **kw):
@@ -319,19 +324,26 @@ def test_random_scenes_match_oracle(hip_libs, oracle_libs, seed, chunk):
     cells, vm, dist, aff, closest = data.read_grid()
     oc, omv, odist, oaff, oclosest = st.grid_records()
     assert np.array_equal(cells, oc)
-    assert (aff != oaff).mean() < 0.005 and (closest != oclosest).mean() < 0.005
+    report_margin("fuzz node affinity mismatch fraction", float((aff != oaff).mean()), FUZZ_NODE_MISMATCH)
+    report_margin("fuzz node closest-id mismatch fraction", float((closest != oclosest).mean()), FUZZ_NODE_MISMATCH)
+    assert (aff != oaff).mean() <= FUZZ_NODE_MISMATCH and (closest != oclosest).mean() <= FUZZ_NODE_MISMATCH
     got = data.read_particles()
     same = got.cdf_affinity == st.arr["cdf_affinity"]
-    assert same.mean() > 0.99
-    for f, tol in (("pos", 2e-5), ("vel", 2e-3)):
+    report_margin("fuzz particle affinity mismatch fraction", 1.0 - float(same.mean()), FUZZ_PART_MISMATCH)
+    assert 1.0 - same.mean() <= FUZZ_PART_MISMATCH
+    for f, tol in (("pos", 2e-5), ("vel", FUZZ_VEL_TOL)):
         err = rel_rms(getattr(got, f)[same], st64.arr[f][same])
         err32 = rel_rms(st.arr[f][same], st64.arr[f][same])
-        assert err < max(tol, 10.0 * err32), (f, err, err32)
+        report_margin(f"fuzz {f} rel rms vs fp64", err, tol, fp32_oracle_err=err32)
+        assert err < tol, (f, err, err32)
     if sc["colliders"]:
         st.update_world_mass_properties()
+        worst = 0.0
         for gb, ob in zip(data.read_body_poses(), st.collider_states()):
             for key in ("rotation", "translation", "linvel", "angvel"):
-                assert np.allclose(gb[key], ob[key], rtol=0.0, atol=2e-3), (key, gb[key], ob[key])
+                worst = max(worst, float(np.abs(np.asarray(gb[key]) - np.asarray(ob[key])).max()))
+        report_margin("fuzz body state abs err", worst, FUZZ_BODY_ATOL)
+        assert worst <= FUZZ_BODY_ATOL
 
 
 @pytest.mark.parametrize("seed", range(6))
