@@ -271,6 +271,11 @@ wgs_status wgs_read_timings(wgs_data *data, float ms[WGS_NUM_PASSES]);
  * with K launches between its marks took (time - overhead) of kernel time. */
 wgs_status wgs_read_timing_overhead(wgs_data *data, float *ms_per_mark);
 wgs_status wgs_get_stats(wgs_data *data, wgs_stats *out);
+/* TEST HOOK (not part of the drop-in surface): runs the device-side exclusive scan that replaces WgPrefixSum
+ * (src/grid/prefix_sum.rs:17-152, prefix_sum.wgsl:11-93) on caller data, so that the reference's own scan test
+ * vectors (src/grid/prefix_sum.rs:183-229) can be put through the HIP code: out[i] = sum of values[0..i), *total
+ * (may be NULL) = sum of all. Blocking. */
+wgs_status wgs_debug_scan(wgs_pipeline *pipeline, const uint32_t *values, uint32_t n, uint32_t *out, uint32_t *total);
 
 /* ---------------------------------------------------------------------------------------------
  * Multi-GPU (x-slab domain decomposition). NEW DESIGN: the reference is single-GPU (one wgpu::Device,

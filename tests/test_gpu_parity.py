@@ -162,6 +162,44 @@ def test_empty_and_single(hip_libs, oracle_libs):
     assert d0.read_positions().shape == (0, 3)
 
 
+@pytest.mark.parametrize("dim", [3, 2])
+def test_reference_prefix_sum_vectors_through_the_hip_scan(hip_libs, oracle_libs, dim):
+    """The ONLY numeric answers the reference's own tests hold for this path — gpu_prefix_sum,
+    src/grid/prefix_sum.rs:183-229: all-ones, iota and random % 10_000 at LEN = 15071 — put through the device scan
+    that replaces WgPrefixSum (kernels_sort.h scan_chunk, via the wgs_debug_scan hook): out[i] = i, out[i] = i(i-1)/2,
+    and equality with eval_cpu (restated in the oracle). Plus the edge lengths around the chunk and wave sizes."""
+    import ctypes as C
+    from helpers import pipeline
+    from wgsparkl_amd import _ffi
+    pipe = pipeline(dim)
+    orc = oracle_libs.Oracle(3, np.float32)
+
+    def hip_scan(v):
+        v = np.ascontiguousarray(v, np.uint32)
+        out = np.zeros(len(v), np.uint32)
+        tot = C.c_uint32(0)
+        u32p = C.POINTER(C.c_uint32)
+        _ffi.check(pipe.lib, pipe.lib.wgs_debug_scan(pipe._h, v.ctypes.data_as(u32p), len(v), out.ctypes.data_as(u32p), C.byref(tot)))
+        return out, tot.value
+
+    n = 15071
+    ones, iota = np.ones(n, np.uint32), np.arange(n, dtype=np.uint32)
+    rnd = (np.random.default_rng(0).integers(0, 2**32, n, dtype=np.uint64) % 10_000).astype(np.uint32)
+    out, tot = hip_scan(ones)
+    assert np.array_equal(out, np.arange(n, dtype=np.uint32)) and tot == n
+    out, tot = hip_scan(iota)
+    i = np.arange(n, dtype=np.uint64)
+    assert np.array_equal(out, ((i * (i - 1)) // 2).astype(np.uint32))
+    for v in (ones, iota, rnd):
+        out, tot = hip_scan(v)
+        assert np.array_equal(out, orc.prefix_sum_eval_cpu(v)) and tot == int(v.astype(np.uint64).sum() & 0xffffffff)
+    for m in (0, 1, 2, 63, 64, 65, 255, 256, 257, 4095, 4096, 4097, 8192, 65536, 65537, 300001):
+        v = ((np.arange(m, dtype=np.uint64) * 7 + 3) % 11).astype(np.uint32)
+        out, tot = hip_scan(v)
+        assert np.array_equal(out, orc.prefix_sum_eval_cpu(v)) if m else len(out) == 0
+        assert tot == int(v.sum())
+
+
 def test_determinism(hip_libs):
     sc = cloud_scene(n=30000, seed=11)
     a = run_gpu(sc, 5).read_particles()

@@ -95,7 +95,6 @@ struct wgs_data {
     int side = 0;
     bool plastic = false;
     bool cpic = false;
-    bool deterministic = true;
     bool prev_sorted = false;   // the current buffer is the sorted output of the previous substep (perm_cell, links valid)
     bool tail_known = false;    // sharded: wgs_shard_add_migrants ran since the last substep (CTR_NPREV is current)
     uint32_t tail_slots = 0;    // sharded: upper bound of the arrivals appended behind the residents
@@ -483,7 +482,8 @@ template <bool TS> wgs_status enqueue_substep(wgs_data *d, int ts_slot, int part
     // on the first substep, on table-rebuild substeps and in sharded runs (particles arrive from neighbours).
     const bool rehash = d->substeps % REHASH_PERIOD == 0;
     const bool fused_cdf = d->cpic && dev.n_rigid == 0 && !(dev.dbg & 1024u);  // (mesh cdfs are only complete after k_p2g_cdf)
-    const bool use_rebin = d->prev_sorted && !rehash && !(dev.dbg & 128u) && (!dev.sharded || d->tail_known || part == 3);
+    // (sharded data stepped with wgs_step: nobody arrived since the last substep, the residents are all there is)
+    const bool use_rebin = d->prev_sorted && !rehash && !(dev.dbg & 128u) && (!dev.sharded || d->tail_known || part == 3 || part == 0);
     if (dev.sharded && d->needs_compact && part != 2) {
         hipLaunchKernelGGL(k_shard_compacted, dim3(1), dim3(64), 0, s, dev);
         d->needs_compact = false;
@@ -517,7 +517,7 @@ template <bool TS> wgs_status enqueue_substep(wgs_data *d, int ts_slot, int part
         if (n > 0) {
             if (use_rebin) {
                 if (!d->residents_binned) hipLaunchKernelGGL(k_rebin<D>, dim3(pgrid), dim3(SORT_THREADS), 0, s, dev, side, epoch);
-                if (dev.sharded && d->tail_slots > 0) {  // the particles that arrived from the neighbours: append + bin
+                if (dev.sharded && d->tail_known && d->tail_slots > 0) {  // the particles that arrived from the neighbours: append + bin
                     const dim3 tg((d->tail_slots + SORT_THREADS - 1) / SORT_THREADS);
                     if (d->append_pending) hipLaunchKernelGGL((k_bin<D, 2>), tg, dim3(SORT_THREADS), 0, s, dev, side, epoch, d->mig);
                     else hipLaunchKernelGGL((k_bin<D, 1>), tg, dim3(SORT_THREADS), 0, s, dev, side, epoch, MigIn{});
@@ -532,17 +532,16 @@ template <bool TS> wgs_status enqueue_substep(wgs_data *d, int ts_slot, int part
                 hipLaunchKernelGGL(k_rigid_mark<D>, dim3(grid_for(d, 1)), dim3(256), 0, s, dev, epoch);
                 hipLaunchKernelGGL(k_rigid_touch<D>, dim3(grid_for(d, 1)), dim3(256), 0, s, dev, epoch);
             }
-            hipLaunchKernelGGL(k_scan_active, dim3(1), dim3(SCAN_THREADS), 0, s, dev, epoch);
-            // collider simulations without mesh colliders: node cdf + block classes ride in this launch, the particle
+            // launch 2: chunked scan (active list, first_particle) + per-block setup and regrouping in canonical order.
+            // Collider simulations without mesh colliders: node cdf + block classes ride in this launch, the particle
             // cdf in the CPIC P2G launch (no CDF launch at all)
             {
-                const uint32_t nsetup = (uint32_t)grid_for(d, 4);  // (more setup workgroups for more blocks was measured: slower)
-                const dim3 g(nsetup + (uint32_t)pgrid);
-                if (fused_cdf) hipLaunchKernelGGL((k_setup_scatter<D, true>), g, dim3(SORT_THREADS), 0, s, dev, side, epoch, nsetup);
-                else hipLaunchKernelGGL((k_setup_scatter<D, false>), g, dim3(SORT_THREADS), 0, s, dev, side, epoch, nsetup);
+                const uint32_t nscan = (dev.cap + SCAN_CHUNK - 1) / SCAN_CHUNK;
+                const uint32_t nreg = std::min((dev.cap + 3u) / 4u, (uint32_t)grid_for(d, 5));
+                const dim3 g(nscan + nreg);
+                if (fused_cdf) hipLaunchKernelGGL((k_regroup<D, true>), g, dim3(SORT_THREADS), 0, s, dev, side, epoch, nscan, use_rebin ? 1 : 0);
+                else hipLaunchKernelGGL((k_regroup<D, false>), g, dim3(SORT_THREADS), 0, s, dev, side, epoch, nscan, use_rebin ? 1 : 0);
             }
-            if (d->deterministic)
-                hipLaunchKernelGGL(k_canonical_order, dim3(grid_for(d, 4)), dim3(SORT_THREADS), 0, s, dev);
         } else {
             HIP_TRY(hipMemsetAsync(dev.counters + CTR_NBLOCKS, 0, sizeof(uint32_t), s));
         }
@@ -650,6 +649,7 @@ template <bool TS> wgs_status enqueue_substep(wgs_data *d, int ts_slot, int part
         d->substeps++;
         d->prev_sorted = true;
         d->tail_known = false;
+        d->tail_slots = 0;
         d->residents_binned = false;
         dev.n = dev.nv;  // the buffer just written holds the valid particles only, in sorted order
         // sharded: CTR_N / CTR_NPREV := CTR_NV before anything bins this buffer — done by the next
@@ -774,10 +774,9 @@ static wgs_status create_impl(wgs_pipeline *pipeline, const wgs_sim_params *para
     TRY_ALLOC(&dev.buf[0], plane_floats);
     TRY_ALLOC(&dev.buf[1], plane_floats);
     TRY_ALLOC(&dev.perm, (size_t)dev.npad);
-    TRY_ALLOC(&dev.perm_pid, (size_t)dev.npad);
     TRY_ALLOC(&dev.perm_cell, (size_t)dev.npad);
     TRY_ALLOC(&dev.cellid, (size_t)dev.npad);
-    TRY_ALLOC(&dev.rank, (size_t)dev.npad);
+    TRY_ALLOC(&dev.mv_next, (size_t)dev.npad);
     TRY_ALLOC(&dev.hkeys, (size_t)hcap);
     TRY_ALLOC(&dev.hvals, (size_t)hcap);
     TRY_ALLOC(&dev.block_key, (size_t)dev.cap);
@@ -789,7 +788,10 @@ static wgs_status create_impl(wgs_pipeline *pipeline, const wgs_sim_params *para
     TRY_ALLOC(&dev.block_start, (size_t)dev.cap);
     TRY_ALLOC(&dev.nbr_plus, (size_t)dev.cap * 8);
     TRY_ALLOC(&dev.nbr_minus, (size_t)dev.cap * 8);
-    TRY_ALLOC(&dev.cell_count, (size_t)dev.cap * NPB);
+    TRY_ALLOC(&dev.cell_head, (size_t)dev.cap * NPB);
+    TRY_ALLOC(&dev.chunk_total, (size_t)(dev.cap + SCAN_CHUNK - 1) / SCAN_CHUNK);
+    TRY_ALLOC(&dev.chunk_flag, (size_t)(dev.cap + SCAN_CHUNK - 1) / SCAN_CHUNK);
+    TRY_ALLOC(&dev.chunk_done, (size_t)(dev.cap + SCAN_CHUNK - 1) / SCAN_CHUNK);
     TRY_ALLOC(&dev.cell_start, (size_t)dev.cap * NPB);
     TRY_ALLOC(&dev.cell_cursor, (size_t)dev.cap * NPB);
     TRY_ALLOC(&dev.nodes, (size_t)dev.cap * NPB);
@@ -1453,6 +1455,60 @@ wgs_status wgs_read_blocks(wgs_data *d, wgs_block_record *out, size_t capacity, 
         HIP_TRY(hipMemcpyAsync(sorted_ids, pidp, sizeof(uint32_t) * (size_t)d->dev.n, hipMemcpyDeviceToHost, d->stream));
         HIP_TRY(hipStreamSynchronize(d->stream));
     }
+    return WGS_OK;
+}
+
+// Test hook: the exclusive scan of launch 2 (kernels_sort.h scan_chunk: what replaces prefix_sum.wgsl) on caller
+// data — values[i] plays the particle count of block i, every block active. The reference's own scan test vectors
+// (src/grid/prefix_sum.rs:183-229) go through the HIP scan this way.
+wgs_status wgs_debug_scan(wgs_pipeline *pipeline, const uint32_t *values, uint32_t n, uint32_t *out, uint32_t *total) {
+    if (!pipeline || (!values && n) || (!out && n)) return fail(WGS_ERR_INVALID_ARGUMENT, "NULL argument");
+    if (n > (1u << 25)) return fail(WGS_ERR_INVALID_ARGUMENT, "n out of range");
+    HIP_TRY(hipSetDevice(pipeline->device));
+    Dev dev{};
+    dev.cap = std::max(1u, n);
+    const uint32_t nscan = (dev.cap + SCAN_CHUNK - 1) / SCAN_CHUNK, epoch = 1u;
+    std::vector<void *> tmp;
+    auto alloc = [&](size_t bytes, int fill) -> void * {
+        void *p = nullptr;
+        if (hipMalloc(&p, bytes ? bytes : 4) != hipSuccess) return nullptr;
+        hipMemset(p, fill, bytes ? bytes : 4);
+        tmp.push_back(p);
+        return p;
+    };
+    auto cleanup = [&]() { for (void *p : tmp) hipFree(p); };
+    dev.counters = (uint32_t *)alloc(sizeof(uint32_t) * CTR_COUNT, 0);
+    dev.block_stamp = (uint32_t *)alloc(sizeof(uint32_t) * dev.cap, 0);
+    dev.block_acc = (uint32_t *)alloc(sizeof(uint32_t) * dev.cap, 0);
+    dev.active = (uint32_t *)alloc(sizeof(uint32_t) * dev.cap, 0);
+    dev.block_start = (uint32_t *)alloc(sizeof(uint32_t) * dev.cap, 0);
+    dev.chunk_total = (unsigned long long *)alloc(sizeof(unsigned long long) * nscan, 0);
+    dev.chunk_flag = (uint32_t *)alloc(sizeof(uint32_t) * nscan, 0);
+    dev.chunk_done = (uint32_t *)alloc(sizeof(uint32_t) * nscan, 0);
+    if (!dev.counters || !dev.block_stamp || !dev.block_acc || !dev.active || !dev.block_start || !dev.chunk_total || !dev.chunk_flag || !dev.chunk_done) {
+        cleanup();
+        return fail(WGS_ERR_HIP, "out of device memory");
+    }
+    std::vector<uint32_t> ones(dev.cap, epoch);
+    uint32_t ctr[CTR_COUNT] = {0};
+    ctr[CTR_NPHYS] = n;
+    hipError_t e = hipMemcpy(dev.counters, ctr, sizeof(ctr), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(dev.block_stamp, ones.data(), sizeof(uint32_t) * dev.cap, hipMemcpyHostToDevice);
+    if (e == hipSuccess && n) e = hipMemcpy(dev.block_acc, values, sizeof(uint32_t) * n, hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(k_scan_only, dim3(nscan), dim3(SORT_THREADS), 0, 0, dev, epoch, nscan);
+        e = hipDeviceSynchronize();
+    }
+    if (e == hipSuccess && n) e = hipMemcpy(out, dev.block_start, sizeof(uint32_t) * n, hipMemcpyDeviceToHost);
+    if (e == hipSuccess && total) {
+        unsigned long long t = 0;  // sum of the chunk totals (low words)
+        std::vector<unsigned long long> ct(nscan);
+        e = hipMemcpy(ct.data(), dev.chunk_total, sizeof(unsigned long long) * nscan, hipMemcpyDeviceToHost);
+        for (auto v : ct) t += v & 0xffffffffull;
+        *total = (uint32_t)t;
+    }
+    cleanup();
+    if (e != hipSuccess) return fail(WGS_ERR_HIP, hipGetErrorString(e));
     return WGS_OK;
 }
 

@@ -1,5 +1,5 @@
-// kernels_sort.h — "grid sort" pass: sparse-grid activation and the counting
-// sort of particles by (block, cell, particle id).
+// kernels_sort.h — "grid sort" pass: sparse-grid activation and the regrouping of the particles by
+// (block, cell, particle id). TWO launches per substep.
 //
 // Replaces the reference's 14 dispatches of WgGrid::queue_sort
 // (grid/grid.rs:30-207; kernels grid.wgsl:186-203,355-379, sort.wgsl:26-36,89-137,
@@ -10,13 +10,21 @@
 //     says which blocks are active now. Touching an already-known block is a plain
 //     L2-served lookup plus an idempotent store; device-scope atomics (memory-side on
 //     MI355X) are only issued for blocks never seen before;
-//   * one pass over the particles does both the activation and the counting
-//     (reference: touch_particle_blocks + update_block_particle_count + finalize);
-//   * counting uses LDS histograms per (wave, block) and one coalesced returning atomic
-//     per (wave, block) instead of one global atomic per particle;
-//   * no per-node linked lists: cells become contiguous ranges of `perm`, and the order
-//     inside a cell is canonical (ascending persistent particle id), so every downstream
-//     fp32 sum is reproducible run to run (reference: atomic race order, sort.wgsl:126,133).
+//   * launch 1 (k_rebin / k_bin), one thread per particle: new cell, block activation, per-block
+//     particle totals (one atomic per (wave, block)). The buffer is the sorted output of the
+//     previous substep and particles move less than a cell per substep, so almost every particle
+//     is a STAYER — same cell as before, nothing else to do for it. The few MOVERS are pushed on
+//     a per-destination-cell list (one atomic exchange each; the reference pushes EVERY particle
+//     on such a list every substep, sort.wgsl:129-137);
+//   * launch 2 (k_regroup): the first workgroups scan the per-block totals in chunks (active list,
+//     first_particle: prefix_sum.wgsl), the others — one wave per active block, lane = cell — set
+//     the block up (neighbour links, node cdf tile) and build the new cell runs by merging each
+//     cell's stayers (already in id order) with its arrivals (selected in id order from the list):
+//     the order inside a cell is canonical (ascending persistent particle id) by construction, so
+//     every downstream fp32 sum is reproducible run to run and independent of the storage order
+//     (reference: atomic race order, sort.wgsl:126,133). The waves only wait for the scan (a flag
+//     per chunk) when they need their block's first_particle, after all their independent work;
+//   * no per-particle rank, no per-cell counters, no sorting pass.
 #pragma once
 #include "kernels_cdf.h"
 
@@ -32,38 +40,25 @@ template <int D> __device__ inline void load_cell(const float *in, uint32_t npad
     if constexpr (D == 3) cell[2] = assoc_cell(xm.z, h);
 }
 
-// Per-cell counting of one wave's particles (sort.wgsl:89-99 extended to cells). Scattered device-scope
-// atomics run at the memory side on MI355X (~20 G/s when every lane hits its own line), so: LDS histogram
-// per (wave, block), lanes get their rank inside the wave's group from an LDS atomic, and ONE coalesced
-// returning global atomic per (wave, block) reserves the group's range inside each cell. The arrival
-// order of those atomics (and the LDS arbitration order) leaks into `rank`; k_canonical_order sorts each
-// cell by particle id afterwards. Wave-uniform control flow: call with all 64 lanes.
-__device__ inline void count_cells(const Dev &d, uint32_t *hist, int lane, uint32_t myid, uint32_t local, uint32_t &cid, uint32_t &rank) {
+// sort.wgsl:129-137 (per-cell linked list), for movers only: slot i becomes the head of its destination
+// cell's list. cell_head holds slot + 1 (0 = empty: the array is zero at rest, k_regroup resets what it consumed).
+__device__ inline void push_mover(const Dev &d, uint32_t cid, uint32_t i) { d.mv_next[i] = atomicExch(&d.cell_head[cid], i + 1u); }
+
+// sort.wgsl:89-99 update_block_particle_count, aggregated: one atomic per (wave, block). Wave-uniform control flow.
+__device__ inline void count_blocks(const Dev &d, int lane, uint32_t myid) {
     unsigned long long todo = __ballot(myid != NONE);
     while (todo) {
         const int leader = __ffsll((long long)todo) - 1;
         const uint32_t id0 = __shfl(myid, leader);
-        const bool mine = myid == id0;
-        const unsigned long long same = __ballot(mine);
+        const unsigned long long same = __ballot(myid == id0);
         todo &= ~same;
         if (lane == leader) atomicAdd(&d.block_acc[id0], (uint32_t)__popcll(same));
-        // Cross-lane traffic through LDS inside one wave uses (relaxed, wavefront-scope) atomic
-        // accesses so the compiler may not forward this lane's own stores to its loads.
-        __hip_atomic_store(&hist[lane], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-        uint32_t r = 0;
-        if (mine) r = __hip_atomic_fetch_add(&hist[local], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-        const uint32_t cnt = __hip_atomic_load(&hist[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-        uint32_t base = 0;
-        if (cnt) base = atomicAdd(&d.cell_count[id0 * NPB + lane], cnt);
-        __hip_atomic_store(&hist[lane], base, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-        if (mine) {
-            cid = id0 * NPB + local;
-            rank = __hip_atomic_load(&hist[local], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT) + r;
-        }
     }
 }
 
-// sort.wgsl:26-36 touch_particle_blocks + sort.wgsl:89-99 update_block_particle_count, fused.
+// sort.wgsl:26-36 touch_particle_blocks + sort.wgsl:89-99 update_block_particle_count, fused: the general form of
+// launch 1 (first substep, table-rebuild substeps, particles that arrived from a neighbouring rank). Every particle
+// it bins is a mover (it has no previous cell).
 // `tail`: sharded steady state — only the particles that arrived from the neighbours, slots [NPREV, N); the
 // residents go through k_rebin. `tail` = 2 also APPENDS them first: thread r copies record r of the two inbound
 // migration messages into slot NPREV + r and does the bookkeeping of the migration round (one launch instead of
@@ -76,10 +71,10 @@ template <int D, int TAIL> __global__ __launch_bounds__(SORT_THREADS) void k_bin
     constexpr int tail = TAIL;  // 0 = every slot, 1 = the arrivals (already appended), 2 = append + bin the arrivals
     constexpr int BS = Dim<D>::BSHIFT, BW = Dim<D>::BW, NN = Dim<D>::NNBR;
     __shared__ uint32_t s_keys[TOUCH_SET], s_ids[TOUCH_SET];
-    __shared__ uint32_t s_hist[SORT_THREADS / 64][NPB];
     const float *in = d.buf[side];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
     if (tid < TOUCH_SET) s_keys[tid] = NONE;
+    if (blockIdx.x == 0 && tid == 0) d.counters[CTR_NCPIC] = 0;  // near-collider list of this substep (k_regroup appends)
     __syncthreads();
     const uint32_t first = tail ? d.counters[CTR_NPREV] : 0u;
     const uint32_t i = first + blockIdx.x * SORT_THREADS + tid;
@@ -171,35 +166,37 @@ template <int D, int TAIL> __global__ __launch_bounds__(SORT_THREADS) void k_bin
         }
     }
     __syncthreads();
-    const uint32_t myid = !valid ? NONE : (myslot != NONE ? s_ids[myslot] : mydirect);
-    // ---- 3. count per cell
-    uint32_t cid = NONE, rank = 0;
-    count_cells(d, s_hist[wave], lane, myid, local, cid, rank);
+    uint32_t myid = !valid ? NONE : (myslot != NONE ? s_ids[myslot] : mydirect);
+    if (myid >= d.cap) myid = NONE;  // grid overflow (reported): the particle is left out of this substep
+    // ---- 3. per-block totals; every particle is a mover into its cell
+    count_blocks(d, lane, myid);
     if (i < slots_end) {
+        const uint32_t cid = myid == NONE ? NONE : myid * NPB + local;
         d.cellid[i] = cid;
-        d.rank[i] = rank;
+        if (cid != NONE) push_mover(d, cid, i);
     }
 }
 
-// Steady-state binning (sort.wgsl:26-36,89-99 for a buffer that is the sorted output of the previous
+// Steady-state launch 1 (sort.wgsl:26-36,89-99 for a buffer that is the sorted output of the previous
 // substep): slot i held cell perm_cell[i] of block b = perm_cell[i] >> 6 one substep ago, particles move
 // less than a cell per substep, so almost every particle is still in block b: its new cell id is
 // b * 64 + new local cell and the blocks to activate are b's neighbour links of the previous substep —
-// no hash lookup, no LDS set. Only particles that changed block go through the hash map.
+// no hash lookup, no LDS set. Only particles that changed block go through the hash map, and only particles
+// that changed CELL are pushed on a list.
 template <int D> __global__ __launch_bounds__(SORT_THREADS) void k_rebin(Dev d, int side, uint32_t epoch) {
     constexpr int BS = Dim<D>::BSHIFT, BW = Dim<D>::BW, NN = Dim<D>::NNBR;
-    __shared__ uint32_t s_hist[SORT_THREADS / 64][NPB];
     const float *in = d.buf[side];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
     const uint32_t i = blockIdx.x * SORT_THREADS + tid;
+    if (blockIdx.x == 0 && tid == 0) d.counters[CTR_NCPIC] = 0;  // near-collider list of this substep (k_regroup appends)
     // sharded runs: the residents only (arrivals have no previous cell: k_bin's tail pass), minus the slots
     // vacated by particles that migrated away
     const bool in_range = i < (d.sharded ? min(d.counters[CTR_NPREV], d.counters[CTR_N]) : num_slots(d));
     bool valid = in_range;
     if (d.sharded && valid) valid = ldpid<D>(in, d.npad, i) != 0xffffffffu;
-    uint32_t myid = NONE, local = 0;
+    uint32_t myid = NONE, local = 0, old = NONE;
     if (valid) {
-        const uint32_t old = d.perm_cell[i];  // NONE only after a grid overflow: take the hash path then
+        old = d.perm_cell[i];  // NONE only after a grid overflow: take the hash path then
         const uint32_t ob = old >> 6;
         const uint32_t okey = old != NONE ? d.block_key[ob] : 0u;
         int c[D], nb[3] = {0, 0, 0};
@@ -217,14 +214,17 @@ template <int D> __global__ __launch_bounds__(SORT_THREADS) void k_rebin(Dev d, 
         } else {
             const uint32_t key = pack_key<D>(nb);
             myid = (old != NONE && key == okey) ? ob : activate_block(d, key, epoch);  // few particles change block
+            if (myid >= d.cap) myid = NONE;
         }
     }
-    // activate every distinct block of the wave and its +1 neighbours (grid.wgsl:300-320)
+    // activate every distinct block of the wave and its +1 neighbours (grid.wgsl:300-320), count its particles
     unsigned long long todo = __ballot(myid != NONE);
     while (todo) {
         const int leader = __ffsll((long long)todo) - 1;
         const uint32_t b1 = __shfl(myid, leader);
-        todo &= ~__ballot(myid == b1);
+        const unsigned long long same = __ballot(myid == b1);
+        todo &= ~same;
+        if (lane == leader) atomicAdd(&d.block_acc[b1], (uint32_t)__popcll(same));
         if (lane < NN) {
             // links of the previous substep when they exist: a plain idempotent store. A block created just now,
             // re-activated after a pause, or whose neighbour was not active (it held no particle) goes
@@ -241,271 +241,303 @@ template <int D> __global__ __launch_bounds__(SORT_THREADS) void k_rebin(Dev d, 
             }
         }
     }
-    uint32_t cid = NONE, rank = 0;
-    count_cells(d, s_hist[wave], lane, myid, local, cid, rank);
-    if (in_range) {  // (a vacated slot gets NONE: k_scatter skips it)
+    if (in_range) {  // (a vacated slot gets NONE: k_regroup skips it)
+        const uint32_t cid = myid == NONE ? NONE : myid * NPB + local;
         d.cellid[i] = cid;
-        d.rank[i] = rank;
+        if (cid != NONE && cid != old) push_mover(d, cid, i);
     }
 }
 
-// Active list + first_particle: one pass over the known blocks (physical ids).
-//   active[a] = id of the a-th block stamped with the current epoch   (grid.wgsl:323-334's
-//               active_blocks list, in physical-id order)
+// ---------------------------------------------------------------------------------------------------------------
+// Launch 2. Chunked scan of the known blocks (physical ids): chunk k = ids [k * SCAN_CHUNK, (k + 1) * SCAN_CHUNK).
+//   active[a] = id of the a-th block stamped with the current epoch   (grid.wgsl:323-334's active_blocks list,
+//               in physical-id order)
 //   block_start[id] = exclusive scan of the particle counts           (sort.wgsl:101-115 + prefix_sum.wgsl)
-// One workgroup; the number of known blocks is at most a few hundred thousand.
-constexpr int SCAN_THREADS = 1024;
-constexpr int SCAN_ITEMS = 4;
-__global__ __launch_bounds__(SCAN_THREADS) void k_scan_active(Dev d, uint32_t epoch) {
-    __shared__ unsigned long long wave_sums[SCAN_THREADS / 64];
-    __shared__ unsigned long long carry_s;
+// A chunk's workgroup publishes its total (flag A), adds the totals of the chunks before it, writes its part of the
+// two arrays and says so (flag B). Flags carry the epoch, so nothing has to be reset between substeps.
+constexpr int SCAN_ITEMS = 16;
+constexpr int SCAN_CHUNK = SORT_THREADS * SCAN_ITEMS;  // 4096 blocks per scan workgroup
+constexpr int RUNCAP = 1024;  // particles of one block a wave stages in LDS (more: same code on global memory)
+
+__device__ inline void wait_flag(const uint32_t *flag, uint32_t epoch) {
+    while (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != epoch) __builtin_amdgcn_s_sleep(2);
+}
+
+__device__ __forceinline__ void scan_chunk(const Dev &d, uint32_t epoch, uint32_t k, uint32_t nchunks, unsigned long long *s_wave, unsigned long long *s_bcast) {
     const uint32_t nphys = min(d.counters[CTR_NPHYS], d.cap);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    if (tid == 0) carry_s = 0ull;
+    // packed scan: high word = number of active blocks, low word = particles
+    unsigned long long v[SCAN_ITEMS], sum = 0ull;
+    const uint32_t first = k * SCAN_CHUNK + (uint32_t)tid * SCAN_ITEMS;
+    uint32_t stamp[SCAN_ITEMS], acc[SCAN_ITEMS];
+#pragma unroll
+    for (int j = 0; j < SCAN_ITEMS; j++) {  // all loads unconditional and independent: one round trip
+        const uint32_t idc = min(first + j, nphys ? nphys - 1u : 0u);
+        stamp[j] = d.block_stamp[idc];
+        acc[j] = d.block_acc[idc];
+    }
+#pragma unroll
+    for (int j = 0; j < SCAN_ITEMS; j++) {
+        const bool act = first + j < nphys && stamp[j] == epoch;
+        v[j] = act ? ((1ull << 32) | (unsigned long long)acc[j]) : 0ull;
+        sum += v[j];
+    }
+    unsigned long long inc = sum;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const unsigned long long t = __shfl_up(inc, off);
+        if (lane >= off) inc += t;
+    }
+    if (lane == 63) s_wave[wave] = inc;
     __syncthreads();
-    for (uint32_t base = 0; base < nphys; base += SCAN_THREADS * SCAN_ITEMS) {
-        // packed scan: high word = number of active blocks, low word = particles
-        unsigned long long v[SCAN_ITEMS];
-        unsigned long long sum = 0ull;
-        const uint32_t first = base + (uint32_t)tid * SCAN_ITEMS;
+    unsigned long long wave_off = 0ull, total = 0ull;
 #pragma unroll
-        for (int k = 0; k < SCAN_ITEMS; k++) {
-            const uint32_t id = first + k;
-            const uint32_t idc = min(id, nphys - 1u);  // both loads unconditional: one round trip, not two
-            const uint32_t stamp = d.block_stamp[idc], acc = d.block_acc[idc];
-            const bool act = id < nphys && stamp == epoch;
-            v[k] = act ? ((1ull << 32) | (unsigned long long)acc) : 0ull;
-            sum += v[k];
-        }
-        unsigned long long inc = sum;
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            const unsigned long long t = __shfl_up(inc, off);
-            if (lane >= off) inc += t;
-        }
-        if (lane == 63) wave_sums[wave] = inc;
-        __syncthreads();
-        unsigned long long wave_off = 0ull;
-        for (int w = 0; w < wave; w++) wave_off += wave_sums[w];
-        unsigned long long run = carry_s + wave_off + inc - sum;
-#pragma unroll
-        for (int k = 0; k < SCAN_ITEMS; k++) {
-            if (v[k]) {
-                const uint32_t id = first + k;
-                d.active[(uint32_t)(run >> 32)] = id;
-                d.block_start[id] = (uint32_t)run;
-            }
-            run += v[k];
-        }
-        __syncthreads();
-        if (tid == SCAN_THREADS - 1) carry_s = run;
-        __syncthreads();
+    for (int w = 0; w < SORT_THREADS / 64; w++) {
+        const unsigned long long t = s_wave[w];
+        if (w < wave) wave_off += t;
+        total += t;
     }
-    if (tid < 4 && d.hdr_clear[tid]) d.hdr_clear[tid][0] = 0u;  // outgoing halo / migrant message counts of this substep
     if (tid == 0) {
-        d.counters[CTR_NBLOCKS] = (uint32_t)(carry_s >> 32);
-        d.counters[CTR_NCPIC] = 0;
+        d.chunk_total[k] = total;
+        __hip_atomic_store(&d.chunk_flag[k], epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
     }
+    // totals of the chunks before this one (at most cap / 4096 of them), fetched in parallel
+    unsigned long long part = 0ull;
+    for (uint32_t p = (uint32_t)tid; p < k; p += SORT_THREADS) {
+        wait_flag(&d.chunk_flag[p], epoch);
+        part += d.chunk_total[p];
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) part += __shfl_xor(part, off);
+    __syncthreads();  // s_wave consumed above
+    if (lane == 0) s_wave[wave] = part;
+    __syncthreads();
+    if (tid == 0) {
+        unsigned long long b = 0ull;
+        for (int w = 0; w < SORT_THREADS / 64; w++) b += s_wave[w];
+        *s_bcast = b;
+    }
+    __syncthreads();
+    const unsigned long long base = *s_bcast;
+    unsigned long long run = base + wave_off + inc - sum;
+#pragma unroll
+    for (int j = 0; j < SCAN_ITEMS; j++) {
+        if (v[j]) {
+            const uint32_t id = first + j;
+            d.active[(uint32_t)(run >> 32)] = id;
+            d.block_start[id] = (uint32_t)run;
+        }
+        run += v[j];
+    }
+    __threadfence();
+    __syncthreads();
+    if (tid == 0) {
+        __hip_atomic_store(&d.chunk_done[k], epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        if (k + 1 == nchunks) d.counters[CTR_NBLOCKS] = (uint32_t)((base + total) >> 32);
+    }
+    if (k == 0 && tid < 4 && d.hdr_clear[tid]) d.hdr_clear[tid][0] = 0u;  // outgoing halo / migrant message counts of this substep
 }
 
-// Per active block, one wave: neighbour links (replaces the per-thread hash lookups of
-// p2g.wgsl:238-275 / g2p.wgsl:72-132), per-cell offsets, and reset of the accumulators.
+// Per active block, one wave, lane = cell: neighbour links (replaces the per-thread hash lookups of
+// p2g.wgsl:238-275 / g2p.wgsl:72-132), the new cell runs (sort.wgsl:117-127 finalize_particles_sort, in canonical
+// order), reset of the accumulators.
 // CDF (collider simulations without mesh colliders): also the node cdf of the block's (BW+2)^D tile and the class of
 // the block (see k_cdf, whose steps 1 and 2 these are; step 3 then runs in the prologue of the CPIC P2G launch), so
 // that a collider simulation needs no CDF launch of its own.
-template <int D, bool CDF> __device__ __forceinline__ void block_setup_body(const Dev &d, uint32_t epoch, uint32_t wg, uint32_t nwg) {
+// `have_old`: the buffer is the sorted output of the previous substep (cell_start / cell_cursor of a block whose
+// links are one epoch old describe its previous runs: that is where the stayers are); otherwise every particle is
+// on a list.
+template <int D, bool CDF>
+__device__ __forceinline__ void regroup_block(const Dev &d, int side, uint32_t epoch, uint32_t id, bool have_old, uint32_t *s_in, uint32_t *s_out) {
     constexpr int NN = Dim<D>::NNBR;
-    const uint32_t B = min(d.counters[CTR_NBLOCKS], d.cap);
     const int lane = threadIdx.x & 63;
-    const uint32_t wave = (wg * SORT_THREADS + threadIdx.x) >> 6;
-    const uint32_t nwaves = (nwg * SORT_THREADS) >> 6;
-    for (uint32_t a = wave; a < B; a += nwaves) {
-        const uint32_t id = d.active[a];
-        uint32_t res = NONE;
-        int b[3] = {0, 0, 0};
-        unpack_key<D>(d.block_key[id], b);
-        if (lane < 16) {
-            const uint32_t o = lane & 7u;
-            const bool minus = lane >= 8;
-            if ((int)o < NN) {
-                const int sgn = minus ? -1 : 1;
-                int nb[3] = {b[0] + sgn * (int)(o & 1u), b[1] + sgn * (int)((o >> 1) & 1u), b[2] + sgn * (int)((o >> 2) & 1u)};
-                if (block_in_key_range<D>(nb)) res = hmap_find(d, pack_key<D>(nb), epoch);
-            }
-            (minus ? d.nbr_minus : d.nbr_plus)[id * 8u + o] = res;
-        }
-        const uint32_t idx = id * NPB + lane;
-        const uint32_t cnt = d.cell_count[idx];
-        uint32_t inc = cnt;
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            const uint32_t t = __shfl_up(inc, off);
-            if (lane >= off) inc += t;
-        }
-        const uint32_t start = d.block_start[id] + inc - cnt;
-        d.cell_start[idx] = start;
-        d.cell_cursor[idx] = start + cnt;  // cell end (cell_count itself is cleared by k_grid_update: the scatter
-                                           // half of this launch still reads it)
-        if (d.n_rigid != 0u) {             // mesh-collider cdf accumulators of this substep (k_p2g_cdf)
-            d.mesh_min[idx] = ~0ull;
-            d.mesh_aff[idx] = 0u;
-        }
-        if (lane == 63) {
-            d.block_count[id] = inc;       // snapshot used by P2G / grid update / G2P
-            d.links_epoch[id] = epoch;     // the neighbour links written above are those of this substep
-            d.block_acc[id] = 0;
-            d.block_cdf_flag[id] = 0;
-        }
-        if constexpr (CDF) {
-            constexpr int BW = Dim<D>::BW, BS = Dim<D>::BSHIFT, TW = Dim<D>::TW, TILE = Dim<D>::TILE;
-            uint32_t mine = 0u;
-            // Quick reject, wave-uniform: a collider whose boundary is farther from the tile's centre than the tile's
-            // half diagonal plus the affinity reach (1.5 h per axis) touches none of its nodes, and a centre outside
-            // the shape then means every node is outside. One projection per collider instead of (BW+2)^D.
-            uint32_t near = 0u;  // bit i: collider i can reach a node of this tile
-            {
-                float ctr[D];
-#pragma unroll
-                for (int k = 0; k < D; k++) ctr[k] = ((float)(b[k] * BW) + 0.5f * (float)(TW - 1)) * d.h;
-                const float reach = (0.5f * (float)(TW - 1) + 1.5f) * d.h * (D == 3 ? 1.7320508f : 1.4142136f) * 1.001f;
-                for (uint32_t i = 0; i < d.n_colliders && i < 16u; i++) {
-                    const ColliderDev &c = d.colliders[i];
-                    if (c.shape_type >= 3u) continue;
-                    float pl[D], projl[D], proj[D];
-                    pose_to_local<D>(c, ctr, pl);
-                    const bool inside = project_local_on_boundary<D>(c, pl, projl);
-                    pose_to_world<D>(c, projl, proj);
-                    float n2 = 0.f;
-#pragma unroll
-                    for (int k = 0; k < D; k++) n2 += (proj[k] - ctr[k]) * (proj[k] - ctr[k]);
-                    near |= (inside || !(n2 > reach * reach)) ? (1u << i) : 0u;
-                }
-            }
-            for (int n = lane; n < ((TILE + 63) / 64) * 64; n += 64) {
-                int t[3] = {n % TW, (n / TW) % TW, D == 3 ? n / (TW * TW) : 0};
-                const int o = (t[0] >= BW ? 1 : 0) | (t[1] >= BW ? 2 : 0) | (t[2] >= BW ? 4 : 0);
-                const uint32_t nb = __shfl(res, o & 7);        // "+" links live in lanes 0..7
-                if (n < TILE && nb != NONE) {                  // nodes of blocks that are not active do not exist
-                    float pt[D];
-#pragma unroll
-                    for (int k = 0; k < D; k++) pt[k] = (float)(b[k] * BW + t[k]) * d.h;
-                    const NodeCdf far_cdf = {1.0e10f, 0u, NONE, 0u};
-                    const NodeCdf c = near ? node_cdf_eval<D>(d, pt, near) : far_cdf;
-                    if (o == 0) d.node_cdf[(size_t)id * NPB + (t[0] + (t[1] << BS) + (D == 3 ? (t[2] << (2 * BS)) : 0))] = c;
-                    mine |= c.affinities;
-                }
-            }
-            const bool any = __ballot(mine != 0u) != 0ull;
-            const uint32_t total = __shfl(inc, 63);
-            if (lane == 0) {
-                d.block_cpic[id] = any ? 1u : 0u;
-                if (any && total > 0u) d.cpic_list[atomicAdd(&d.counters[CTR_NCPIC], 1u)] = id;  // few blocks
-            }
-        }
+    const float *in = d.buf[side];
+    const uint32_t idx = id * NPB + lane;
+    // ---- previous runs of this block (before anything of it is overwritten)
+    const bool old_ok = have_old && d.links_epoch[id] == epoch - 1u;
+    uint32_t cs_old = 0, ce_old = 0;
+    if (old_ok) {
+        cs_old = d.cell_start[idx];
+        ce_old = d.cell_cursor[idx];
     }
-}
-
-// sort.wgsl:117-127 finalize_particles_sort (the sorted-ids half). Also writes the particle
-// ids in sorted order (= the reference's sorted_particle_ids) so that the canonical-order
-// pass reads them contiguously instead of gathering through `perm`.
-// The cell offsets are recomputed here from the cell counts (one coalesced 256-byte read + a wave scan per distinct
-// block of the wave: one to three blocks in a sorted buffer) instead of read from cell_start, so that this pass does
-// not depend on the block setup and shares its launch. Wave-uniform control flow: call with all 64 lanes.
-template <int D> __device__ __forceinline__ void scatter_body(const Dev &d, int side, uint32_t i, uint32_t *offs) {
-    const int lane = threadIdx.x & 63;
-    uint32_t cid = NONE;
-    if (i < num_slots(d)) cid = d.cellid[i];
-    const uint32_t myid = cid == NONE ? NONE : cid / NPB;
-    uint32_t start = 0;
-    unsigned long long todo = __ballot(myid != NONE);
-    while (todo) {
-        const int leader = __ffsll((long long)todo) - 1;
-        const uint32_t id0 = __shfl(myid, leader);
-        const bool mine = myid == id0;
-        todo &= ~__ballot(mine);
-        const uint32_t cnt = d.cell_count[id0 * NPB + lane];
-        uint32_t inc = cnt;
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            const uint32_t v = __shfl_up(inc, off);
-            if (lane >= off) inc += v;
+    uint32_t head = d.cell_head[idx];
+    // ---- neighbour links
+    uint32_t res = NONE;
+    int b[3] = {0, 0, 0};
+    unpack_key<D>(d.block_key[id], b);
+    if (lane < 16) {
+        const uint32_t o = lane & 7u;
+        const bool minus = lane >= 8;
+        if ((int)o < NN) {
+            const int sgn = minus ? -1 : 1;
+            int nb[3] = {b[0] + sgn * (int)(o & 1u), b[1] + sgn * (int)((o >> 1) & 1u), b[2] + sgn * (int)((o >> 2) & 1u)};
+            if (block_in_key_range<D>(nb)) res = hmap_find(d, pack_key<D>(nb), epoch);
         }
-        __hip_atomic_store(&offs[lane], d.block_start[id0] + inc - cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-        if (mine) start = __hip_atomic_load(&offs[cid % NPB], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+        (minus ? d.nbr_minus : d.nbr_plus)[id * 8u + o] = res;
     }
-    if (cid == NONE) return;
-    const uint32_t r = start + d.rank[i];
-    d.perm[r] = i;
-    d.perm_cell[r] = cid;
-    d.perm_pid[r] = ldpid<D>(d.buf[side], d.npad, i);
-}
-
-// Block setup and scatter in ONE launch: both only need the scan (active list, block_start) and the cell counts. The
-// first `nsetup` workgroups run the (longer) per-block setup, the others scatter 256 particles each.
-template <int D, bool CDF> __global__ __launch_bounds__(SORT_THREADS) void k_setup_scatter(Dev d, int side, uint32_t epoch, uint32_t nsetup) {
-    __shared__ uint32_t s_offs[SORT_THREADS / 64][64];
-    if (blockIdx.x < nsetup) block_setup_body<D, CDF>(d, epoch, blockIdx.x, nsetup);
-    else scatter_body<D>(d, side, (blockIdx.x - nsetup) * SORT_THREADS + threadIdx.x, s_offs[threadIdx.x >> 6]);
-}
-
-// Canonical order inside each cell: ascending persistent particle id. One thread per cell.
-// Cells whose membership did not change since the last substep are already sorted (the buffer
-// is written in canonical order), so the common case is one contiguous read and an early exit.
-constexpr int CANON_REG = 12;
-__global__ __launch_bounds__(SORT_THREADS) void k_canonical_order(Dev d) {
-    const uint32_t B = min(d.counters[CTR_NBLOCKS], d.cap);
-    const uint32_t total = B * NPB;
-    for (uint32_t t = blockIdx.x * SORT_THREADS + threadIdx.x; t < total; t += gridDim.x * SORT_THREADS) {
-        const uint32_t c = d.active[t >> 6] * NPB + (t & 63u);
-        const uint32_t s = d.cell_start[c], e = d.cell_cursor[c];
-        const uint32_t m = e - s;
-        if (m < 2) continue;
-        if (m <= CANON_REG) {
-            uint32_t k[CANON_REG];
+    // ---- stage the new cell ids of the block's previous run (contiguous: cells are consecutive runs)
+    const uint32_t run0 = __shfl(cs_old, 0), run1 = __shfl(ce_old, 63);
+    const uint32_t runlen = run1 - run0;
+    const bool in_lds = runlen <= (uint32_t)RUNCAP;
+    if (in_lds)
+        for (uint32_t t = lane; t < runlen; t += 64) s_in[t] = d.cellid[run0 + t];
+    // (single wave: LDS accesses of a wave execute in order, the relaxed wavefront-scope atomics below keep the
+    // compiler from reordering or forwarding across lanes)
+    auto new_cell_of = [&](uint32_t i) {
+        return in_lds ? __hip_atomic_load(&s_in[i - run0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT) : d.cellid[i];
+    };
+    // ---- pass 1: members of the new run = stayers of the previous run + arrivals on the list
+    uint32_t n_stay = 0, n_arr = 0;
+    for (uint32_t i = cs_old; i < ce_old; i++) n_stay += new_cell_of(i) == idx ? 1u : 0u;
+    for (uint32_t a = head; a != 0u; a = d.mv_next[a - 1u]) n_arr++;
+    const uint32_t total = n_stay + n_arr;
+    uint32_t inc = total;
 #pragma unroll
-            for (int q = 0; q < CANON_REG; q++) k[q] = (uint32_t)q < m ? d.perm_pid[s + q] : NONE;  // NONE sorts last
-            bool sorted = true;
-#pragma unroll
-            for (int q = 1; q < CANON_REG; q++) sorted = sorted && k[q - 1] <= k[q];
-            if (sorted) continue;
-            // (pid << 32 | perm) packed so that one 64-bit compare-exchange moves both;
-            // odd-even transposition sort: fixed network, no run-time register indexing
-            unsigned long long kp[CANON_REG];
-#pragma unroll
-            for (int q = 0; q < CANON_REG; q++)
-                kp[q] = ((unsigned long long)k[q] << 32) | ((uint32_t)q < m ? d.perm[s + q] : NONE);
-#pragma unroll
-            for (int pass = 0; pass < CANON_REG; pass++) {
-#pragma unroll
-                for (int q = pass & 1; q + 1 < CANON_REG; q += 2) {
-                    const unsigned long long lo = kp[q] < kp[q + 1] ? kp[q] : kp[q + 1];
-                    const unsigned long long hi = kp[q] < kp[q + 1] ? kp[q + 1] : kp[q];
-                    kp[q] = lo;
-                    kp[q + 1] = hi;
-                }
-            }
-#pragma unroll
-            for (int q = 0; q < CANON_REG; q++)
-                if ((uint32_t)q < m) {
-                    d.perm[s + q] = (uint32_t)kp[q];
-                    d.perm_pid[s + q] = (uint32_t)(kp[q] >> 32);
-                }
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t t = __shfl_up(inc, off);
+        if (lane >= off) inc += t;
+    }
+    const uint32_t btotal = __shfl(inc, 63);
+    // ---- the scan's result for this block (first_particle)
+    wait_flag(&d.chunk_done[id / SCAN_CHUNK], epoch);
+    const uint32_t bstart = __hip_atomic_load(&d.block_start[id], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const uint32_t lstart = inc - total;  // start of this cell's run inside the block
+    // ---- pass 2: merge in ascending particle id. Stayers are in id order already; the next arrival is selected
+    // from the (short) list: smallest id above the last one taken.
+    const bool out_lds = btotal <= (uint32_t)RUNCAP;
+    uint32_t out = lstart;
+    auto emit = [&](uint32_t src) {
+        if (out_lds) {
+            __hip_atomic_store(&s_out[out], ((uint32_t)lane << 26) | src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
         } else {
-            for (uint32_t a = s + 1; a < e; a++) {
-                const uint32_t pa = d.perm[a], ka = d.perm_pid[a];
-                uint32_t j = a;
-                while (j > s) {
-                    const uint32_t kj = d.perm_pid[j - 1];
-                    if (kj <= ka) break;
-                    d.perm[j] = d.perm[j - 1];
-                    d.perm_pid[j] = kj;
-                    j--;
-                }
-                d.perm[j] = pa;
-                d.perm_pid[j] = ka;
+            d.perm[bstart + out] = src;
+            d.perm_cell[bstart + out] = idx;
+        }
+        out++;
+    };
+    uint32_t arr_slot = NONE, arr_pid = 0;
+    bool have_last = false;
+    uint32_t last_pid = 0;
+    auto next_arrival = [&]() {  // smallest pid on the list that is > last_pid (ids are unique)
+        arr_slot = NONE;
+        for (uint32_t a = head; a != 0u; a = d.mv_next[a - 1u]) {
+            const uint32_t p = ldpid<D>(in, d.npad, a - 1u);
+            if (have_last && p <= last_pid) continue;
+            if (arr_slot == NONE || p < arr_pid) { arr_slot = a - 1u; arr_pid = p; }
+        }
+    };
+    if (n_arr) next_arrival();
+    for (uint32_t i = cs_old; i < ce_old; i++) {
+        if (new_cell_of(i) != idx) continue;
+        if (arr_slot != NONE) {
+            const uint32_t ps = ldpid<D>(in, d.npad, i);
+            while (arr_slot != NONE && arr_pid < ps) {
+                emit(arr_slot);
+                have_last = true;
+                last_pid = arr_pid;
+                next_arrival();
             }
         }
+        emit(i);
     }
+    while (arr_slot != NONE) {
+        emit(arr_slot);
+        have_last = true;
+        last_pid = arr_pid;
+        next_arrival();
+    }
+    if (out_lds)
+        for (uint32_t t = lane; t < btotal; t += 64) {
+            const uint32_t v = __hip_atomic_load(&s_out[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+            d.perm[bstart + t] = v & 0x03ffffffu;
+            d.perm_cell[bstart + t] = id * NPB + (v >> 26);
+        }
+    // ---- new runs, reset of what this substep consumed
+    d.cell_start[idx] = bstart + lstart;
+    d.cell_cursor[idx] = bstart + lstart + total;
+    if (head != 0u) d.cell_head[idx] = 0u;
+    if (d.n_rigid != 0u) {             // mesh-collider cdf accumulators of this substep (k_p2g_cdf)
+        d.mesh_min[idx] = ~0ull;
+        d.mesh_aff[idx] = 0u;
+    }
+    if (lane == 63) {
+        d.block_count[id] = btotal;    // snapshot used by P2G / grid update / G2P
+        d.links_epoch[id] = epoch;     // the neighbour links and cell runs written above are those of this substep
+        d.block_acc[id] = 0;           // (the scan has read it: its chunk is done)
+        d.block_cdf_flag[id] = 0;
+    }
+    if constexpr (CDF) {
+        constexpr int BW = Dim<D>::BW, BS = Dim<D>::BSHIFT, TW = Dim<D>::TW, TILE = Dim<D>::TILE;
+        uint32_t mine = 0u;
+        // Quick reject, wave-uniform: a collider whose boundary is farther from the tile's centre than the tile's
+        // half diagonal plus the affinity reach (1.5 h per axis) touches none of its nodes, and a centre outside
+        // the shape then means every node is outside. One projection per collider instead of (BW+2)^D.
+        uint32_t near = 0u;  // bit i: collider i can reach a node of this tile
+        {
+            float ctr[D];
+#pragma unroll
+            for (int k = 0; k < D; k++) ctr[k] = ((float)(b[k] * BW) + 0.5f * (float)(TW - 1)) * d.h;
+            const float reach = (0.5f * (float)(TW - 1) + 1.5f) * d.h * (D == 3 ? 1.7320508f : 1.4142136f) * 1.001f;
+            for (uint32_t i = 0; i < d.n_colliders && i < 16u; i++) {
+                const ColliderDev &c = d.colliders[i];
+                if (c.shape_type >= 3u) continue;
+                float pl[D], projl[D], proj[D];
+                pose_to_local<D>(c, ctr, pl);
+                const bool inside = project_local_on_boundary<D>(c, pl, projl);
+                pose_to_world<D>(c, projl, proj);
+                float n2 = 0.f;
+#pragma unroll
+                for (int k = 0; k < D; k++) n2 += (proj[k] - ctr[k]) * (proj[k] - ctr[k]);
+                near |= (inside || !(n2 > reach * reach)) ? (1u << i) : 0u;
+            }
+        }
+        for (int n = lane; n < ((TILE + 63) / 64) * 64; n += 64) {
+            int t[3] = {n % TW, (n / TW) % TW, D == 3 ? n / (TW * TW) : 0};
+            const int o = (t[0] >= BW ? 1 : 0) | (t[1] >= BW ? 2 : 0) | (t[2] >= BW ? 4 : 0);
+            const uint32_t nb = __shfl(res, o & 7);        // "+" links live in lanes 0..7
+            if (n < TILE && nb != NONE) {                  // nodes of blocks that are not active do not exist
+                float pt[D];
+#pragma unroll
+                for (int k = 0; k < D; k++) pt[k] = (float)(b[k] * BW + t[k]) * d.h;
+                const NodeCdf far_cdf = {1.0e10f, 0u, NONE, 0u};
+                const NodeCdf c = near ? node_cdf_eval<D>(d, pt, near) : far_cdf;
+                if (o == 0) d.node_cdf[(size_t)id * NPB + (t[0] + (t[1] << BS) + (D == 3 ? (t[2] << (2 * BS)) : 0))] = c;
+                mine |= c.affinities;
+            }
+        }
+        const bool any = __ballot(mine != 0u) != 0ull;
+        if (lane == 0) {
+            d.block_cpic[id] = any ? 1u : 0u;
+            if (any && btotal > 0u) d.cpic_list[atomicAdd(&d.counters[CTR_NCPIC], 1u)] = id;  // few blocks
+        }
+    }
+}
+
+// Launch 2: the first `nscan` workgroups scan, the others regroup (one wave per active block, strided over the
+// physical ids). The scan workgroups have the lowest indices, so they are resident before any wave can wait for them.
+template <int D, bool CDF> __global__ __launch_bounds__(SORT_THREADS) void k_regroup(Dev d, int side, uint32_t epoch, uint32_t nscan, int have_old) {
+    __shared__ unsigned long long s_wave[SORT_THREADS / 64];
+    __shared__ unsigned long long s_bcast;
+    __shared__ uint32_t s_in[SORT_THREADS / 64][RUNCAP], s_out[SORT_THREADS / 64][RUNCAP];
+    if (blockIdx.x < nscan) {
+        scan_chunk(d, epoch, blockIdx.x, nscan, s_wave, &s_bcast);
+        return;
+    }
+    const uint32_t nphys = min(d.counters[CTR_NPHYS], d.cap);
+    const uint32_t wave = ((blockIdx.x - nscan) * SORT_THREADS + threadIdx.x) >> 6;
+    const uint32_t nwaves = ((gridDim.x - nscan) * SORT_THREADS) >> 6;
+    const int w = threadIdx.x >> 6;
+    for (uint32_t id = wave; id < nphys; id += nwaves) {
+        if (d.block_stamp[id] != epoch) continue;  // wave-uniform
+        regroup_block<D, CDF>(d, side, epoch, id, have_old != 0, s_in[w], s_out[w]);
+    }
+}
+
+// Test hook (wgs_debug_scan): the scan workgroups alone.
+__global__ __launch_bounds__(SORT_THREADS) void k_scan_only(Dev d, uint32_t epoch, uint32_t nscan) {
+    __shared__ unsigned long long s_wave[SORT_THREADS / 64];
+    __shared__ unsigned long long s_bcast;
+    scan_chunk(d, epoch, blockIdx.x, nscan, s_wave, &s_bcast);
 }
 
 }  // namespace wgs

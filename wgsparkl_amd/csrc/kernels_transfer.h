@@ -243,7 +243,6 @@ template <int D, int PHASE, bool TWOWAY = false> __global__ __launch_bounds__(25
             d.nodes[node] = sum;
             continue;
         }
-        d.cell_count[node] = 0;  // the sort's per-cell accumulators are zero at rest (last read: k_setup_scatter)
         if constexpr (PHASE == 2) sum = d.nodes[node];
         if constexpr (PHASE == 3) {
             if (from_nodes) sum = d.nodes[node];

@@ -120,10 +120,9 @@ struct Dev {
     uint32_t npad;       // plane stride (floats)
     float *buf[2];       // ping-pong particle buffers
     uint32_t *perm;      // sorted slot -> index in the current buffer
-    uint32_t *perm_pid;  // sorted slot -> persistent particle id (the reference's sorted_particle_ids)
     uint32_t *perm_cell; // sorted slot -> physical block id * 64 + cell in block
-    uint32_t *cellid;    // per particle (current-buffer index): dense block id * 64 + cell in block
-    uint32_t *rank;      // per particle: position inside its cell (arrival order; canonicalised later)
+    uint32_t *cellid;    // per particle (current-buffer index): NEW dense cell id = physical block id * 64 + cell in block
+    uint32_t *mv_next;   // per particle: next mover (slot + 1, 0 = end) on the list of the same destination cell
     // sparse block grid (grid.wgsl:82-184): open-addressing hash of packed block keys
     uint32_t *hkeys;     // hcap: packed key or NONE
     uint32_t *hvals;     // hcap: physical block id of the slot's key (NONE while the insert is in flight)
@@ -133,15 +132,17 @@ struct Dev {
     uint32_t *block_key;   // cap: packed virtual id
     uint32_t *block_stamp; // cap: epoch of the last substep in which the block was active
     uint32_t *links_epoch; // cap: epoch at which nbr_plus / nbr_minus of the block were last written
-    uint32_t *block_acc;   // cap: particle counter being accumulated by k_bin (zero at rest)
+    uint32_t *block_acc;   // cap: particle counter being accumulated by k_bin / k_rebin (zero at rest)
     uint32_t *block_count; // cap: particles whose associated cell is in the block (num_particles)
     uint32_t *block_start; // cap: exclusive scan of block_count over the active list (first_particle)
     uint32_t *active;      // cap: physical ids of the blocks active in this substep, [0, num_active_blocks)
     uint32_t *nbr_plus;    // cap*8: physical ids of b + {0,1}^D (always active)
     uint32_t *nbr_minus;   // cap*8: physical ids of b - {0,1}^D, NONE when inactive
-    uint32_t *cell_count;  // cap*64 (zero outside the sort)
+    uint32_t *cell_head;   // cap*64: head of the cell's list of movers of this substep (slot + 1; zero outside the sort)
     uint32_t *cell_start;  // cap*64
     uint32_t *cell_cursor; // cap*64: end of the cell's range in perm
+    unsigned long long *chunk_total;  // cap / 4096: (active blocks << 32 | particles) of a scan chunk (kernels_sort.h)
+    uint32_t *chunk_flag, *chunk_done; // cap / 4096: epoch at which the chunk's total / its part of the scan was published
     float4 *nodes;         // cap*64: velocity|momentum xyz, mass (2D: vx, vy, mass, 0)
     NodeCdf *node_cdf;     // cap*64
     float4 *slab;          // cap*TILE: per-block tile (block + its "+1" rim): momentum after P2G, velocity after the grid update
@@ -155,7 +156,7 @@ struct Dev {
     BodyDev *bodies;         // 16: mass properties
     int32_t *impulses;       // 16 * 8: fixed-point (x 1e5) linear[D] + angular impulses accumulated by P2G
     float4 *imp_slab;        // cap*TILE*IMPQ per-block partial node impulses (two-way coupling only), or null
-    uint32_t *hdr_clear[4];  // sharded: headers of the registered outgoing message buffers, zeroed by k_scan_active
+    uint32_t *hdr_clear[4];  // sharded: headers of the registered outgoing message buffers, zeroed by the scan of k_regroup
     // rigid particles of mesh colliders (kernels_rigid.h); n_rigid == 0 when there is none
     uint32_t n_rigid, n_rvtx;
     float *rp_local, *rp_world;          // n_rigid * D: sample points, body frame / world
