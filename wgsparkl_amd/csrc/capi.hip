@@ -537,7 +537,8 @@ template <bool TS> wgs_status enqueue_substep(wgs_data *d, int ts_slot, int part
             // cdf in the CPIC P2G launch (no CDF launch at all)
             {
                 const uint32_t nscan = (dev.cap + SCAN_CHUNK - 1) / SCAN_CHUNK;
-                const uint32_t nreg = std::min((dev.cap + 3u) / 4u, (uint32_t)grid_for(d, 5));
+                // one resident round: 4 workgroups per CU (127 VGPRs, 36 KB of LDS), the scan workgroups among them
+                const uint32_t nreg = std::max(1u, std::min((dev.cap + 3u) / 4u, (uint32_t)grid_for(d, 4) - std::min(nscan, (uint32_t)grid_for(d, 2))));
                 const dim3 g(nscan + nreg);
                 if (fused_cdf) hipLaunchKernelGGL((k_regroup<D, true>), g, dim3(SORT_THREADS), 0, s, dev, side, epoch, nscan, use_rebin ? 1 : 0);
                 else hipLaunchKernelGGL((k_regroup<D, false>), g, dim3(SORT_THREADS), 0, s, dev, side, epoch, nscan, use_rebin ? 1 : 0);
@@ -789,9 +790,10 @@ static wgs_status create_impl(wgs_pipeline *pipeline, const wgs_sim_params *para
     TRY_ALLOC(&dev.nbr_plus, (size_t)dev.cap * 8);
     TRY_ALLOC(&dev.nbr_minus, (size_t)dev.cap * 8);
     TRY_ALLOC(&dev.cell_head, (size_t)dev.cap * NPB);
-    TRY_ALLOC(&dev.chunk_total, (size_t)(dev.cap + SCAN_CHUNK - 1) / SCAN_CHUNK);
-    TRY_ALLOC(&dev.chunk_flag, (size_t)(dev.cap + SCAN_CHUNK - 1) / SCAN_CHUNK);
-    TRY_ALLOC(&dev.chunk_done, (size_t)(dev.cap + SCAN_CHUNK - 1) / SCAN_CHUNK);
+    TRY_ALLOC(&dev.chunk_a, (size_t)(dev.cap + SCAN_CHUNK - 1) / SCAN_CHUNK);
+    TRY_ALLOC(&dev.chunk_b, (size_t)(dev.cap + SCAN_CHUNK - 1) / SCAN_CHUNK);
+    TRY_ALLOC(&dev.group_a, (size_t)((dev.cap + SCAN_CHUNK - 1) / SCAN_CHUNK) * SORT_THREADS);
+    TRY_ALLOC(&dev.group_b, (size_t)((dev.cap + SCAN_CHUNK - 1) / SCAN_CHUNK) * SORT_THREADS);
     TRY_ALLOC(&dev.cell_start, (size_t)dev.cap * NPB);
     TRY_ALLOC(&dev.cell_cursor, (size_t)dev.cap * NPB);
     TRY_ALLOC(&dev.nodes, (size_t)dev.cap * NPB);
@@ -1482,10 +1484,11 @@ wgs_status wgs_debug_scan(wgs_pipeline *pipeline, const uint32_t *values, uint32
     dev.block_acc = (uint32_t *)alloc(sizeof(uint32_t) * dev.cap, 0);
     dev.active = (uint32_t *)alloc(sizeof(uint32_t) * dev.cap, 0);
     dev.block_start = (uint32_t *)alloc(sizeof(uint32_t) * dev.cap, 0);
-    dev.chunk_total = (unsigned long long *)alloc(sizeof(unsigned long long) * nscan, 0);
-    dev.chunk_flag = (uint32_t *)alloc(sizeof(uint32_t) * nscan, 0);
-    dev.chunk_done = (uint32_t *)alloc(sizeof(uint32_t) * nscan, 0);
-    if (!dev.counters || !dev.block_stamp || !dev.block_acc || !dev.active || !dev.block_start || !dev.chunk_total || !dev.chunk_flag || !dev.chunk_done) {
+    dev.chunk_a = (unsigned long long *)alloc(sizeof(unsigned long long) * nscan, 0);
+    dev.chunk_b = (unsigned long long *)alloc(sizeof(unsigned long long) * nscan, 0);
+    dev.group_a = (unsigned long long *)alloc(sizeof(unsigned long long) * nscan * SORT_THREADS, 0);
+    dev.group_b = (unsigned long long *)alloc(sizeof(unsigned long long) * nscan * SORT_THREADS, 0);
+    if (!dev.counters || !dev.block_stamp || !dev.block_acc || !dev.active || !dev.block_start || !dev.chunk_a || !dev.chunk_b || !dev.group_a || !dev.group_b) {
         cleanup();
         return fail(WGS_ERR_HIP, "out of device memory");
     }
@@ -1496,14 +1499,14 @@ wgs_status wgs_debug_scan(wgs_pipeline *pipeline, const uint32_t *values, uint32
     if (e == hipSuccess) e = hipMemcpy(dev.block_stamp, ones.data(), sizeof(uint32_t) * dev.cap, hipMemcpyHostToDevice);
     if (e == hipSuccess && n) e = hipMemcpy(dev.block_acc, values, sizeof(uint32_t) * n, hipMemcpyHostToDevice);
     if (e == hipSuccess) {
-        hipLaunchKernelGGL(k_scan_only, dim3(nscan), dim3(SORT_THREADS), 0, 0, dev, epoch, nscan);
+        hipLaunchKernelGGL(k_scan_only, dim3(nscan + std::min((n + 3u) / 4u + 1u, 2048u)), dim3(SORT_THREADS), 0, 0, dev, epoch, nscan);
         e = hipDeviceSynchronize();
     }
     if (e == hipSuccess && n) e = hipMemcpy(out, dev.block_start, sizeof(uint32_t) * n, hipMemcpyDeviceToHost);
     if (e == hipSuccess && total) {
         unsigned long long t = 0;  // sum of the chunk totals (low words)
         std::vector<unsigned long long> ct(nscan);
-        e = hipMemcpy(ct.data(), dev.chunk_total, sizeof(unsigned long long) * nscan, hipMemcpyDeviceToHost);
+        e = hipMemcpy(ct.data(), dev.chunk_b, sizeof(unsigned long long) * nscan, hipMemcpyDeviceToHost);
         for (auto v : ct) t += v & 0xffffffffull;
         *total = (uint32_t)t;
     }
@@ -1511,6 +1514,17 @@ wgs_status wgs_debug_scan(wgs_pipeline *pipeline, const uint32_t *values, uint32
     if (e != hipSuccess) return fail(WGS_ERR_HIP, hipGetErrorString(e));
     return WGS_OK;
 }
+
+#ifdef WGS_ABLATE
+// stage clocks of launch 2 (kernels_sort.h g_prof): read and reset. Experiment builds only, not in the header.
+wgs_status wgs_debug_prof(unsigned long long *out /* WGS_PROF_ROWS * 8 */) {
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_prof), sizeof(unsigned long long) * WGS_PROF_ROWS * 8));
+    std::vector<unsigned long long> zero((size_t)WGS_PROF_ROWS * 8, 0ull);
+    HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_prof), zero.data(), sizeof(unsigned long long) * WGS_PROF_ROWS * 8));
+    return WGS_OK;
+}
+#endif
 
 wgs_status wgs_read_timing_overhead(wgs_data *d, float *ms_per_mark) {
     if (!d || !ms_per_mark) return fail(WGS_ERR_INVALID_ARGUMENT, "NULL argument");

@@ -253,21 +253,53 @@ template <int D> __global__ __launch_bounds__(SORT_THREADS) void k_rebin(Dev d, 
 //   active[a] = id of the a-th block stamped with the current epoch   (grid.wgsl:323-334's active_blocks list,
 //               in physical-id order)
 //   block_start[id] = exclusive scan of the particle counts           (sort.wgsl:101-115 + prefix_sum.wgsl)
-// A chunk's workgroup publishes its total (flag A), adds the totals of the chunks before it, writes its part of the
-// two arrays and says so (flag B). Flags carry the epoch, so nothing has to be reset between substeps.
+// in two levels: the scan workgroups produce the totals before every group of 16 blocks, the wave that regroups a block
+// adds the blocks of its own group (block_prefix) and writes the block's two entries.
+// A chunk's workgroup publishes its total, adds the totals of the chunks before it and publishes the group totals
+// (wait_tagged / publish_tagged: epoch-tagged words, no fences).
+#ifdef WGS_ABLATE
+// Stage clocks of launch 2 (timing experiments, tools/gpu_sort_prof.py; never compiled into the product): one row of
+// absolute wall_clock64 readings (100 MHz) per regrouped block id: [0] start, [1..7] stages, and row WGS_PROF_ROWS - 1
+// [0] = when the scan published its last word. Plain stores, no atomics.
+constexpr int WGS_PROF_ROWS = 8192;
+__device__ unsigned long long g_prof[WGS_PROF_ROWS][8];
+#define WGS_PROF_START() if (lane == 0 && id < WGS_PROF_ROWS - 1) g_prof[id][0] = wall_clock64();
+#define WGS_PROF(k) if (lane == 0 && id < WGS_PROF_ROWS - 1) g_prof[id][1 + (k)] = wall_clock64();
+#define WGS_PROF_END()
+#else
+#define WGS_PROF_START()
+#define WGS_PROF(k)
+#define WGS_PROF_END()
+#endif
 constexpr int SCAN_ITEMS = 16;
 constexpr int SCAN_CHUNK = SORT_THREADS * SCAN_ITEMS;  // 4096 blocks per scan workgroup
-constexpr int RUNCAP = 1024;  // particles of one block a wave stages in LDS (more: same code on global memory)
+constexpr int RUNCAP = 768;   // particles of one block a wave stages in LDS (more: same code on global memory)
 
-__device__ inline void wait_flag(const uint32_t *flag, uint32_t epoch) {
-    while (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != epoch) __builtin_amdgcn_s_sleep(2);
+// Cross-workgroup hand-over inside launch 2 WITHOUT fences: on a multi-XCD part an agent-scope release / acquire
+// fence writes back / invalidates a whole L2, and four thousand waves doing that made this launch 100 us long. Every
+// value that crosses workgroups is instead one 64-bit word = (epoch << 32 | value), stored and polled with relaxed
+// agent-scope atomics (coherent accesses, no cache maintenance): a reader that sees the current epoch in the high word
+// has the value in the low word of the very same access. Epochs only grow, so nothing is reset between substeps.
+__device__ inline uint32_t wait_tagged(const unsigned long long *word, uint32_t epoch) {
+    unsigned long long v = __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    while ((uint32_t)(v >> 32) != epoch) {
+        __builtin_amdgcn_s_sleep(8);
+        v = __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    return (uint32_t)v;
+}
+__device__ inline void publish_tagged(unsigned long long *word, uint32_t epoch, uint32_t value) {
+    __hip_atomic_store(word, ((unsigned long long)epoch << 32) | value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 __device__ __forceinline__ void scan_chunk(const Dev &d, uint32_t epoch, uint32_t k, uint32_t nchunks, unsigned long long *s_wave, unsigned long long *s_bcast) {
     const uint32_t nphys = min(d.counters[CTR_NPHYS], d.cap);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+#ifdef WGS_ABLATE
+    if (tid == 0 && k == 0) g_prof[WGS_PROF_ROWS - 1][1] = wall_clock64();
+#endif
     // packed scan: high word = number of active blocks, low word = particles
-    unsigned long long v[SCAN_ITEMS], sum = 0ull;
+    unsigned long long sum = 0ull;
     const uint32_t first = k * SCAN_CHUNK + (uint32_t)tid * SCAN_ITEMS;
     uint32_t stamp[SCAN_ITEMS], acc[SCAN_ITEMS];
 #pragma unroll
@@ -279,8 +311,7 @@ __device__ __forceinline__ void scan_chunk(const Dev &d, uint32_t epoch, uint32_
 #pragma unroll
     for (int j = 0; j < SCAN_ITEMS; j++) {
         const bool act = first + j < nphys && stamp[j] == epoch;
-        v[j] = act ? ((1ull << 32) | (unsigned long long)acc[j]) : 0ull;
-        sum += v[j];
+        sum += act ? ((1ull << 32) | (unsigned long long)acc[j]) : 0ull;
     }
     unsigned long long inc = sum;
 #pragma unroll
@@ -297,16 +328,17 @@ __device__ __forceinline__ void scan_chunk(const Dev &d, uint32_t epoch, uint32_
         if (w < wave) wave_off += t;
         total += t;
     }
+#ifdef WGS_ABLATE
+    if (tid == 0 && k == 0) g_prof[WGS_PROF_ROWS - 1][2] = wall_clock64();
+#endif
     if (tid == 0) {
-        d.chunk_total[k] = total;
-        __hip_atomic_store(&d.chunk_flag[k], epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        publish_tagged(&d.chunk_a[k], epoch, (uint32_t)(total >> 32));
+        publish_tagged(&d.chunk_b[k], epoch, (uint32_t)total);
     }
     // totals of the chunks before this one (at most cap / 4096 of them), fetched in parallel
     unsigned long long part = 0ull;
-    for (uint32_t p = (uint32_t)tid; p < k; p += SORT_THREADS) {
-        wait_flag(&d.chunk_flag[p], epoch);
-        part += d.chunk_total[p];
-    }
+    for (uint32_t p = (uint32_t)tid; p < k; p += SORT_THREADS)
+        part += ((unsigned long long)wait_tagged(&d.chunk_a[p], epoch) << 32) + wait_tagged(&d.chunk_b[p], epoch);
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) part += __shfl_xor(part, off);
     __syncthreads();  // s_wave consumed above
@@ -319,23 +351,44 @@ __device__ __forceinline__ void scan_chunk(const Dev &d, uint32_t epoch, uint32_
     }
     __syncthreads();
     const unsigned long long base = *s_bcast;
-    unsigned long long run = base + wave_off + inc - sum;
-#pragma unroll
-    for (int j = 0; j < SCAN_ITEMS; j++) {
-        if (v[j]) {
-            const uint32_t id = first + j;
-            d.active[(uint32_t)(run >> 32)] = id;
-            d.block_start[id] = (uint32_t)run;
-        }
-        run += v[j];
-    }
-    __threadfence();
-    __syncthreads();
-    if (tid == 0) {
-        __hip_atomic_store(&d.chunk_done[k], epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-        if (k + 1 == nchunks) d.counters[CTR_NBLOCKS] = (uint32_t)((base + total) >> 32);
-    }
+    // what the regrouping waves of this launch need: the totals before each group of SCAN_ITEMS blocks (one coalesced
+    // pair of words per thread); a wave adds the few blocks of its own group itself (block_prefix)
+    const unsigned long long run = base + wave_off + inc - sum;
+    publish_tagged(&d.group_a[k * SORT_THREADS + tid], epoch, (uint32_t)(run >> 32));
+    publish_tagged(&d.group_b[k * SORT_THREADS + tid], epoch, (uint32_t)run);
+    if (tid == 0 && k + 1 == nchunks) d.counters[CTR_NBLOCKS] = (uint32_t)((base + total) >> 32);
+#ifdef WGS_ABLATE
+    if (tid == 0) g_prof[WGS_PROF_ROWS - 1][0] = wall_clock64();
+#endif
     if (k == 0 && tid < 4 && d.hdr_clear[tid]) d.hdr_clear[tid][0] = 0u;  // outgoing halo / migrant message counts of this substep
+}
+
+// Second level of the scan, by the wave that owns block `id`: loads of the group's 16 (stamp, count) pairs — issued
+// with the wave's other first-round loads —, then the group's tagged totals. Returns first_particle and the block's
+// index in the active list.
+struct GroupLoads {
+    uint32_t stamp, acc;
+};
+__device__ inline GroupLoads block_prefix_loads(const Dev &d, uint32_t id, int lane) {
+    GroupLoads g = {0u, 0u};
+    if (lane < SCAN_ITEMS) {
+        const uint32_t j = min((id & ~(uint32_t)(SCAN_ITEMS - 1)) + (uint32_t)lane, d.cap - 1u);
+        g.stamp = d.block_stamp[j];
+        g.acc = d.block_acc[j];
+    }
+    return g;
+}
+__device__ inline void block_prefix(const Dev &d, uint32_t epoch, uint32_t id, int lane, const GroupLoads &g, uint32_t nphys, uint32_t &start, uint32_t &aidx) {
+    const uint32_t gbase = id & ~(uint32_t)(SCAN_ITEMS - 1), j = id & (uint32_t)(SCAN_ITEMS - 1);
+    const bool before = lane < (int)j && gbase + (uint32_t)lane < nphys && g.stamp == epoch;
+    const uint32_t cnt = (uint32_t)__popcll(__ballot(before));
+    uint32_t psum = before ? g.acc : 0u;
+#pragma unroll
+    for (int off = 8; off > 0; off >>= 1) psum += __shfl_xor(psum, off);   // lanes 0..15 hold the terms
+    psum = __shfl(psum, 0);
+    const uint32_t grp = id / SCAN_ITEMS;
+    aidx = wait_tagged(&d.group_a[grp], epoch) + cnt;
+    start = wait_tagged(&d.group_b[grp], epoch) + psum;
 }
 
 // Per active block, one wave, lane = cell: neighbour links (replaces the per-thread hash lookups of
@@ -348,48 +401,99 @@ __device__ __forceinline__ void scan_chunk(const Dev &d, uint32_t epoch, uint32_
 // links are one epoch old describe its previous runs: that is where the stayers are); otherwise every particle is
 // on a list.
 template <int D, bool CDF>
-__device__ __forceinline__ void regroup_block(const Dev &d, int side, uint32_t epoch, uint32_t id, bool have_old, uint32_t *s_in, uint32_t *s_out) {
+__device__ __forceinline__ void regroup_block(const Dev &d, int side, uint32_t epoch, uint32_t id, uint32_t nphys, bool have_old, uint32_t *s_in,
+                                              uint32_t *s_out, uint32_t *s_pid) {
     constexpr int NN = Dim<D>::NNBR;
     const int lane = threadIdx.x & 63;
     const float *in = d.buf[side];
     const uint32_t idx = id * NPB + lane;
-    // ---- previous runs of this block (before anything of it is overwritten)
-    const bool old_ok = have_old && d.links_epoch[id] == epoch - 1u;
-    uint32_t cs_old = 0, ce_old = 0;
-    if (old_ok) {
-        cs_old = d.cell_start[idx];
-        ce_old = d.cell_cursor[idx];
+    WGS_PROF_START()
+    // ---- first round of loads, all independent: activity stamp, previous runs and links of this block (read before
+    // anything of it is overwritten), list heads
+    const uint32_t stamp = d.block_stamp[id];
+    const uint32_t le = d.links_epoch[id];
+    uint32_t cs_old = d.cell_start[idx], ce_old = d.cell_cursor[idx];
+    const uint32_t head = d.cell_head[idx];
+    const uint32_t bkey = d.block_key[id];
+    uint32_t link = NONE;
+    if (lane < 16) link = (lane >= 8 ? d.nbr_minus : d.nbr_plus)[id * 8u + (lane & 7u)];
+    const GroupLoads grp = block_prefix_loads(d, id, lane);
+    if (stamp != epoch) return;  // wave-uniform: not active in this substep
+    const bool old_ok = have_old && le == epoch - 1u;
+    if (!old_ok) {
+        cs_old = ce_old = 0u;
+        link = NONE;
     }
-    uint32_t head = d.cell_head[idx];
-    // ---- neighbour links
+    // a neighbour linked one substep ago keeps its physical id: it only has to be active now (one round trip instead
+    // of the three of a hash lookup)
+    uint32_t link_stamp = 0u;
+    if (link != NONE) link_stamp = d.block_stamp[link];
+    // ---- stage the new cell ids of the block's previous run (contiguous: cells are consecutive runs); with movers
+    // into this block also the particle ids of the run (the merge compares them)
+    const uint32_t run0 = __shfl(cs_old, 0), run1 = __shfl(ce_old, 63);
+    const uint32_t runlen = run1 - run0;
+    const bool in_lds = runlen <= (uint32_t)RUNCAP;
+    const bool any_arr = __ballot(head != 0u) != 0ull;
+    if (in_lds) {
+        for (uint32_t t = lane; t < runlen; t += 64) s_in[t] = d.cellid[run0 + t];
+        if (any_arr)
+            for (uint32_t t = lane; t < runlen; t += 64) s_pid[t] = ldpid<D>(in, d.npad, run0 + t);
+    }
+    // ---- neighbour links (replaces the per-thread hash lookups of p2g.wgsl:238-275 / g2p.wgsl:72-132)
     uint32_t res = NONE;
     int b[3] = {0, 0, 0};
-    unpack_key<D>(d.block_key[id], b);
+    unpack_key<D>(bkey, b);
     if (lane < 16) {
         const uint32_t o = lane & 7u;
         const bool minus = lane >= 8;
         if ((int)o < NN) {
-            const int sgn = minus ? -1 : 1;
-            int nb[3] = {b[0] + sgn * (int)(o & 1u), b[1] + sgn * (int)((o >> 1) & 1u), b[2] + sgn * (int)((o >> 2) & 1u)};
-            if (block_in_key_range<D>(nb)) res = hmap_find(d, pack_key<D>(nb), epoch);
+            if (link != NONE) {
+                res = link_stamp == epoch ? link : NONE;
+            } else {  // not linked a substep ago (or no previous substep): it may have become active since
+                const int sgn = minus ? -1 : 1;
+                int nb[3] = {b[0] + sgn * (int)(o & 1u), b[1] + sgn * (int)((o >> 1) & 1u), b[2] + sgn * (int)((o >> 2) & 1u)};
+                if (block_in_key_range<D>(nb)) res = hmap_find(d, pack_key<D>(nb), epoch);
+            }
         }
         (minus ? d.nbr_minus : d.nbr_plus)[id * 8u + o] = res;
     }
-    // ---- stage the new cell ids of the block's previous run (contiguous: cells are consecutive runs)
-    const uint32_t run0 = __shfl(cs_old, 0), run1 = __shfl(ce_old, 63);
-    const uint32_t runlen = run1 - run0;
-    const bool in_lds = runlen <= (uint32_t)RUNCAP;
-    if (in_lds)
-        for (uint32_t t = lane; t < runlen; t += 64) s_in[t] = d.cellid[run0 + t];
+    WGS_PROF(0)
     // (single wave: LDS accesses of a wave execute in order, the relaxed wavefront-scope atomics below keep the
     // compiler from reordering or forwarding across lanes)
     auto new_cell_of = [&](uint32_t i) {
         return in_lds ? __hip_atomic_load(&s_in[i - run0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT) : d.cellid[i];
     };
-    // ---- pass 1: members of the new run = stayers of the previous run + arrivals on the list
+    auto pid_of_old = [&](uint32_t i) {
+        return in_lds ? __hip_atomic_load(&s_pid[i - run0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT) : ldpid<D>(in, d.npad, i);
+    };
+    WGS_PROF(1)
+    // ---- pass 1: members of the new run = stayers of the previous run + arrivals on the list. The first ARRC
+    // arrivals are kept in registers with their ids (next pointer and id of a node are fetched together).
+    constexpr int ARRC = 4;
+    uint32_t a_slot[ARRC], a_pid[ARRC];
+#pragma unroll
+    for (int k = 0; k < ARRC; k++) { a_slot[k] = NONE; a_pid[k] = NONE; }
     uint32_t n_stay = 0, n_arr = 0;
     for (uint32_t i = cs_old; i < ce_old; i++) n_stay += new_cell_of(i) == idx ? 1u : 0u;
-    for (uint32_t a = head; a != 0u; a = d.mv_next[a - 1u]) n_arr++;
+    for (uint32_t a = head; a != 0u;) {
+        const uint32_t nxt = d.mv_next[a - 1u], p = ldpid<D>(in, d.npad, a - 1u);
+#pragma unroll
+        for (int k = 0; k < ARRC; k++)
+            if (n_arr == (uint32_t)k) { a_slot[k] = a - 1u; a_pid[k] = p; }
+        n_arr++;
+        a = nxt;
+    }
+    if (n_arr > 1u && n_arr <= (uint32_t)ARRC) {  // ascending id (empty entries hold NONE = the largest value)
+#pragma unroll
+        for (int pass = 0; pass < ARRC; pass++)
+#pragma unroll
+            for (int k = pass & 1; k + 1 < ARRC; k += 2)
+                if (a_pid[k] > a_pid[k + 1]) {
+                    const uint32_t tp = a_pid[k], ts = a_slot[k];
+                    a_pid[k] = a_pid[k + 1]; a_slot[k] = a_slot[k + 1];
+                    a_pid[k + 1] = tp; a_slot[k + 1] = ts;
+                }
+    }
     const uint32_t total = n_stay + n_arr;
     uint32_t inc = total;
 #pragma unroll
@@ -398,75 +502,10 @@ __device__ __forceinline__ void regroup_block(const Dev &d, int side, uint32_t e
         if (lane >= off) inc += t;
     }
     const uint32_t btotal = __shfl(inc, 63);
-    // ---- the scan's result for this block (first_particle)
-    wait_flag(&d.chunk_done[id / SCAN_CHUNK], epoch);
-    const uint32_t bstart = __hip_atomic_load(&d.block_start[id], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const uint32_t lstart = inc - total;  // start of this cell's run inside the block
-    // ---- pass 2: merge in ascending particle id. Stayers are in id order already; the next arrival is selected
-    // from the (short) list: smallest id above the last one taken.
-    const bool out_lds = btotal <= (uint32_t)RUNCAP;
-    uint32_t out = lstart;
-    auto emit = [&](uint32_t src) {
-        if (out_lds) {
-            __hip_atomic_store(&s_out[out], ((uint32_t)lane << 26) | src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-        } else {
-            d.perm[bstart + out] = src;
-            d.perm_cell[bstart + out] = idx;
-        }
-        out++;
-    };
-    uint32_t arr_slot = NONE, arr_pid = 0;
-    bool have_last = false;
-    uint32_t last_pid = 0;
-    auto next_arrival = [&]() {  // smallest pid on the list that is > last_pid (ids are unique)
-        arr_slot = NONE;
-        for (uint32_t a = head; a != 0u; a = d.mv_next[a - 1u]) {
-            const uint32_t p = ldpid<D>(in, d.npad, a - 1u);
-            if (have_last && p <= last_pid) continue;
-            if (arr_slot == NONE || p < arr_pid) { arr_slot = a - 1u; arr_pid = p; }
-        }
-    };
-    if (n_arr) next_arrival();
-    for (uint32_t i = cs_old; i < ce_old; i++) {
-        if (new_cell_of(i) != idx) continue;
-        if (arr_slot != NONE) {
-            const uint32_t ps = ldpid<D>(in, d.npad, i);
-            while (arr_slot != NONE && arr_pid < ps) {
-                emit(arr_slot);
-                have_last = true;
-                last_pid = arr_pid;
-                next_arrival();
-            }
-        }
-        emit(i);
-    }
-    while (arr_slot != NONE) {
-        emit(arr_slot);
-        have_last = true;
-        last_pid = arr_pid;
-        next_arrival();
-    }
-    if (out_lds)
-        for (uint32_t t = lane; t < btotal; t += 64) {
-            const uint32_t v = __hip_atomic_load(&s_out[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-            d.perm[bstart + t] = v & 0x03ffffffu;
-            d.perm_cell[bstart + t] = id * NPB + (v >> 26);
-        }
-    // ---- new runs, reset of what this substep consumed
-    d.cell_start[idx] = bstart + lstart;
-    d.cell_cursor[idx] = bstart + lstart + total;
-    if (head != 0u) d.cell_head[idx] = 0u;
-    if (d.n_rigid != 0u) {             // mesh-collider cdf accumulators of this substep (k_p2g_cdf)
-        d.mesh_min[idx] = ~0ull;
-        d.mesh_aff[idx] = 0u;
-    }
-    if (lane == 63) {
-        d.block_count[id] = btotal;    // snapshot used by P2G / grid update / G2P
-        d.links_epoch[id] = epoch;     // the neighbour links and cell runs written above are those of this substep
-        d.block_acc[id] = 0;           // (the scan has read it: its chunk is done)
-        d.block_cdf_flag[id] = 0;
-    }
-    if constexpr (CDF) {
+    WGS_PROF(2)
+    // ---- node cdf tile + block class (independent of the scan: placed before the wait for it)
+    if (CDF WGS_ABLATE_AND(!(d.dbg & (1u << 21)))) {
         constexpr int BW = Dim<D>::BW, BS = Dim<D>::BSHIFT, TW = Dim<D>::TW, TILE = Dim<D>::TILE;
         uint32_t mine = 0u;
         // Quick reject, wave-uniform: a collider whose boundary is farther from the tile's centre than the tile's
@@ -511,6 +550,91 @@ __device__ __forceinline__ void regroup_block(const Dev &d, int side, uint32_t e
             if (any && btotal > 0u) d.cpic_list[atomicAdd(&d.counters[CTR_NCPIC], 1u)] = id;  // few blocks
         }
     }
+    WGS_PROF(3)
+    // ---- pass 2: merge in ascending particle id. Stayers are in id order already; the next arrival is selected
+    // from the (short) list: smallest id above the last one taken.
+    const bool out_lds = btotal <= (uint32_t)RUNCAP;
+    // the scan's result for this block (first_particle) is only needed where global memory is written: a block that
+    // fits the LDS stage asks for it after the merge
+    uint32_t bstart = 0, aidx = 0;
+    auto fetch_bstart = [&]() { block_prefix(d, epoch, id, lane, grp, nphys, bstart, aidx); };
+    if (!out_lds) fetch_bstart();
+    uint32_t out = lstart;
+    auto emit = [&](uint32_t src) {
+        if (out_lds) {
+            __hip_atomic_store(&s_out[out], ((uint32_t)lane << 26) | src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+        } else {
+            d.perm[bstart + out] = src;
+            d.perm_cell[bstart + out] = idx;
+        }
+        out++;
+    };
+    uint32_t arr_slot = NONE, arr_pid = 0, arr_k = 0;
+    bool have_last = false;
+    uint32_t last_pid = 0;
+    const bool cached = n_arr <= (uint32_t)ARRC;
+    auto next_arrival = [&]() {
+        arr_slot = NONE;
+        if (cached) {  // k-th entry of the sorted register copy
+#pragma unroll
+            for (int k = 0; k < ARRC; k++)
+                if (arr_k == (uint32_t)k && (uint32_t)k < n_arr) { arr_slot = a_slot[k]; arr_pid = a_pid[k]; }
+            arr_k++;
+            return;
+        }
+        // long list: smallest id on it that is above the last one taken (ids are unique)
+        for (uint32_t a = head; a != 0u; a = d.mv_next[a - 1u]) {
+            const uint32_t p = ldpid<D>(in, d.npad, a - 1u);
+            if (have_last && p <= last_pid) continue;
+            if (arr_slot == NONE || p < arr_pid) { arr_slot = a - 1u; arr_pid = p; }
+        }
+    };
+    if (n_arr) next_arrival();
+    for (uint32_t i = cs_old; i < ce_old; i++) {
+        if (new_cell_of(i) != idx) continue;
+        if (arr_slot != NONE) {
+            const uint32_t ps = pid_of_old(i);
+            while (arr_slot != NONE && arr_pid < ps) {
+                emit(arr_slot);
+                have_last = true;
+                last_pid = arr_pid;
+                next_arrival();
+            }
+        }
+        emit(i);
+    }
+    while (arr_slot != NONE) {
+        emit(arr_slot);
+        have_last = true;
+        last_pid = arr_pid;
+        next_arrival();
+    }
+    WGS_PROF(4)
+    if (out_lds) fetch_bstart();
+    WGS_PROF(5)
+    if (out_lds)
+        for (uint32_t t = lane; t < btotal; t += 64) {
+            const uint32_t v = __hip_atomic_load(&s_out[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+            d.perm[bstart + t] = v & 0x03ffffffu;
+            d.perm_cell[bstart + t] = id * NPB + (v >> 26);
+        }
+    // ---- new runs, reset of what this substep consumed
+    d.cell_start[idx] = bstart + lstart;
+    d.cell_cursor[idx] = bstart + lstart + total;
+    if (head != 0u) d.cell_head[idx] = 0u;
+    if (d.n_rigid != 0u) {             // mesh-collider cdf accumulators of this substep (k_p2g_cdf)
+        d.mesh_min[idx] = ~0ull;
+        d.mesh_aff[idx] = 0u;
+    }
+    if (lane == 63) {
+        d.active[aidx] = id;           // grid.wgsl:323-334: the active list, in physical-id order
+        d.block_start[id] = bstart;    // first_particle
+        d.block_count[id] = btotal;    // snapshot used by P2G / grid update / G2P
+        d.links_epoch[id] = epoch;     // the neighbour links and cell runs written above are those of this substep
+        d.block_cdf_flag[id] = 0;      // (block_acc is cleared by the grid update: the waves of this group read it)
+    }
+    WGS_PROF(6)
+    WGS_PROF_END()
 }
 
 // Launch 2: the first `nscan` workgroups scan, the others regroup (one wave per active block, strided over the
@@ -518,8 +642,9 @@ __device__ __forceinline__ void regroup_block(const Dev &d, int side, uint32_t e
 template <int D, bool CDF> __global__ __launch_bounds__(SORT_THREADS) void k_regroup(Dev d, int side, uint32_t epoch, uint32_t nscan, int have_old) {
     __shared__ unsigned long long s_wave[SORT_THREADS / 64];
     __shared__ unsigned long long s_bcast;
-    __shared__ uint32_t s_in[SORT_THREADS / 64][RUNCAP], s_out[SORT_THREADS / 64][RUNCAP];
+    __shared__ uint32_t s_in[SORT_THREADS / 64][RUNCAP], s_out[SORT_THREADS / 64][RUNCAP], s_pid[SORT_THREADS / 64][RUNCAP];
     if (blockIdx.x < nscan) {
+        __builtin_amdgcn_s_setprio(3);  // every regrouping wave ends up waiting for these few workgroups
         scan_chunk(d, epoch, blockIdx.x, nscan, s_wave, &s_bcast);
         return;
     }
@@ -527,17 +652,31 @@ template <int D, bool CDF> __global__ __launch_bounds__(SORT_THREADS) void k_reg
     const uint32_t wave = ((blockIdx.x - nscan) * SORT_THREADS + threadIdx.x) >> 6;
     const uint32_t nwaves = ((gridDim.x - nscan) * SORT_THREADS) >> 6;
     const int w = threadIdx.x >> 6;
-    for (uint32_t id = wave; id < nphys; id += nwaves) {
-        if (d.block_stamp[id] != epoch) continue;  // wave-uniform
-        regroup_block<D, CDF>(d, side, epoch, id, have_old != 0, s_in[w], s_out[w]);
-    }
+    for (uint32_t id = wave; id < nphys; id += nwaves) regroup_block<D, CDF>(d, side, epoch, id, nphys, have_old != 0, s_in[w], s_out[w], s_pid[w]);
 }
 
-// Test hook (wgs_debug_scan): the scan workgroups alone.
+// Test hook (wgs_debug_scan): the scan workgroups, and workgroups that finish it per block exactly like the
+// regrouping waves do (block_prefix), writing block_start only.
 __global__ __launch_bounds__(SORT_THREADS) void k_scan_only(Dev d, uint32_t epoch, uint32_t nscan) {
     __shared__ unsigned long long s_wave[SORT_THREADS / 64];
     __shared__ unsigned long long s_bcast;
-    scan_chunk(d, epoch, blockIdx.x, nscan, s_wave, &s_bcast);
+    if (blockIdx.x < nscan) {
+        scan_chunk(d, epoch, blockIdx.x, nscan, s_wave, &s_bcast);
+        return;
+    }
+    const uint32_t nphys = min(d.counters[CTR_NPHYS], d.cap);
+    const int lane = threadIdx.x & 63;
+    const uint32_t wave = ((blockIdx.x - nscan) * SORT_THREADS + threadIdx.x) >> 6;
+    const uint32_t nwaves = ((gridDim.x - nscan) * SORT_THREADS) >> 6;
+    for (uint32_t id = wave; id < nphys; id += nwaves) {
+        const GroupLoads g = block_prefix_loads(d, id, lane);
+        uint32_t start = 0, aidx = 0;
+        block_prefix(d, epoch, id, lane, g, nphys, start, aidx);
+        if (lane == 0) {
+            d.block_start[id] = start;
+            d.active[aidx] = id;
+        }
+    }
 }
 
 }  // namespace wgs

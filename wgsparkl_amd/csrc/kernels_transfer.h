@@ -181,6 +181,7 @@ template <int D, int PHASE, bool TWOWAY = false> __global__ __launch_bounds__(25
     for (uint32_t t = blockIdx.x * 256 + threadIdx.x; t < total; t += gridDim.x * 256) {
         const uint32_t b = d.active[t >> 6], ln = t & 63u;
         const uint32_t node = b * NPB + ln;
+        if (ln == 0u) d.block_acc[b] = 0u;  // the sort's per-block accumulator is zero at rest (last read: k_regroup)
         int l[3];
         l[0] = ln & (BW - 1);
         l[1] = (ln >> BS) & (BW - 1);

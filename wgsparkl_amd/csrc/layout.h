@@ -141,8 +141,8 @@ struct Dev {
     uint32_t *cell_head;   // cap*64: head of the cell's list of movers of this substep (slot + 1; zero outside the sort)
     uint32_t *cell_start;  // cap*64
     uint32_t *cell_cursor; // cap*64: end of the cell's range in perm
-    unsigned long long *chunk_total;  // cap / 4096: (active blocks << 32 | particles) of a scan chunk (kernels_sort.h)
-    uint32_t *chunk_flag, *chunk_done; // cap / 4096: epoch at which the chunk's total / its part of the scan was published
+    unsigned long long *chunk_a, *chunk_b;  // cap / 4096: (epoch << 32 | active blocks), (epoch << 32 | particles) of a scan chunk
+    unsigned long long *group_a, *group_b;  // cap / 16: the same two totals before every group of 16 blocks (second level: block_prefix)
     float4 *nodes;         // cap*64: velocity|momentum xyz, mass (2D: vx, vy, mass, 0)
     NodeCdf *node_cdf;     // cap*64
     float4 *slab;          // cap*TILE: per-block tile (block + its "+1" rim): momentum after P2G, velocity after the grid update
