@@ -160,12 +160,12 @@ typedef struct {
 typedef struct {
     uint32_t num_particles;
     uint32_t num_active_blocks;   /* of the last executed substep */
-    uint32_t grid_capacity;       /* rounded up to a power of two like src/grid/grid.rs:283 */
+    uint32_t grid_capacity;       /* rounded up to a power of two like src/grid/grid.rs:283; grows, see wgs_set_grid_growth */
     uint32_t overflow;            /* sticky: WGS_ERR_GRID_OVERFLOW / WGS_ERR_KEY_RANGE seen on device */
     uint64_t substeps_done;
     uint64_t device_bytes;        /* HBM held by this wgs_data */
     uint32_t num_near_collider_blocks; /* particle-bearing blocks whose tile sees a collider (the CPIC passes' list), last substep */
-    uint32_t reserved;
+    uint32_t grid_growths;        /* times the block capacity was doubled (wgs_set_grid_growth) */
 } wgs_stats;
 
 typedef struct wgs_pipeline wgs_pipeline;
@@ -271,6 +271,14 @@ wgs_status wgs_read_timings(wgs_data *data, float ms[WGS_NUM_PASSES]);
  * with K launches between its marks took (time - overhead) of kernel time. */
 wgs_status wgs_read_timing_overhead(wgs_data *data, float *ms_per_mark);
 wgs_status wgs_get_stats(wgs_data *data, wgs_stats *out);
+/* The reference sizes the sparse grid once and has a stub where it should grow it ("TODO: resize the hashmap and
+ * retry", src/grid/grid.rs:43-45,116-117); blocks beyond the capacity are dropped silently
+ * (src/grid/grid.wgsl:126-128). Here, by default, the block capacity DOUBLES whenever a wgs_step / wgs_sharded_step
+ * call finds that the previous call ended with more than half of it active (the check reads counters left in pinned
+ * host memory: no synchronisation; the growth itself drains the stream once). Particle state is untouched: the next
+ * substep rebuilds the table. enabled = 0 restores the fixed capacity; WGS_ERR_GRID_OVERFLOW remains for growth that
+ * outruns the check (more than half a capacity of new blocks inside one call). */
+wgs_status wgs_set_grid_growth(wgs_data *data, int32_t enabled);
 /* TEST HOOK (not part of the drop-in surface): runs the device-side exclusive scan that replaces WgPrefixSum
  * (src/grid/prefix_sum.rs:17-152, prefix_sum.wgsl:11-93) on caller data, so that the reference's own scan test
  * vectors (src/grid/prefix_sum.rs:183-229) can be put through the HIP code: out[i] = sum of values[0..i), *total

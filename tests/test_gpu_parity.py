@@ -216,6 +216,69 @@ def test_grid_overflow_is_reported(hip_libs):
         run_gpu(sc, 1)
 
 
+def _exploding_cube():
+    sc = scenes.neo_hookean_cube(n_side=8)
+    ps = sc["particles"]
+    c = ps.pos.mean(0)
+    ps.vel[:] = ((ps.pos - c) * 25.0).astype(np.float32)       # radial: the cube flies apart
+    ps.lambda_[:] = 1.0                                         # (next to no stiffness: nothing holds it together)
+    ps.mu[:] = 1.0
+    sc["params"] = SimulationParams(gravity=(0.0, 0.0, 0.0), dt=sc["params"].dt)
+    return sc
+
+
+def test_grid_grows_before_it_overflows(hip_libs):
+    """SURVEY 8f4, second half (the reference's resize loop is a stub, src/grid/grid.rs:43-45,116-117): a scene whose
+    active blocks outgrow the capacity it was created with. With growth (the default) the capacity doubles between
+    wgs_step calls and the run is bit-identical to one that had a large capacity from the start; with growth switched
+    off the overflow is reported, as before."""
+    from helpers import pipeline
+    from wgsparkl_amd import MpmData, _ffi
+    pipe = pipeline(3)
+
+    def run(cap, grow, frames=30, per=10):
+        sc = _exploding_cube()
+        data = MpmData.new(pipe, sc["params"], sc["particles"], sc["colliders"], sc["cell_width"], cap, sc["model"])
+        _ffi.check(pipe.lib, pipe.lib.wgs_set_grid_growth(data._h, 1 if grow else 0))
+        for _ in range(frames):
+            pipe.step(data, per)           # asynchronous: the growth check looks at what the PREVIOUS call left behind
+        data.sync()
+        return data
+
+    big = run(4096, True)
+    assert big.stats()["grid_growths"] == 0 and big.stats()["num_active_blocks"] > 64
+    small = run(64, True)
+    st = small.stats()
+    assert st["overflow"] == 0 and st["grid_growths"] >= 1 and st["grid_capacity"] > 64
+    a, b = big.read_particles(), small.read_particles()
+    for f in ("pos", "vel", "def_grad", "affine"):
+        assert np.array_equal(getattr(a, f), getattr(b, f)), f
+    with pytest.raises(_ffi.WgsError):
+        run(64, False)
+
+
+def test_fast_translation_needs_no_more_capacity_than_its_active_blocks(hip_libs):
+    """Physical block ids persist between table rebuilds, so a body that moves fast touches, within the 64-substep
+    rebuild period, many more blocks than are ever active at once. The capacity bounds the ACTIVE blocks (like the
+    reference's, which rebuilds its table every substep): the table is rebuilt early when three quarters of the ids are
+    handed out, instead of reporting an overflow."""
+    from helpers import pipeline
+    from wgsparkl_amd import MpmData, _ffi
+    pipe = pipeline(3)
+    sc = scenes.neo_hookean_cube(n_side=16)
+    sc["particles"].vel[:, 0] = 900.0                               # 0.75 cells per substep
+    sc["params"] = SimulationParams(gravity=(0.0, 0.0, 0.0), dt=sc["params"].dt)
+    data = MpmData.new(pipe, sc["params"], sc["particles"], [], sc["cell_width"], 128, sc["model"])   # 64 active blocks
+    _ffi.check(pipe.lib, pipe.lib.wgs_set_grid_growth(data._h, 0))
+    for _ in range(40):
+        pipe.step(data, 4)
+    data.sync()                                                     # raises on WGS_ERR_GRID_OVERFLOW
+    st = data.stats()
+    assert st["overflow"] == 0 and st["grid_capacity"] == 128 and st["num_active_blocks"] <= 64
+    got = data.read_particles()
+    assert np.allclose(got.vel[:, 0], 900.0, rtol=1e-5) and np.abs(got.def_grad - np.eye(3, dtype=np.float32).reshape(-1)).max() < 1e-4
+
+
 def test_sharded_pipelined_protocol_matches_single_domain(hip_libs):
     """The order bench.py uses for N > 1: wgs_shard_bin_residents before the previous substep's migrants are absorbed
     (the migration messages overlap the re-binning). Same result as the single-domain run, nobody lost."""

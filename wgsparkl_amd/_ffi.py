@@ -28,7 +28,7 @@ EXPORTS = (
     "wgs_shard_pack_migrants", "wgs_shard_add_migrants", "wgs_shard_export",
     # one call per frame on sharded data (RCCL inside the library) + build identification
     "wgs_comm_get_unique_id", "wgs_comm_create", "wgs_comm_destroy", "wgs_shard_attach", "wgs_sharded_step",
-    "wgs_sharded_step_lockstep", "wgs_build_info", "wgs_debug_scan",
+    "wgs_sharded_step_lockstep", "wgs_build_info", "wgs_debug_scan", "wgs_set_grid_growth",
 )
 
 
@@ -101,7 +101,7 @@ def make_types(D: int):
 
     class Stats(C.Structure):
         _fields_ = [("num_particles", u), ("num_active_blocks", u), ("grid_capacity", u), ("overflow", u),
-                    ("substeps_done", C.c_uint64), ("device_bytes", C.c_uint64), ("num_near_collider_blocks", u), ("reserved", u)]
+                    ("substeps_done", C.c_uint64), ("device_bytes", C.c_uint64), ("num_near_collider_blocks", u), ("grid_growths", u)]
 
     ns = dict(SimParams=SimParams, Elastic=Elastic, DruckerPrager=DruckerPrager, PlasticState=PlasticState,
               Phase=Phase, Cdf=Cdf, Dynamics=Dynamics, Particle=Particle, Pose=Pose, Velocity=Velocity,
@@ -180,6 +180,7 @@ def load(dim: int):
     lib.wgs_shard_add_migrants.argtypes = [vp, vp, vp, vp, vp, C.c_uint32]
     lib.wgs_shard_export.argtypes = [vp, vp, C.c_uint32, u32p]
     lib.wgs_build_info.restype = C.c_char_p
+    lib.wgs_set_grid_growth.argtypes = [vp, C.c_int32]
     lib.wgs_debug_scan.argtypes = [vp, u32p, C.c_uint32, u32p, u32p]
     lib.wgs_comm_get_unique_id.argtypes = [C.c_char_p]
     lib.wgs_comm_create.argtypes = [vp, C.c_char_p, C.c_int32, C.c_int32, C.c_int32, C.POINTER(vp)]

@@ -129,6 +129,11 @@ struct wgs_data {
     float timings[WGS_NUM_PASSES] = {0};
     float mark_overhead_ms = 0.f;   // average distance of two adjacent timing marks in the last timestamped step
     bool timings_pending = false;
+    uint32_t *watch = nullptr;          // pinned host copy of the device counters as of the end of the last wgs_step call
+    hipEvent_t watch_event = nullptr;
+    bool watch_pending = false, force_rehash = false, auto_grow = true;
+    uint32_t grid_grown = 0;            // times the block capacity was doubled
+    uint32_t watch_skips = 0;
     ShardLink *link = nullptr;          // wgs_shard_attach
     int reduce_impulses = 0;            // sharded two-way coupling: 1 = ncclAllReduce of the body impulses before
                                         // integrate_bodies, 2 = the caller sums them and integrates (lockstep group)
@@ -161,6 +166,107 @@ wgs_status enable_impulses(wgs_data *d) {
         if (st != WGS_OK) return st;
     }
     d->two_way = true;
+    return WGS_OK;
+}
+
+// Every array sized by the block capacity (dev.cap, dev.hmask set by the caller). All of them are rebuilt by the
+// sort of a table-rebuild substep, so a fresh zeroed set is a valid state (see grow_grid).
+wgs_status alloc_grid(wgs_data *d) {
+    Dev &dev = d->dev;
+    wgs_status st = WGS_OK;
+    const size_t hcap = (size_t)dev.hmask + 1, cap = dev.cap, nchunk = (cap + SCAN_CHUNK - 1) / SCAN_CHUNK;
+#define GRID_ALLOC(ptr, count)                              \
+    if ((st = dev_alloc(d, ptr, (size_t)(count))) != WGS_OK) return st
+    GRID_ALLOC(&dev.hkeys, hcap);
+    GRID_ALLOC(&dev.hvals, hcap);
+    GRID_ALLOC(&dev.block_key, cap);
+    GRID_ALLOC(&dev.block_count, cap);
+    GRID_ALLOC(&dev.block_stamp, cap);
+    GRID_ALLOC(&dev.links_epoch, cap);
+    GRID_ALLOC(&dev.block_acc, cap);
+    GRID_ALLOC(&dev.active, cap);
+    GRID_ALLOC(&dev.block_start, cap);
+    GRID_ALLOC(&dev.nbr_plus, cap * 8);
+    GRID_ALLOC(&dev.nbr_minus, cap * 8);
+    GRID_ALLOC(&dev.cell_head, cap * NPB);
+    GRID_ALLOC(&dev.chunk_a, nchunk);
+    GRID_ALLOC(&dev.chunk_b, nchunk);
+    GRID_ALLOC(&dev.group_a, nchunk * SORT_THREADS);
+    GRID_ALLOC(&dev.group_b, nchunk * SORT_THREADS);
+    GRID_ALLOC(&dev.cell_start, cap * NPB);
+    GRID_ALLOC(&dev.cell_cursor, cap * NPB);
+    GRID_ALLOC(&dev.nodes, cap * NPB);
+    GRID_ALLOC(&dev.node_cdf, cap * NPB);
+    GRID_ALLOC(&dev.slab, cap * Dim<D>::TILE);
+    GRID_ALLOC(&dev.block_cdf_flag, cap);
+    GRID_ALLOC(&dev.block_cpic, cap);
+    GRID_ALLOC(&dev.cpic_list, cap);
+    if (d->two_way) GRID_ALLOC(&dev.imp_slab, cap * Dim<D>::TILE * (D == 3 ? 2 : 1));
+    if (dev.mesh_min) {
+        GRID_ALLOC(&dev.mesh_min, cap * NPB);
+        GRID_ALLOC(&dev.mesh_aff, cap * NPB);
+    }
+#undef GRID_ALLOC
+    return WGS_OK;
+}
+
+void release_alloc(wgs_data *d, void *p) {
+    if (!p) return;
+    for (size_t i = 0; i < d->allocs.size(); i++)
+        if (d->allocs[i] == p) {
+            d->device_bytes -= d->alloc_bytes[i];
+            d->allocs.erase(d->allocs.begin() + (long)i);
+            d->alloc_bytes.erase(d->alloc_bytes.begin() + (long)i);
+            break;
+        }
+    hipFree(p);
+}
+
+// SURVEY 8f4, second half — the reference's resize loop is a stub (src/grid/grid.rs:43-45,116-117: "TODO: resize the
+// hashmap and retry"). Here the block capacity doubles BEFORE the table fills: a new zeroed set of grid arrays replaces
+// the old one and the next substep rebuilds the table from the particles (the same full pass every 64th substep runs).
+// Particle state is untouched, so nothing is lost; the stream is drained once (rare).
+wgs_status grow_grid(wgs_data *d, uint32_t new_cap) {
+    Dev &dev = d->dev;
+    HIP_TRY(hipStreamSynchronize(d->stream));
+    void *old[] = {dev.hkeys, dev.hvals, dev.block_key, dev.block_count, dev.block_stamp, dev.links_epoch, dev.block_acc, dev.active,
+                   dev.block_start, dev.nbr_plus, dev.nbr_minus, dev.cell_head, dev.chunk_a, dev.chunk_b, dev.group_a, dev.group_b,
+                   dev.cell_start, dev.cell_cursor, dev.nodes, dev.node_cdf, dev.slab, dev.block_cdf_flag, dev.block_cpic, dev.cpic_list,
+                   dev.imp_slab, dev.mesh_min, dev.mesh_aff};
+    for (void *p : old) release_alloc(d, p);
+    dev.imp_slab = nullptr;  // (alloc_grid re-creates what was in use: two_way / mesh_min say so)
+    const bool had_mesh = dev.mesh_min != nullptr;
+    dev.cap = new_cap;
+    dev.hmask = new_cap * 2u - 1u;
+    if (!had_mesh) dev.mesh_min = nullptr;
+    wgs_status st = alloc_grid(d);
+    if (st != WGS_OK) return st;
+    HIP_TRY(hipMemsetAsync(dev.hkeys, 0xff, sizeof(uint32_t) * ((size_t)dev.hmask + 1), d->stream));
+    HIP_TRY(hipMemsetAsync(dev.hvals, 0xff, sizeof(uint32_t) * ((size_t)dev.hmask + 1), d->stream));
+    HIP_TRY(hipMemsetAsync(dev.counters + CTR_NPHYS, 0, sizeof(uint32_t), d->stream));
+    d->prev_sorted = false;      // block ids start over: the next substep bins every particle through the hash map
+    d->last_ncpic = UINT32_MAX;
+    d->grid_grown++;
+    return WGS_OK;
+}
+
+// Looks at the counters the LAST wgs_step call left in pinned host memory (no synchronisation: skipped while that copy
+// is still in flight) and keeps the table comfortable: more than half of the capacity active -> double it; more than
+// three quarters of the ids handed out (blocks that were active at some point since the last rebuild) -> rebuild at
+// the next substep instead of waiting for the 64-substep period.
+wgs_status maintain_grid(wgs_data *d) {
+    if (!d->watch || !d->watch_pending) return WGS_OK;
+    if (hipEventQuery(d->watch_event) != hipSuccess) {
+        // the host runs ahead of the device: let it, for two calls; then wait for the copy (a bounded run-ahead keeps
+        // the observation fresh enough to act before the table fills)
+        if (++d->watch_skips < 2u) return WGS_OK;
+        HIP_TRY(hipEventSynchronize(d->watch_event));
+    }
+    d->watch_skips = 0;
+    d->watch_pending = false;
+    const uint32_t nblocks = d->watch[CTR_NBLOCKS], nphys = d->watch[CTR_NPHYS], cap = d->dev.cap;
+    if (d->auto_grow && nblocks > cap / 2u && cap < (1u << 24)) return grow_grid(d, cap * 2u);
+    if (nphys > cap / 4u * 3u) d->force_rehash = true;
     return WGS_OK;
 }
 
@@ -404,6 +510,18 @@ __global__ void k_export_blocks(Dev d, uint32_t nblocks, wgs_block_record *out) 
 wgs_status flush_append(wgs_data *d);
 wgs_status allreduce_impulses(wgs_data *d);  // capi_sharded.inc
 
+// leaves a copy of the device counters in pinned host memory for the next call's maintain_grid (asynchronous)
+wgs_status watch_counters(wgs_data *d) {
+    if (!d->watch) {
+        HIP_TRY(hipHostMalloc((void **)&d->watch, sizeof(uint32_t) * CTR_COUNT, hipHostMallocDefault));
+        HIP_TRY(hipEventCreateWithFlags(&d->watch_event, hipEventDisableTiming));
+    }
+    HIP_TRY(hipMemcpyAsync(d->watch, d->dev.counters, sizeof(uint32_t) * CTR_COUNT, hipMemcpyDeviceToHost, d->stream));
+    HIP_TRY(hipEventRecord(d->watch_event, d->stream));
+    d->watch_pending = true;
+    return WGS_OK;
+}
+
 wgs_status fetch_counters(wgs_data *d) {
     {
         wgs_status fst = flush_append(d);  // sharded: a recorded but not yet executed migrant append
@@ -416,6 +534,7 @@ wgs_status fetch_counters(wgs_data *d) {
     d->last_ncpic = host[CTR_NCPIC] < d->dev.cap ? host[CTR_NCPIC] : d->dev.cap;
     d->sticky_errors |= host[CTR_ERRORS];
     if (host[CTR_NBLOCKS] > d->dev.cap) d->sticky_errors |= ERRBIT_OVERFLOW;
+    if (host[CTR_NPHYS] > d->dev.cap / 4u * 3u) d->force_rehash = true;
     return WGS_OK;
 }
 
@@ -472,15 +591,21 @@ template <bool TS> wgs_status enqueue_substep(wgs_data *d, int ts_slot, int part
     const int side = d->side;
     const uint32_t n = dev.n;
     const int pgrid = (int)((n + SORT_THREADS - 1) / SORT_THREADS);
+    static const bool trace = getenv("WGS_TRACE") != nullptr;   // developer aid: drain the stream at every pass boundary and say so
     auto mark = [&](int m) {
         if (TS) hipEventRecord(d->events.ev[ts_slot][m], s);
+        if (trace) {
+            const hipError_t te = hipStreamSynchronize(s);
+            fprintf(stderr, "[wgs trace] substep %llu part %d mark %d: %s\n", (unsigned long long)d->substeps, part, m, hipGetErrorString(te));
+        }
     };
     const uint32_t epoch = (uint32_t)(d->substeps + 1);
     // Steady state: the buffer is in the sorted order of the previous substep, whose block ids, cell ids
     // (perm_cell) and neighbour links are still valid, so the particles are re-binned RELATIVE to their old
     // block (k_rebin: no hash lookups except for the few particles that changed block). The full k_bin runs
     // on the first substep, on table-rebuild substeps and in sharded runs (particles arrive from neighbours).
-    const bool rehash = d->substeps % REHASH_PERIOD == 0;
+    const bool rehash = d->substeps % REHASH_PERIOD == 0 || (d->force_rehash && part != 2 && part != 3);
+    if (rehash && part != 2 && part != 3) d->force_rehash = false;
     const bool fused_cdf = d->cpic && dev.n_rigid == 0 && !(dev.dbg & 1024u);  // (mesh cdfs are only complete after k_p2g_cdf)
     // (sharded data stepped with wgs_step: nobody arrived since the last substep, the residents are all there is)
     const bool use_rebin = d->prev_sorted && !rehash && !(dev.dbg & 128u) && (!dev.sharded || d->tail_known || part == 3 || part == 0);
@@ -744,8 +869,7 @@ static wgs_status create_impl(wgs_pipeline *pipeline, const wgs_sim_params *para
     dev.npad = (((uint32_t)particle_capacity + 63u) / 64u) * 64u;
     if (dev.npad == 0) dev.npad = 64;
     dev.cap = next_pow2(grid_capacity);  // grid.rs:283
-    const uint32_t hcap = dev.cap * 2u;  // half-full table (reference: exactly cap slots, quirk B4)
-    dev.hmask = hcap - 1u;
+    dev.hmask = dev.cap * 2u - 1u;  // half-full table (reference: exactly cap slots, quirk B4)
     dev.h = cell_width;
     dev.inv_h = 1.0f / cell_width;
     {
@@ -778,30 +902,8 @@ static wgs_status create_impl(wgs_pipeline *pipeline, const wgs_sim_params *para
     TRY_ALLOC(&dev.perm_cell, (size_t)dev.npad);
     TRY_ALLOC(&dev.cellid, (size_t)dev.npad);
     TRY_ALLOC(&dev.mv_next, (size_t)dev.npad);
-    TRY_ALLOC(&dev.hkeys, (size_t)hcap);
-    TRY_ALLOC(&dev.hvals, (size_t)hcap);
-    TRY_ALLOC(&dev.block_key, (size_t)dev.cap);
-    TRY_ALLOC(&dev.block_count, (size_t)dev.cap);
-    TRY_ALLOC(&dev.block_stamp, (size_t)dev.cap);
-    TRY_ALLOC(&dev.links_epoch, (size_t)dev.cap);
-    TRY_ALLOC(&dev.block_acc, (size_t)dev.cap);
-    TRY_ALLOC(&dev.active, (size_t)dev.cap);
-    TRY_ALLOC(&dev.block_start, (size_t)dev.cap);
-    TRY_ALLOC(&dev.nbr_plus, (size_t)dev.cap * 8);
-    TRY_ALLOC(&dev.nbr_minus, (size_t)dev.cap * 8);
-    TRY_ALLOC(&dev.cell_head, (size_t)dev.cap * NPB);
-    TRY_ALLOC(&dev.chunk_a, (size_t)(dev.cap + SCAN_CHUNK - 1) / SCAN_CHUNK);
-    TRY_ALLOC(&dev.chunk_b, (size_t)(dev.cap + SCAN_CHUNK - 1) / SCAN_CHUNK);
-    TRY_ALLOC(&dev.group_a, (size_t)((dev.cap + SCAN_CHUNK - 1) / SCAN_CHUNK) * SORT_THREADS);
-    TRY_ALLOC(&dev.group_b, (size_t)((dev.cap + SCAN_CHUNK - 1) / SCAN_CHUNK) * SORT_THREADS);
-    TRY_ALLOC(&dev.cell_start, (size_t)dev.cap * NPB);
-    TRY_ALLOC(&dev.cell_cursor, (size_t)dev.cap * NPB);
-    TRY_ALLOC(&dev.nodes, (size_t)dev.cap * NPB);
-    TRY_ALLOC(&dev.node_cdf, (size_t)dev.cap * NPB);
-    TRY_ALLOC(&dev.slab, (size_t)dev.cap * Dim<D>::TILE);
-    TRY_ALLOC(&dev.block_cdf_flag, (size_t)dev.cap);
-    TRY_ALLOC(&dev.block_cpic, (size_t)dev.cap);
-    TRY_ALLOC(&dev.cpic_list, (size_t)dev.cap);
+    st = alloc_grid(d);
+    if (st != WGS_OK) return bail(st);
     TRY_ALLOC(&dev.counters, (size_t)CTR_COUNT);
     TRY_ALLOC(&d->sp, (size_t)1);
     TRY_ALLOC(&d->colliders, (size_t)WGS_MAX_COLLIDERS);
@@ -1094,8 +1196,16 @@ void wgs_data_destroy(wgs_data *d) {
             for (int m = 0; m < Events::MARKS; m++) hipEventDestroy(d->events.ev[s][m]);
     for (void *p : d->allocs) hipFree(p);
     if (d->stream && d->owns_stream) hipStreamDestroy(d->stream);
+    if (d->watch) hipHostFree(d->watch);
+    if (d->watch_event) hipEventDestroy(d->watch_event);
     delete d->link;
     delete d;
+}
+
+wgs_status wgs_set_grid_growth(wgs_data *d, int32_t enabled) {
+    if (!d) return fail(WGS_ERR_INVALID_ARGUMENT, "data is NULL");
+    d->auto_grow = enabled != 0;
+    return WGS_OK;
 }
 
 wgs_status wgs_set_constitutive_model(wgs_data *d, int32_t model) {
@@ -1116,6 +1226,10 @@ wgs_status wgs_step(wgs_pipeline *pipeline, wgs_data *d, uint32_t num_substeps, 
         }
         d->events.used = 0;
     }
+    {
+        wgs_status mst = maintain_grid(d);
+        if (mst != WGS_OK) return mst;
+    }
     for (uint32_t i = 0; i < num_substeps; i++) {
         wgs_status st;
         if (timestamps && d->events.used < Events::MAX_SUBSTEPS) {
@@ -1127,7 +1241,7 @@ wgs_status wgs_step(wgs_pipeline *pipeline, wgs_data *d, uint32_t num_substeps, 
         if (st != WGS_OK) return st;
     }
     if (timestamps) d->timings_pending = true;
-    return WGS_OK;
+    return watch_counters(d);
 }
 
 wgs_status wgs_sync(wgs_data *d) {
@@ -1557,7 +1671,7 @@ wgs_status wgs_get_stats(wgs_data *d, wgs_stats *out) {
     out->substeps_done = d->substeps;
     out->device_bytes = d->device_bytes;
     out->num_near_collider_blocks = d->cpic && d->last_ncpic != UINT32_MAX ? d->last_ncpic : 0u;
-    out->reserved = 0u;
+    out->grid_growths = d->grid_grown;
     return WGS_OK;
 }
 

@@ -571,7 +571,7 @@ __device__ __forceinline__ void regroup_block(const Dev &d, int side, uint32_t e
     };
     uint32_t arr_slot = NONE, arr_pid = 0, arr_k = 0;
     bool have_last = false;
-    uint32_t last_pid = 0;
+    uint32_t last_pid = 0, last_slot = 0;
     const bool cached = n_arr <= (uint32_t)ARRC;
     auto next_arrival = [&]() {
         arr_slot = NONE;
@@ -582,11 +582,19 @@ __device__ __forceinline__ void regroup_block(const Dev &d, int side, uint32_t e
             arr_k++;
             return;
         }
-        // long list: smallest id on it that is above the last one taken (ids are unique)
+        // long list: smallest (id, slot) on it that is above the last one taken. Ids are unique in a healthy run; after
+        // a reported grid overflow the buffer can hold the same particle twice, and the merge must still place every
+        // list node exactly once (slots are unique).
+        unsigned long long best = ~0ull;
+        const unsigned long long last_key = ((unsigned long long)last_pid << 32) | last_slot;
         for (uint32_t a = head; a != 0u; a = d.mv_next[a - 1u]) {
-            const uint32_t p = ldpid<D>(in, d.npad, a - 1u);
-            if (have_last && p <= last_pid) continue;
-            if (arr_slot == NONE || p < arr_pid) { arr_slot = a - 1u; arr_pid = p; }
+            const unsigned long long key = ((unsigned long long)ldpid<D>(in, d.npad, a - 1u) << 32) | (a - 1u);
+            if (have_last && key <= last_key) continue;
+            if (key < best) best = key;
+        }
+        if (best != ~0ull) {
+            arr_slot = (uint32_t)best;
+            arr_pid = (uint32_t)(best >> 32);
         }
     };
     if (n_arr) next_arrival();
@@ -598,6 +606,7 @@ __device__ __forceinline__ void regroup_block(const Dev &d, int side, uint32_t e
                 emit(arr_slot);
                 have_last = true;
                 last_pid = arr_pid;
+                last_slot = arr_slot;
                 next_arrival();
             }
         }
@@ -607,6 +616,7 @@ __device__ __forceinline__ void regroup_block(const Dev &d, int side, uint32_t e
         emit(arr_slot);
         have_last = true;
         last_pid = arr_pid;
+        last_slot = arr_slot;
         next_arrival();
     }
     WGS_PROF(4)
