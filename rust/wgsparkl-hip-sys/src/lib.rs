@@ -4,7 +4,7 @@
 //! `MpmPipeline` / `MpmData` surface.
 //! build.rs: println!("cargo:rustc-link-lib=dylib=wgsparkl3d_hip");   (feature dim3; wgsparkl2d_hip for dim2)
 #![allow(non_camel_case_types)]
-use std::os::raw::c_char;
+use std::os::raw::{c_char, c_void};
 
 pub const DIM: usize = if cfg!(feature = "dim2") { 2 } else { 3 };
 pub type wgs_status = i32;
@@ -128,8 +128,15 @@ pub struct wgs_stats {
     pub substeps_done: u64,
     pub device_bytes: u64,
     pub num_near_collider_blocks: u32,
-    pub reserved: u32,
+    pub grid_growths: u32,
 }
+
+#[repr(C)]
+pub struct wgs_comm {
+    _private: [u8; 0],
+}
+pub const WGS_COMM_ID_BYTES: usize = 128;
+pub const WGS_COMM_SELF_NEIGHBOURS: i32 = 1;
 
 extern "C" {
     pub fn wgs_last_error() -> *const c_char;
@@ -166,6 +173,48 @@ extern "C" {
     ) -> wgs_status;
     pub fn wgs_read_timings(d: *mut wgs_data, ms: *mut f32) -> wgs_status;
     pub fn wgs_get_stats(d: *mut wgs_data, out: *mut wgs_stats) -> wgs_status;
-    // sharded (multi-GPU) entry points: include/wgsparkl_hip.h "Multi-GPU" section; driven from
-    // wgsparkl_amd/sharded.py in this repository.
+    pub fn wgs_read_timing_overhead(d: *mut wgs_data, ms_per_mark: *mut f32) -> wgs_status;
+    pub fn wgs_build_info() -> *const c_char;
+    pub fn wgs_set_grid_growth(d: *mut wgs_data, enabled: i32) -> wgs_status;
+    /// test hook: the device scan on caller data (prefix_sum.rs:183-229 vectors)
+    pub fn wgs_debug_scan(p: *mut wgs_pipeline, values: *const u32, n: u32, out: *mut u32, total: *mut u32) -> wgs_status;
+
+    // ---- multi-GPU (x-slab decomposition): include/wgsparkl_hip.h "Multi-GPU" sections ----
+    pub fn wgs_data_create_sharded(
+        p: *mut wgs_pipeline, params: *const wgs_sim_params, particles: *const wgs_particle, n: usize, global_ids: *const u32,
+        colliders: *const wgs_collider, nc: usize, cell_width: f32, grid_capacity: u32, particle_capacity: u32, block_lo: i32,
+        block_hi: i32, force_plastic: i32, out: *mut *mut wgs_data,
+    ) -> wgs_status;
+    pub fn wgs_shard_halo_record_bytes() -> u32;
+    pub fn wgs_shard_particle_record_bytes() -> u32;
+    pub fn wgs_shard_buffer_header_bytes() -> u32;
+    pub fn wgs_set_stream(d: *mut wgs_data, hip_stream: *mut c_void) -> wgs_status;
+    // one call per frame: the whole substep protocol inside the library, RCCL point-to-point as transport
+    pub fn wgs_comm_get_unique_id(id: *mut u8) -> wgs_status; // WGS_COMM_ID_BYTES = 128
+    pub fn wgs_comm_create(
+        p: *mut wgs_pipeline, id: *const u8, rank: i32, world: i32, flags: i32, out: *mut *mut wgs_comm,
+    ) -> wgs_status;
+    pub fn wgs_comm_destroy(c: *mut wgs_comm);
+    pub fn wgs_shard_attach(
+        d: *mut wgs_data, comm: *mut wgs_comm, has_lower: i32, has_upper: i32, halo_capacity_blocks: u32, migrant_capacity: u32,
+    ) -> wgs_status;
+    pub fn wgs_sharded_step(p: *mut wgs_pipeline, d: *mut wgs_data, num_substeps: u32) -> wgs_status;
+    pub fn wgs_sharded_step_lockstep(p: *mut wgs_pipeline, slabs: *mut *mut wgs_data, num_slabs: u32, num_substeps: u32) -> wgs_status;
+    // the per-phase view of the same protocol (a host that brings its own transport)
+    pub fn wgs_shard_register_buffers(
+        d: *mut wgs_data, halo_out_lo: *mut c_void, halo_out_hi: *mut c_void, mig_out_lo: *mut c_void, mig_out_hi: *mut c_void,
+    ) -> wgs_status;
+    pub fn wgs_shard_bin_residents(p: *mut wgs_pipeline, d: *mut wgs_data) -> wgs_status;
+    pub fn wgs_shard_step_begin(p: *mut wgs_pipeline, d: *mut wgs_data) -> wgs_status;
+    pub fn wgs_shard_pack_halos(d: *mut wgs_data, buf_lo: *mut c_void, buf_hi: *mut c_void, capacity_records: u32) -> wgs_status;
+    pub fn wgs_shard_add_halos(d: *mut wgs_data, in_lo: *const c_void, in_hi: *const c_void, capacity_records: u32) -> wgs_status;
+    pub fn wgs_shard_pack_halo(d: *mut wgs_data, layer_bx: i32, device_buf: *mut c_void, capacity_records: u32) -> wgs_status;
+    pub fn wgs_shard_add_halo(d: *mut wgs_data, device_buf: *const c_void, capacity_records: u32) -> wgs_status;
+    pub fn wgs_shard_step_end(p: *mut wgs_pipeline, d: *mut wgs_data) -> wgs_status;
+    pub fn wgs_shard_pack_migrants(d: *mut wgs_data, dev_lo: *mut c_void, dev_hi: *mut c_void, capacity_records: u32) -> wgs_status;
+    pub fn wgs_shard_add_migrants(
+        d: *mut wgs_data, in_lo: *const c_void, in_hi: *const c_void, out_lo: *const c_void, out_hi: *const c_void,
+        capacity_records: u32,
+    ) -> wgs_status;
+    pub fn wgs_shard_export(d: *mut wgs_data, device_buf: *mut c_void, capacity_records: u32, count: *mut u32) -> wgs_status;
 }

@@ -110,3 +110,13 @@ def test_product_never_imports_the_oracle():
                 if re.search(r"(from|import)\s+oracle\b|oracle/|mpm_oracle|liborc", txt):
                     bad.append(os.path.join(base, f))
     assert not bad, bad
+
+
+def test_rust_binding_declares_every_header_symbol():
+    """rust/wgsparkl-hip-sys/src/lib.rs cannot be compiled here (no cargo / rustc in the image), so at least its
+    declarations are kept in step with the header: every function of include/wgsparkl_hip.h appears in the extern block."""
+    rs = open(os.path.join(ROOT, "rust", "wgsparkl-hip-sys", "src", "lib.rs")).read()
+    declared_rs = set(re.findall(r"pub fn (wgs_[a-z_]+)\(", rs))
+    assert set(DECLARED) <= declared_rs, sorted(set(DECLARED) - declared_rs)
+    assert declared_rs <= set(DECLARED), sorted(declared_rs - set(DECLARED))
+    assert "grid_growths" in rs and "WGS_COMM_ID_BYTES" in rs
