@@ -2,13 +2,13 @@
 committed under profiles/: per-kernel rocprofv3 --stats table, PMC byte counters per launch with the
 gfx950 FETCH_SIZE correction of MI355X_MICROARCH.md (x2 for 16-B-per-lane streams), the bench line."""
 import csv, glob, json, os, sys, collections
-R = sys.argv[1] if len(sys.argv) > 1 else "r01"
+R = sys.argv[1] if len(sys.argv) > 1 else "r02"
 src = f"gpurun_out/{R}"
 os.makedirs("profiles", exist_ok=True)
 st = sorted(glob.glob(f"{src}/stats/**/*_kernel_stats.csv", recursive=True), key=os.path.getmtime)[-1]
 rows = list(csv.DictReader(open(st)))
 with open(f"profiles/{R}_kernel_stats.csv", "w") as f:
-    f.write("# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 100 --warmup 10 --no-cpu-baseline (MI355X)\n")
+    f.write("# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 100 --warmup 10 --no-cpu-baseline --no-extra (MI355X)\n")
     w = csv.writer(f); w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs"])
     for r in rows: w.writerow([r["Name"], r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["Percentage"], r["MinNs"], r["MaxNs"]])
 pmc = collections.defaultdict(dict)

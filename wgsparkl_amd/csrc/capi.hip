@@ -1630,6 +1630,13 @@ wgs_status wgs_debug_scan(wgs_pipeline *pipeline, const uint32_t *values, uint32
 }
 
 #ifdef WGS_ABLATE
+wgs_status wgs_debug_p2g_prof(unsigned long long *out /* WGS_P2G_ROWS * 8 */) {
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_p2g_prof), sizeof(unsigned long long) * WGS_P2G_ROWS * 8));
+    std::vector<unsigned long long> zero((size_t)WGS_P2G_ROWS * 8, 0ull);
+    HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_p2g_prof), zero.data(), sizeof(unsigned long long) * WGS_P2G_ROWS * 8));
+    return WGS_OK;
+}
 // stage clocks of launch 2 (kernels_sort.h g_prof): read and reset. Experiment builds only, not in the header.
 wgs_status wgs_debug_prof(unsigned long long *out /* WGS_PROF_ROWS * 8 */) {
     HIP_TRY(hipDeviceSynchronize());

@@ -24,6 +24,14 @@ namespace wgs {
 // [rank][cell] so that the 64 lanes of a wave read 64 consecutive float4 (conflict-free
 // ds_read_b128) while the global side reads whole 64-byte runs of the cell-sorted arrays.
 constexpr int P2G_J = 4;
+#ifdef WGS_ABLATE
+// stage clocks of P2G (timing experiments, tools/gpu_p2g_prof.py): one row per active-list index of the plain body
+constexpr int WGS_P2G_ROWS = 8192;
+__device__ unsigned long long g_p2g_prof[WGS_P2G_ROWS][8];
+#define P2G_PROF(k) if (threadIdx.x == 0 && filter != 2 && a < WGS_P2G_ROWS) g_p2g_prof[a][k] = wall_clock64();
+#else
+#define P2G_PROF(k)
+#endif
 template <int D> struct P2GCfg;
 template <> struct P2GCfg<3> {
     static constexpr int NW = 3;        // waves per workgroup = sz values
