@@ -22,10 +22,10 @@ PART_TOL = 2e-5        # relative RMS of particle x, v, F, C' vs the fp64 oracle
 CPIC_GRID_V_TOL = 5e-5
 CPIC_PART_TOL = 5e-5
 # fuzz scenes (random colliders of every kind, some dynamic, 12 substeps, against the fp32 oracle)
-FUZZ_NODE_MISMATCH = 0.005
-FUZZ_PART_MISMATCH = 0.01
-FUZZ_VEL_TOL = 2e-3
-FUZZ_BODY_ATOL = 2e-3
+FUZZ_NODE_MISMATCH = 0.001     # measured: 0 in all 32 fuzz cases (profiles/r02_parity_margins.json)
+FUZZ_PART_MISMATCH = 0.002     # measured: 0
+FUZZ_VEL_TOL = 1e-4            # measured worst: 2.5e-5 (12 substeps of fp32 round-off growth through contact)
+FUZZ_BODY_ATOL = 1e-4          # measured worst: 9.3e-6 (fixed-point impulses: 1e-5 resolution)
 
 
 def cloud_scene(n=20000, dim=3, model=MODEL_COROTATED, seed=7, **kw):
@@ -696,8 +696,10 @@ def test_random_api_sequences_match_oracle(hip_libs, oracle_libs, seed):
     data.sync()
     got = data.read_particles()
     same = got.cdf_affinity == st.arr["cdf_affinity"]
-    assert same.mean() > 0.98
-    assert rel_rms(got.pos[same], st.arr["pos"][same]) < 5e-5
+    report_margin("api sequence affinity mismatch fraction", 1.0 - float(same.mean()), 0.005)
+    report_margin("api sequence pos rel rms", rel_rms(got.pos[same], st.arr["pos"][same]), 2e-5)
+    assert same.mean() > 0.995
+    assert rel_rms(got.pos[same], st.arr["pos"][same]) < 2e-5
 
 
 def test_rccl_exchange_selftest(hip_libs):
@@ -953,7 +955,7 @@ def test_dynamic_bodies_on_sharded_data(hip_libs, name):
     ids = np.concatenate([o["ids"] for o in outs])
     assert np.array_equal(np.sort(ids), np.arange(sc["particles"].n, dtype=np.uint32))
     order = np.argsort(ids)
-    for f, tol in (("pos", 1e-5), ("vel", 2e-3)):
+    for f, tol in (("pos", 1e-5), ("vel", 5e-5)):
         got = np.concatenate([o[f] for o in outs])[order]
         err = rel_rms(got, getattr(ref_p, f))
         report_margin(f"sharded two-way {f}", err, tol)
@@ -1146,9 +1148,11 @@ def test_set_sim_params_and_colliders(hip_libs, oracle_libs):
     data.sync()
     got = data.read_particles()
     same = got.cdf_affinity == st.arr["cdf_affinity"]
-    assert same.mean() > 0.99
+    report_margin("setters affinity mismatch fraction", 1.0 - float(same.mean()), 0.005)
+    report_margin("setters vel rel rms", rel_rms(got.vel[same], st.arr["vel"][same]), 1e-4)
+    assert same.mean() > 0.995
     assert rel_rms(got.pos[same], st.arr["pos"][same]) < 1e-5
-    assert rel_rms(got.vel[same], st.arr["vel"][same]) < 2e-3
+    assert rel_rms(got.vel[same], st.arr["vel"][same]) < 1e-4
 
 
 # ---------------------------------------------------------------------------------------------

@@ -33,11 +33,12 @@ namespace wgs {
 constexpr int SORT_THREADS = 256;
 constexpr int TOUCH_SET = 32;  // distinct blocks a workgroup can de-duplicate in LDS
 
-template <int D> __device__ inline void load_cell(const float *in, uint32_t npad, uint32_t i, float h, int *cell) {
-    const float4 xm = ldq(in, npad, Pl<D>::XM, i);
-    cell[0] = assoc_cell(xm.x, h);
-    cell[1] = assoc_cell(xm.y, h);
-    if constexpr (D == 3) cell[2] = assoc_cell(xm.z, h);
+template <int D> __device__ inline void load_cell(const Dev &d, const float *in, uint32_t i, int *cell) {
+    const float4 xm = ldq(in, d.npad, Pl<D>::XM, i);
+    const bool p2 = d.h_pow2 != 0u;  // x * (1 / h) is then x / h bit for bit, without the IEEE division sequence
+    cell[0] = assoc_cell(xm.x, d.h, d.inv_h, p2);
+    cell[1] = assoc_cell(xm.y, d.h, d.inv_h, p2);
+    if constexpr (D == 3) cell[2] = assoc_cell(xm.z, d.h, d.inv_h, p2);
 }
 
 // sort.wgsl:129-137 (per-cell linked list), for movers only: slot i becomes the head of its destination
@@ -106,7 +107,7 @@ template <int D, int TAIL> __global__ __launch_bounds__(SORT_THREADS) void k_bin
     uint32_t key = NONE, local = 0;
     if (valid) {
         int c[D];
-        load_cell<D>(in, d.npad, i, d.h, c);
+        load_cell<D>(d, in, i, c);
         uint32_t shift = 0;
 #pragma unroll
         for (int k = 0; k < D; k++) {
@@ -200,7 +201,7 @@ template <int D> __global__ __launch_bounds__(SORT_THREADS) void k_rebin(Dev d, 
         const uint32_t ob = old >> 6;
         const uint32_t okey = old != NONE ? d.block_key[ob] : 0u;
         int c[D], nb[3] = {0, 0, 0};
-        load_cell<D>(in, d.npad, i, d.h, c);
+        load_cell<D>(d, in, i, c);
         uint32_t shift = 0;
 #pragma unroll
         for (int k = 0; k < D; k++) {
