@@ -116,7 +116,10 @@ class Leg:
         args = (pipe, scene["params"], ps, scene["global_ids"], scene["colliders"], scene["cell_width"], scene["grid_capacity"], lo, hi,
                 rank > 0, rank < world - 1)
         if env["native"]:
-            self.data = NativeShard(*args, comm=env["comm"], **kw)
+            from wgsparkl_amd.sharded import uniform_material_of
+            # every rank generates particles of the same single material (scenes.py): the constants become kernel
+            # arguments on sharded data too, like wgs_data_create decides by itself for a single domain
+            self.data = NativeShard(*args, comm=env["comm"], uniform_material=uniform_material_of(ps), **kw)
             self.parallelism = f"{world} x-slabs, halo + migration over RCCL send/recv inside wgs_sharded_step"
         else:
             self.data = GpuShard(*args, **kw)

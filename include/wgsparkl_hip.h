@@ -271,6 +271,13 @@ wgs_status wgs_read_timings(wgs_data *data, float ms[WGS_NUM_PASSES]);
  * with K launches between its marks took (time - overhead) of kernel time. */
 wgs_status wgs_read_timing_overhead(wgs_data *data, float *ms_per_mark);
 wgs_status wgs_get_stats(wgs_data *data, wgs_stats *out);
+/* Per-material constants are per-PARTICLE data in the reference (GpuModels, src/models/mod.rs:12-50; init_volume and
+ * mass in ParticleDynamics), re-read by every pass. When every particle of a simulation has the same (mass,
+ * init_volume, lambda, mu) the step keeps them as kernel arguments instead (32 bytes per particle and substep less
+ * through HBM; results are bit-identical). wgs_data_create detects this by itself; on SHARDED data a rank only sees
+ * its own particles, so the caller asserts it — on every rank, before the first step — with this call. 3D only
+ * (a no-op in the 2D library). */
+wgs_status wgs_set_uniform_material(wgs_data *data, float mass, float init_volume, float lambda, float mu);
 /* The reference sizes the sparse grid once and has a stub where it should grow it ("TODO: resize the hashmap and
  * retry", src/grid/grid.rs:43-45,116-117); blocks beyond the capacity are dropped silently
  * (src/grid/grid.wgsl:126-128). Here, by default, the block capacity DOUBLES whenever a wgs_step / wgs_sharded_step

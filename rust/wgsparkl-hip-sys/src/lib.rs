@@ -176,6 +176,7 @@ extern "C" {
     pub fn wgs_read_timing_overhead(d: *mut wgs_data, ms_per_mark: *mut f32) -> wgs_status;
     pub fn wgs_build_info() -> *const c_char;
     pub fn wgs_set_grid_growth(d: *mut wgs_data, enabled: i32) -> wgs_status;
+    pub fn wgs_set_uniform_material(d: *mut wgs_data, mass: f32, init_volume: f32, lambda: f32, mu: f32) -> wgs_status;
     /// test hook: the device scan on caller data (prefix_sum.rs:183-229 vectors)
     pub fn wgs_debug_scan(p: *mut wgs_pipeline, values: *const u32, n: u32, out: *mut u32, total: *mut u32) -> wgs_status;
 

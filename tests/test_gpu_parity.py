@@ -216,6 +216,28 @@ def test_grid_overflow_is_reported(hip_libs):
         run_gpu(sc, 1)
 
 
+def test_uniform_material_mode_is_bit_identical(hip_libs, monkeypatch):
+    """One material for all particles: the four per-particle constants (mass, V0, lambda, mu) become kernel arguments
+    and F[8] rides in their place (layout.h, Dev::uniform) — 32 bytes per particle and substep less through HBM. Same
+    arithmetic on the same values: bit-identical to the general layout (WGS_DEBUG = 65536 keeps that one), incl. the
+    CPIC passes and Drucker-Prager, and the read-back shows the caller's constants."""
+    for make in (lambda: scenes.neo_hookean_cube(n_side=20, with_floor=True), lambda: scenes.sand_column(nx=12, ny=20, nz=12, with_floor=True)):
+        def run():
+            sc = make()
+            sc["particles"].pos[:, 1] -= 5.6
+            sc["particles"].vel[:, 1] = -2.0
+            data = run_gpu(sc, 30)
+            return sc, data.read_particles(), data.read_grid()
+        sc, a, ga = run()
+        monkeypatch.setenv("WGS_DEBUG", "65536")
+        _, b, gb = run()
+        monkeypatch.delenv("WGS_DEBUG")
+        for f in ("pos", "vel", "def_grad", "affine", "mass", "init_volume", "lambda_", "mu", "cdf_affinity", "dp_state"):
+            assert np.array_equal(getattr(a, f), getattr(b, f)), f
+        assert np.array_equal(a.mass, sc["particles"].mass) and np.array_equal(a.mu, sc["particles"].mu)
+        assert np.array_equal(ga[0], gb[0]) and np.array_equal(ga[1], gb[1])
+
+
 def _exploding_cube():
     sc = scenes.neo_hookean_cube(n_side=8)
     ps = sc["particles"]
@@ -911,14 +933,15 @@ def test_checkpoint_restart_is_bit_exact(hip_libs):
 
 def _native_slabs(sc, world, pipe, **kw):
     """The scene cut into `world` x-slabs balanced by particle count, each a NativeShard of a lockstep group."""
-    from wgsparkl_amd.sharded import NativeShard, SlabPartition, associated_block_x, split_scene
+    from wgsparkl_amd.sharded import NativeShard, SlabPartition, associated_block_x, split_scene, uniform_material_of
     ps = sc["particles"]
     part = SlabPartition.balanced(associated_block_x(ps.pos, sc["cell_width"], ps.dim), world)
     shards = []
     for r, (sub, gids) in enumerate(split_scene(ps, part, sc["cell_width"])):
         lo, hi = part.block_range(r)
         shards.append(NativeShard(pipe, sc["params"], sub, gids, sc["colliders"], sc["cell_width"], sc["grid_capacity"],
-                                  lo, hi, r > 0, r < world - 1, particle_capacity=ps.n, model=sc["model"], **kw))
+                                  lo, hi, r > 0, r < world - 1, particle_capacity=ps.n, model=sc["model"],
+                                  uniform_material=uniform_material_of(ps), **kw))
     return shards, part
 
 

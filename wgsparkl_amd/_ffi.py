@@ -28,7 +28,7 @@ EXPORTS = (
     "wgs_shard_pack_migrants", "wgs_shard_add_migrants", "wgs_shard_export",
     # one call per frame on sharded data (RCCL inside the library) + build identification
     "wgs_comm_get_unique_id", "wgs_comm_create", "wgs_comm_destroy", "wgs_shard_attach", "wgs_sharded_step",
-    "wgs_sharded_step_lockstep", "wgs_build_info", "wgs_debug_scan", "wgs_set_grid_growth",
+    "wgs_sharded_step_lockstep", "wgs_build_info", "wgs_debug_scan", "wgs_set_grid_growth", "wgs_set_uniform_material",
 )
 
 
@@ -181,6 +181,7 @@ def load(dim: int):
     lib.wgs_shard_export.argtypes = [vp, vp, C.c_uint32, u32p]
     lib.wgs_build_info.restype = C.c_char_p
     lib.wgs_set_grid_growth.argtypes = [vp, C.c_int32]
+    lib.wgs_set_uniform_material.argtypes = [vp, C.c_float, C.c_float, C.c_float, C.c_float]
     lib.wgs_debug_scan.argtypes = [vp, u32p, C.c_uint32, u32p, u32p]
     lib.wgs_comm_get_unique_id.argtypes = [C.c_char_p]
     lib.wgs_comm_create.argtypes = [vp, C.c_char_p, C.c_int32, C.c_int32, C.c_int32, C.POINTER(vp)]

@@ -287,7 +287,7 @@ void fill_collider(ColliderDev &c, const wgs_collider &in) {
     for (int k = 0; k < 3; k++) c.com[k] = in.com[k];
 }
 
-constexpr uint32_t WGS_LAUNCH_SHAPE_SWITCHES = 128u | 1024u | 4096u | 8192u | 16384u | 32768u;  // WGS_DEBUG bits the shipped library honours
+constexpr uint32_t WGS_LAUNCH_SHAPE_SWITCHES = 128u | 1024u | 4096u | 8192u | 16384u | 32768u | 65536u;  // WGS_DEBUG bits the shipped library honours
 constexpr uint32_t P2G_SMALL_BUDGET_MIN_PARTICLES = 600000;  // one-way CPIC P2G body at 168 VGPRs from this size on
 constexpr uint32_t P2G_PAIR_MIN_BLOCKS = 8;  // near-collider blocks from which P2G runs both bodies in one launch
 int grid_for(const wgs_data *d, int blocks_per_cu) { return d->pipeline->num_cus * blocks_per_cu; }
@@ -316,7 +316,7 @@ template <int DIM> __device__ inline void unpack_slot(const float *in, uint32_t 
         const float4 xm = ldq(in, npad, P::XM, j), c0 = ldq(in, npad, P::CV0, j), c1 = ldq(in, npad, P::CV1, j),
                      c2 = ldq(in, npad, P::CV2, j), f0 = ldq(in, npad, P::F0, j), f1 = ldq(in, npad, P::F1, j),
                      f2 = ldq(in, npad, P::F2, j);
-        u.x[0] = xm.x; u.x[1] = xm.y; u.x[D - 1] = xm.z; u.mass = xm.w;
+        u.x[0] = xm.x; u.x[1] = xm.y; u.x[D - 1] = xm.z; u.mass = xm.w;  // (uniform-material mode: fixed up by the caller)
         u.C[0] = c0.x; u.C[1] = c0.y; u.C[2] = c0.z; u.C[3] = c0.w;
         u.C[m9(4)] = c1.x; u.C[m9(5)] = c1.y; u.C[m9(6)] = c1.z; u.C[m9(7)] = c1.w; u.C[m9(8)] = c2.x;
         u.v[0] = c2.y; u.v[1] = c2.z; u.v[D - 1] = c2.w;
@@ -347,6 +347,28 @@ template <int DIM> __device__ inline void unpack_slot(const float *in, uint32_t 
     }
 }
 
+// uniform-material mode (layout.h): XM.w holds F[8], the four constants are kernel arguments
+template <int DIM> __device__ inline void fix_uniform(const Dev &d, Unpacked &u) {
+    if constexpr (DIM == 3) {
+        if (d.uniform) {
+            u.F[m9(8)] = u.mass;
+            u.mass = d.uni_mass; u.vol = d.uni_vol; u.lam = d.uni_lambda; u.mu = d.uni_mu;
+        }
+    }
+}
+
+// general layout -> uniform-material layout: F[8] takes the place of the mass in XM.w
+__global__ void k_to_uniform(Dev d, int side) {
+    if constexpr (D == 3) {
+        float *buf = d.buf[side];
+        for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < d.n; j += gridDim.x * blockDim.x) {
+            float4 xm = ldq(buf, d.npad, Pl<3>::XM, j);
+            xm.w = ldq(buf, d.npad, Pl<3>::F2, j).x;
+            stq(buf, d.npad, Pl<3>::XM, j, xm);
+        }
+    }
+}
+
 __global__ void k_export_particles(Dev d, int side, ParticleOffsets o, bool plastic, bool cpic, uint32_t cdf_epoch, const float *s_radius,
                                    const float *s_dp, const float *s_phase, const uint32_t *s_flags, float *out,
                                    float *plastic_out) {
@@ -356,6 +378,7 @@ __global__ void k_export_particles(Dev d, int side, ParticleOffsets o, bool plas
         const uint32_t pid = ldpid<D>(in, npad, j);
         Unpacked u;
         unpack_slot<D>(in, npad, j, plastic, cpic, cdf_epoch, u);
+        fix_uniform<D>(d, u);
         float *r = out + (size_t)pid * o.stride;
         for (int k = 0; k < D; k++) {
             r[o.pos + k] = u.x[k];
@@ -413,6 +436,7 @@ __global__ void k_prep_instances(Dev d, int side, uint32_t mode, bool cpic, uint
         const uint32_t pid = ldpid<D>(in, npad, j);
         Unpacked u;
         unpack_slot<D>(in, npad, j, false, cpic, cdf_epoch, u);
+        fix_uniform<D>(d, u);
         float *r = inst + (size_t)pid * 24;
         // deformation: mat3x3 as three padded columns (instancing3d.rs:66-74); 2D embeds F in the xy block
         float m[9] = {1.f, 0.f, 0.f, 0.f, 1.f, 0.f, 0.f, 0.f, 1.f};
@@ -880,7 +904,8 @@ static wgs_status create_impl(wgs_pipeline *pipeline, const wgs_sim_params *para
     // Developer switches (read once, here; 0 in production): A/B of launch shapes, SAME results — 128 = full k_bin on
     // every substep (no k_rebin), 1024 = node cdf in a launch of its own (k_cdf) instead of k_setup_scatter<CDF>,
     // 4096 = the two G2P bodies as two launches, 8192 = the two P2G bodies always as two launches, 16384 = never the
-    // spill-free variant of the plastic G2P pair, 32768 = never the small register budget of the one-way P2G pair.
+    // spill-free variant of the plastic G2P pair, 32768 = never the small register budget of the one-way P2G pair,
+    // 65536 = never the uniform-material mode (the per-particle constants always travel with the particle).
     // The ablations that change the RESULTS (64 = G2P moves bytes only, 256 = P2G without its accumulation loop,
     // 512 = P2G without its particle loads) exist only in builds with -DWGS_ABLATE; the shipped library ignores them.
     dev.dbg = getenv("WGS_DEBUG") ? (uint32_t)strtoul(getenv("WGS_DEBUG"), nullptr, 0) : 0u;
@@ -976,6 +1001,13 @@ static wgs_status create_impl(wgs_pipeline *pipeline, const wgs_sim_params *para
         if ((phase == 0.0f && dp[4] != 0.0f) || (phase > 0.0f && max_stretch > 0.0f && max_stretch < FLT_MAX)) plastic = true;
     }
     d->plastic = plastic || force_plastic != 0;
+    // one material for all particles (bitwise)? -> uniform-material mode (layout.h). Sharded data: the caller says so
+    // (wgs_set_uniform_material), a rank cannot know the other ranks' particles.
+    bool uniform = D == 3 && n > 0 && !sharded && !(dev.dbg & 65536u);
+    for (uint32_t i = 1; i < n && uniform; i++)
+        uniform = memcmp(&particles[i].dynamics.mass, &particles[0].dynamics.mass, 4) == 0 &&
+                  memcmp(&particles[i].dynamics.init_volume, &particles[0].dynamics.init_volume, 4) == 0 &&
+                  memcmp(&particles[i].model, &particles[0].model, sizeof(wgs_elastic_coefficients)) == 0;
 #define H2D(dst, src, bytes)                                                               \
     if (hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, d->stream) != hipSuccess)   \
         return bail(fail(WGS_ERR_HIP, "hipMemcpy H2D failed"));
@@ -1007,6 +1039,14 @@ static wgs_status create_impl(wgs_pipeline *pipeline, const wgs_sim_params *para
         hipLaunchKernelGGL(k_bodies_refresh<D>, dim3(1), dim3(16), 0, d->stream, dev, 0xffffu);
     if (d->bodies_move && enable_impulses(d) != WGS_OK) return bail(fail(WGS_ERR_HIP, "out of device memory for the impulse accumulators"));
 #undef H2D
+    if (uniform) {
+        dev.uniform = 1u;
+        dev.uni_mass = particles[0].dynamics.mass;
+        dev.uni_vol = particles[0].dynamics.init_volume;
+        dev.uni_lambda = particles[0].model.lambda;
+        dev.uni_mu = particles[0].model.mu;
+        hipLaunchKernelGGL(k_to_uniform, dim3(grid_for(d, 4)), dim3(256), 0, d->stream, dev, 0);
+    }
     if (hipStreamSynchronize(d->stream) != hipSuccess) return bail(fail(WGS_ERR_HIP, "initial upload failed"));
     *out = d;
     return WGS_OK;
@@ -1200,6 +1240,22 @@ void wgs_data_destroy(wgs_data *d) {
     if (d->watch_event) hipEventDestroy(d->watch_event);
     delete d->link;
     delete d;
+}
+
+wgs_status wgs_set_uniform_material(wgs_data *d, float mass, float init_volume, float lambda, float mu) {
+    if (!d) return fail(WGS_ERR_INVALID_ARGUMENT, "data is NULL");
+    if (D != 3) return WGS_OK;  // the 2D layout has no separate constants quad: nothing to gain
+    if (d->substeps != 0) return fail(WGS_ERR_INVALID_ARGUMENT, "wgs_set_uniform_material: call before the first step");
+    if (d->dev.uniform) return WGS_OK;
+    HIP_TRY(hipSetDevice(d->pipeline->device));
+    d->dev.uniform = 1u;
+    d->dev.uni_mass = mass;
+    d->dev.uni_vol = init_volume;
+    d->dev.uni_lambda = lambda;
+    d->dev.uni_mu = mu;
+    if (d->dev.n) hipLaunchKernelGGL(k_to_uniform, dim3(grid_for(d, 4)), dim3(256), 0, d->stream, d->dev, d->side);
+    HIP_TRY(hipGetLastError());
+    return WGS_OK;
 }
 
 wgs_status wgs_set_grid_growth(wgs_data *d, int32_t enabled) {

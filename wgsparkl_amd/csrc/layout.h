@@ -41,13 +41,13 @@ template <> struct Dim<2> {
 //   fused G2P+update reads XM + F* + pid, writes everything.
 template <int D> struct Pl;
 template <> struct Pl<3> {
-    static constexpr int XM = 0;    // x, y, z, mass
+    static constexpr int XM = 0;    // x, y, z, mass   (uniform-material mode: x, y, z, F[8] — see Dev::uniform)
     static constexpr int CV0 = 1;   // C'[0..3]           (APIC matrix, column-major; particle3d.wgsl:12)
     static constexpr int CV1 = 2;   // C'[4..7]
     static constexpr int CV2 = 3;   // C'[8], vx, vy, vz
     static constexpr int F0 = 4;    // F[0..3]
     static constexpr int F1 = 5;    // F[4..7]
-    static constexpr int F2 = 6;    // F[8], init_volume, lambda, mu
+    static constexpr int F2 = 6;    // F[8], init_volume, lambda, mu   (uniform-material mode: not touched by the step)
     static constexpr int NBASE = 7;
     static constexpr int DP0 = 7;   // h0, h1, h2, h3                    (models/drucker_prager.wgsl:8-16)
     static constexpr int DP1 = 8;   // dp.lambda, dp.mu, plastic det, plastic hardening
@@ -169,6 +169,13 @@ struct Dev {
     float h;             // cell width
     float inv_h;
     uint32_t h_pow2;     // cell width is a power of two: x * inv_h == x / h bit for bit
+    // Uniform-material mode (3D): every particle has the same (mass, init_volume, lambda, mu), so the four constants
+    // travel as kernel arguments instead of being read and re-written with every particle in every substep (the sort
+    // is physical): F[8] takes the place of the mass in XM.w and the F2 quad drops out of the step — the fused kernel
+    // moves 160 instead of 192 bytes per particle. Decided at creation (all particles equal) or by the caller
+    // (wgs_set_uniform_material); the general layout remains for everything else.
+    uint32_t uniform;
+    float uni_mass, uni_vol, uni_lambda, uni_mu;
     int model;           // WGS_MODEL_*
     uint32_t dbg;        // launch-shape A/B switches (env WGS_DEBUG; same results, see capi.hip), 0 in production. The
                          // result-changing ablations only exist in builds with -DWGS_ABLATE (never the shipped library)

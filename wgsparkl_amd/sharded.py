@@ -596,10 +596,14 @@ class NativeShard:
     def __init__(self, pipeline: MpmPipeline, params: SimulationParams, particles: ParticleSet, global_ids: np.ndarray,
                  colliders, cell_width: float, grid_capacity: int, block_lo: int, block_hi: int, has_lower: bool,
                  has_upper: bool, particle_capacity: int, model: int = MODEL_COROTATED, force_plastic: bool = False,
-                 halo_capacity_blocks: int = 4096, migrant_capacity: int = 4096, comm: Optional[NativeComm] = None):
+                 halo_capacity_blocks: int = 4096, migrant_capacity: int = 4096, comm: Optional[NativeComm] = None,
+                 uniform_material=None):
+        """`uniform_material` = (mass, init_volume, lambda, mu) shared by EVERY particle of EVERY rank (the caller's
+        promise: a rank only sees its own), or None: the constants then travel with each particle."""
         self.pipeline, self.lib, self.T = pipeline, pipeline.lib, pipeline.T
         T, D = self.T, pipeline.dim
         self.dim = D
+        self.uniform_material = uniform_material
         self.n_colliders = len(colliders)
         sp = T.SimParams()
         sp.gravity = (C.c_float * D)(*params.gravity)
@@ -619,6 +623,8 @@ class NativeShard:
         self.capacity = cap
         if model != MODEL_COROTATED:
             _ffi.check(self.lib, self.lib.wgs_set_constitutive_model(self._h, int(model)))
+        if uniform_material is not None:
+            _ffi.check(self.lib, self.lib.wgs_set_uniform_material(self._h, *[float(x) for x in uniform_material]))
         if any(any(c.inv_mass) or any(c.inv_inertia_local) for c in colliders):   # dynamic bodies: two-way coupling
             arr = (T.MassProperties * len(colliders))()
             for i, c in enumerate(colliders):
@@ -663,7 +669,7 @@ class NativeShard:
         cnt = C.c_uint32(0)
         _ffi.check(self.lib, self.lib.wgs_shard_export(self._h, C.c_void_p(buf.data_ptr()), self.capacity, C.byref(cnt)))
         rec = buf[self.hdr: self.hdr + cnt.value * self.part_rec].cpu().numpy().reshape(cnt.value, self.part_rec)
-        return unpack_records(rec, self.dim)
+        return unpack_records(rec, self.dim, self.uniform_material if self.dim == 3 else None)
 
     def close(self):
         if getattr(self, "_h", None):
@@ -683,8 +689,19 @@ def native_lockstep(pipeline: MpmPipeline, shards: List[NativeShard], num_subste
     _ffi.check(pipeline.lib, pipeline.lib.wgs_sharded_step_lockstep(pipeline._h, arr, len(shards), int(num_substeps)))
 
 
-def unpack_records(rec: np.ndarray, dim: int):
-    """Particle records (quad layout of csrc/layout.h) -> dict of arrays."""
+def uniform_material_of(particles: ParticleSet):
+    """(mass, init_volume, lambda, mu) if all particles of the set share them bitwise, else None."""
+    if particles.n == 0:
+        return None
+    cols = (particles.mass, particles.init_volume, particles.lambda_, particles.mu)
+    if all(bool(np.all(c.view(np.uint32) == c.view(np.uint32)[0])) for c in cols):
+        return tuple(float(c[0]) for c in cols)
+    return None
+
+
+def unpack_records(rec: np.ndarray, dim: int, uniform_material=None):
+    """Particle records (quad layout of csrc/layout.h) -> dict of arrays. In uniform-material mode (3D) the record's
+    XM.w slot holds F[8] and the mass is the shared one."""
     ids = rec[:, -2].copy().view(np.uint32)     # [..quads.., pid, cdf epoch]
     if dim == 3:
         q = lambda k: rec[:, 4 * k:4 * k + 4]
@@ -692,6 +709,9 @@ def unpack_records(rec: np.ndarray, dim: int):
         C_ = np.concatenate([q(1), q(2), q(3)[:, :1]], 1)
         vel = q(3)[:, 1:4]
         F = np.concatenate([q(4), q(5), q(6)[:, :1]], 1)
+        if uniform_material is not None:
+            F = np.concatenate([q(4), q(5), q(0)[:, 3:4]], 1)
+            mass = np.full(len(rec), np.float32(uniform_material[0]), np.float32)
     else:
         q = lambda k: rec[:, 4 * k:4 * k + 4]
         pos, mass = q(0)[:, :2], q(0)[:, 2]
