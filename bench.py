@@ -204,6 +204,9 @@ def main():
         print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch with --nproc-per-node {args.gpus}", file=sys.stderr)
         sys.exit(2)
     dbg_env = os.environ.get("WGS_DEBUG")
+    if os.environ.get("WGS_REHASH_PERIOD") and not args.allow_debug_switches:
+        print("bench.py: WGS_REHASH_PERIOD is set (developer override); unset it or pass --allow-debug-switches", file=sys.stderr)
+        sys.exit(2)
     if dbg_env not in (None, "", "0") and not args.allow_debug_switches:
         print(f"bench.py: WGS_DEBUG={dbg_env} is set (developer launch-shape switches); unset it or pass --allow-debug-switches", file=sys.stderr)
         sys.exit(2)
@@ -304,8 +307,8 @@ def main():
             "roofline": rl,
             "pass_ms_per_step": main_res["pass_ms_per_step"],
             "build": {"info": build_info, "WGS_DEBUG": dbg_env, "transport_note": transport_note},
-            "notes": "the every-64-substeps hash-table rebuild (k_bin instead of k_rebin, +0.06-0.26 ms once) falls inside the timed region "
-                     "whenever warmup + steps cross a multiple of 64; amortised ~1 us per substep",
+            "notes": "the hash table of block ids is rebuilt (k_bin instead of k_rebin, ~+0.25 ms once at this size) on the first substep, every "
+                     "1024 substeps and whenever three quarters of the ids are handed out; none of these falls inside this timed region",
         }
 
     # ---- CPU baseline + validation of the HIP path on the bench data itself (rank 0, N = 1)

@@ -301,7 +301,7 @@ def test_fast_translation_needs_no_more_capacity_than_its_active_blocks(hip_libs
     assert np.allclose(got.vel[:, 0], 900.0, rtol=1e-5) and np.abs(got.def_grad - np.eye(3, dtype=np.float32).reshape(-1)).max() < 1e-4
 
 
-def test_sharded_pipelined_protocol_matches_single_domain(hip_libs):
+def test_sharded_pipelined_protocol_matches_single_domain(hip_libs, monkeypatch):
     """The order bench.py uses for N > 1: wgs_shard_bin_residents before the previous substep's migrants are absorbed
     (the migration messages overlap the re-binning). Same result as the single-domain run, nobody lost."""
     from helpers import pipeline
@@ -312,7 +312,8 @@ def test_sharded_pipelined_protocol_matches_single_domain(hip_libs):
     rng = np.random.default_rng(8)
     ps.vel[:] = rng.normal(0.0, 3.0, ps.vel.shape).astype(np.float32)
     ps.vel[:, 0] += 8.0
-    k, world = 80, 3                                           # crosses a table rebuild (64 substeps)
+    monkeypatch.setenv("WGS_REHASH_PERIOD", "64")             # (developer override, same results; the default is 1024)
+    k, world = 80, 3                                           # crosses a table rebuild
     ref = run_gpu(sc, k).read_particles()
     part = SlabPartition.balanced(associated_block_x(ps.pos, sc["cell_width"], 3), world)
     pipe = pipeline(3)
@@ -522,6 +523,7 @@ def test_steady_state_rebinning_is_bit_identical_to_full_binning(hip_libs, seed,
     across two table rebuilds — must end bit-identical."""
     sc = _random_scene(seed)
     k = 150
+    monkeypatch.setenv("WGS_REHASH_PERIOD", "64")             # (developer override, same results; the default is 1024)
     a = run_gpu(sc, k).read_particles()
     monkeypatch.setenv("WGS_DEBUG", "128")
     b = run_gpu(sc, k).read_particles()
@@ -986,11 +988,12 @@ def test_dynamic_bodies_on_sharded_data(hip_libs, name):
 
 
 @pytest.mark.parametrize("world,dim", [(2, 3), (3, 3), (4, 3), (2, 2)])
-def test_native_lockstep_matches_single_domain(hip_libs, world, dim):
+def test_native_lockstep_matches_single_domain(hip_libs, world, dim, monkeypatch):
     """wgs_sharded_step_lockstep — the C++ driver of the substep protocol that wgs_sharded_step runs per rank over
     RCCL — reproduces the single-domain run (80 substeps: crosses a table rebuild; particles migrate)."""
     from helpers import pipeline
     from wgsparkl_amd.sharded import associated_block_x, native_lockstep
+    monkeypatch.setenv("WGS_REHASH_PERIOD", "64")             # table rebuilds inside the run (developer override, same results)
     sc = scenes.neo_hookean_cube(n_side=28) if dim == 3 else scenes.elastic_block_2d(nx=60, ny=40, with_floor=False)
     ps = sc["particles"]
     rng = np.random.default_rng(8)

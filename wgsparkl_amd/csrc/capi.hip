@@ -134,6 +134,7 @@ struct wgs_data {
     bool watch_pending = false, force_rehash = false, auto_grow = true;
     uint32_t grid_grown = 0;            // times the block capacity was doubled
     uint32_t watch_skips = 0;
+    uint32_t rehash_period = REHASH_PERIOD;  // substeps between unconditional table rebuilds (developer override: WGS_REHASH_PERIOD)
     ShardLink *link = nullptr;          // wgs_shard_attach
     int reduce_impulses = 0;            // sharded two-way coupling: 1 = ncclAllReduce of the body impulses before
                                         // integrate_bodies, 2 = the caller sums them and integrates (lockstep group)
@@ -628,7 +629,7 @@ template <bool TS> wgs_status enqueue_substep(wgs_data *d, int ts_slot, int part
     // (perm_cell) and neighbour links are still valid, so the particles are re-binned RELATIVE to their old
     // block (k_rebin: no hash lookups except for the few particles that changed block). The full k_bin runs
     // on the first substep, on table-rebuild substeps and in sharded runs (particles arrive from neighbours).
-    const bool rehash = d->substeps % REHASH_PERIOD == 0 || (d->force_rehash && part != 2 && part != 3);
+    const bool rehash = d->substeps % d->rehash_period == 0 || (d->force_rehash && part != 2 && part != 3);
     if (rehash && part != 2 && part != 3) d->force_rehash = false;
     const bool fused_cdf = d->cpic && dev.n_rigid == 0 && !(dev.dbg & 1024u);  // (mesh cdfs are only complete after k_p2g_cdf)
     // (sharded data stepped with wgs_step: nobody arrived since the last substep, the residents are all there is)
@@ -909,6 +910,7 @@ static wgs_status create_impl(wgs_pipeline *pipeline, const wgs_sim_params *para
     // The ablations that change the RESULTS (64 = G2P moves bytes only, 256 = P2G without its accumulation loop,
     // 512 = P2G without its particle loads) exist only in builds with -DWGS_ABLATE; the shipped library ignores them.
     dev.dbg = getenv("WGS_DEBUG") ? (uint32_t)strtoul(getenv("WGS_DEBUG"), nullptr, 0) : 0u;
+    if (getenv("WGS_REHASH_PERIOD")) d->rehash_period = std::max(1u, (uint32_t)strtoul(getenv("WGS_REHASH_PERIOD"), nullptr, 0));  // same results
 #ifndef WGS_ABLATE
     dev.dbg &= WGS_LAUNCH_SHAPE_SWITCHES;
 #endif
@@ -1288,6 +1290,9 @@ wgs_status wgs_step(wgs_pipeline *pipeline, wgs_data *d, uint32_t num_substeps, 
     }
     for (uint32_t i = 0; i < num_substeps; i++) {
         wgs_status st;
+        if (i > 0 && i % 64u == 0u) {  // long calls: keep an eye on the table inside the call too (bounded run-ahead)
+            if ((st = watch_counters(d)) != WGS_OK || (st = maintain_grid(d)) != WGS_OK) return st;
+        }
         if (timestamps && d->events.used < Events::MAX_SUBSTEPS) {
             st = enqueue_substep<true>(d, d->events.used, 0);
             d->events.used++;

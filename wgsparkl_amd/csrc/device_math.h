@@ -61,7 +61,9 @@ __device__ inline int assoc_cell(float x, float h, float inv_h, bool h_pow2) {
 // atomics (memory-side on MI355X, ~1-2 us each and bandwidth-limited on a small table)
 // are only issued for blocks never seen before. The table is cleared every REHASH_PERIOD
 // substeps to drop blocks that stopped being active.
-constexpr uint32_t REHASH_PERIOD = 64;
+// (long: a rebuild substep costs ~2 ordinary ones; the host also triggers one as soon as three quarters of the ids are
+// handed out, capi.hip maintain_grid, which is what bounds the table in practice)
+constexpr uint32_t REHASH_PERIOD = 1024;
 constexpr uint32_t ID_OVERFLOW = 0xfffffffeu;
 
 // grid/grid.wgsl:167-184 find_block_header_id (active blocks only)
