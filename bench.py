@@ -199,6 +199,19 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(env_world or "1")
+    # stdout carries ONE line, the JSON of rank 0: everything else any library prints there (the RCCL version banner,
+    # gloo's connection messages, ...) is sent to stderr by pointing file descriptor 1 at it until that line is due
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
+    def emit(obj):
+        sys.stdout.flush()
+        try:
+            C.CDLL(None).fflush(None)      # C stdio buffers of the libraries
+        except Exception:
+            pass
+        os.write(json_fd, (json.dumps(obj) + "\n").encode())
     force_sharded = os.environ.get("WGS_BENCH_FORCE_SHARDED") == "1"
     if world != args.gpus and not force_sharded:
         print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch with --nproc-per-node {args.gpus}", file=sys.stderr)
@@ -336,7 +349,7 @@ def main():
         chk.close()
         del st, got, chk
         if not val["ok"]:
-            print(json.dumps(out))
+            emit(out)
             print("bench.py: the HIP path disagrees with the oracle on the bench data", file=sys.stderr)
             sys.exit(3)
 
@@ -367,7 +380,7 @@ def main():
         del sc
 
     if rank == 0:
-        print(json.dumps(out))
+        emit(out)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
