@@ -941,6 +941,10 @@ static wgs_status create_impl(wgs_pipeline *pipeline, const wgs_sim_params *para
     TRY_ALLOC(&d->static_phase, (size_t)dev.npad * 2);
     TRY_ALLOC(&d->static_flags, (size_t)dev.npad);
     TRY_ALLOC(&d->shard_counts, (size_t)4);
+    if (sharded) {
+        dev.leavers_cap = std::max<uint32_t>(4096u, (uint32_t)(particle_capacity / 16));
+        TRY_ALLOC(&dev.leavers, (size_t)dev.leavers_cap);
+    }
 #undef TRY_ALLOC
     dev.sp = d->sp;
     dev.colliders = d->colliders;

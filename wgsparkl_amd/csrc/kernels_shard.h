@@ -139,7 +139,12 @@ template <int D> __global__ __launch_bounds__(256) void k_pack_migrants(Dev d, i
         d.counters[CTR_N] = n;
         d.counters[CTR_NPREV] = n;  // residents of the next substep (arrivals are appended behind)
     }
-    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+    // mode 0: the fused G2P launch listed the slots of the particles that left the slab (Dev::leavers); mode 1 (read-back):
+    // every slot
+    const uint32_t nl = mode == 0 ? min(d.counters[CTR_NLEAVE], d.leavers_cap) : n;
+    for (uint32_t t = blockIdx.x * 256 + threadIdx.x; t < nl; t += gridDim.x * 256) {
+        const uint32_t i = mode == 0 ? d.leavers[t] : t;
+        if (i >= n) continue;
         const uint32_t pid = ldpid<D>(buf, npad, i);
         if (pid == PID_DEAD) continue;
         int face = -1;
@@ -147,7 +152,7 @@ template <int D> __global__ __launch_bounds__(256) void k_pack_migrants(Dev d, i
             face = 0;
         } else {
             const float4 xm = ldq(buf, npad, Pl<D>::XM, i);
-            const int bx = assoc_cell(xm.x, d.h) >> BS;
+            const int bx = assoc_cell(xm.x, d.h, d.inv_h, d.h_pow2 != 0u) >> BS;
             if (bx < d.shard_lo) face = 0;
             else if (bx >= d.shard_hi) face = 1;
         }

@@ -178,6 +178,7 @@ template <int D, int PHASE, bool TWOWAY = false> __global__ __launch_bounds__(25
     const float dt = d.sp->dt;
     const float lim = d.h / dt;
     float g[3] = {d.sp->gravity[0], d.sp->gravity[1], d.sp->gravity[2]};
+    if (d.sharded && PHASE != 1 && blockIdx.x == 0 && threadIdx.x == 0) d.counters[CTR_NLEAVE] = 0;  // list of the coming G2P launch
     // Two-way coupling: the node impulses are summed per body in LDS first (integers: any order gives the same sum) and
     // leave the workgroup as at most 16 x 6 global atomics. One atomic per node and component instead serialises at the
     // memory side: 40 k of them on a dozen addresses took 290 us in a scene whose cube rests on the floor.

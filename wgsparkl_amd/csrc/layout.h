@@ -105,6 +105,7 @@ struct NodeCdf {        // grid.wgsl:233-240
 // Counter slots in Dev::counters
 enum { CTR_NBLOCKS = 0, CTR_ERRORS = 1, CTR_NPHYS = 2, CTR_NCPIC = 3, CTR_N = 4, CTR_NV = 5,
        CTR_NPREV = 6,  // sharded runs: slots [0, NPREV) are the sorted output of the last substep, [NPREV, N) arrivals
+       CTR_NLEAVE = 7,  // sharded runs: particles the last fused G2P launch found outside the slab (Dev::leavers)
        CTR_COUNT = 8 };
 enum { ERRBIT_OVERFLOW = 1u, ERRBIT_KEYRANGE = 2u, ERRBIT_SHARD = 4u };
 
@@ -156,6 +157,9 @@ struct Dev {
     BodyDev *bodies;         // 16: mass properties
     int32_t *impulses;       // 16 * 8: fixed-point (x 1e5) linear[D] + angular impulses accumulated by P2G
     float4 *imp_slab;        // cap*TILE*IMPQ per-block partial node impulses (two-way coupling only), or null
+    uint32_t *leavers;       // sharded: output slots of the particles that left [shard_lo, shard_hi) in the last substep (filled by the
+                             // fused G2P, consumed by k_pack_migrants: no pass over all particles to find a handful)
+    uint32_t leavers_cap;
     uint32_t *hdr_clear[4];  // sharded: headers of the registered outgoing message buffers, zeroed by the scan of k_regroup
     // rigid particles of mesh colliders (kernels_rigid.h); n_rigid == 0 when there is none
     uint32_t n_rigid, n_rvtx;
