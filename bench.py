@@ -112,7 +112,7 @@ class Leg:
         # face touches at most (ny / 8 + 3) x (nz / 8 + 3) blocks (+ margin); a handful of particles cross a cut per
         # substep while the body falls along y. An overflow is reported by wgs_sync and by the particle count below.
         kw = dict(particle_capacity=int(ps.n * 1.25) + 4096, model=scene["model"], halo_capacity_blocks=(ny // 8 + 3) * (nz // 8 + 3) + 32,
-                  migrant_capacity=max(512, (ny * nz) // 16))
+                  migrant_capacity=max(512, (ny * nz) // 32))
         args = (pipe, scene["params"], ps, scene["global_ids"], scene["colliders"], scene["cell_width"], scene["grid_capacity"], lo, hi,
                 rank > 0, rank < world - 1)
         if env["native"]:
