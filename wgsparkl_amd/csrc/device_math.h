@@ -81,6 +81,21 @@ __device__ inline uint32_t hmap_find(const Dev &d, uint32_t key, uint32_t epoch)
     return NONE;
 }
 
+// the block's physical id whether it is active or not (NONE: not in the table)
+__device__ inline uint32_t hmap_lookup(const Dev &d, uint32_t key) {
+    uint32_t slot = hash_key(key) & d.hmask;
+    for (uint32_t probe = 0; probe <= d.hmask; ++probe) {
+        const uint32_t st = d.hkeys[slot];
+        if (st == key) {
+            const uint32_t id = d.hvals[slot];
+            return id < d.cap ? id : NONE;
+        }
+        if (st == NONE) return NONE;
+        slot = (slot + 1u) & d.hmask;
+    }
+    return NONE;
+}
+
 // K lookups at once, probing in lockstep: every round issues the loads of all unresolved keys together, then the values
 // of the hits, then their stamps — a few dependent round trips for the lot instead of up to three per key, one key
 // after the other.

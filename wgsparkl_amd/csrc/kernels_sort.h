@@ -361,6 +361,7 @@ __device__ __forceinline__ void scan_chunk(const Dev &d, uint32_t epoch, uint32_
 #ifdef WGS_ABLATE
     if (tid == 0) g_prof[WGS_PROF_ROWS - 1][0] = wall_clock64();
 #endif
+    if (k == 0 && tid == 0) d.counters[CTR_NPHYS_SEEN + (epoch & 1u)] = d.counters[CTR_NPHYS];
     if (k == 0 && tid < 4 && d.hdr_clear[tid]) d.hdr_clear[tid][0] = 0u;  // outgoing halo / migrant message counts of this substep
 }
 
@@ -417,7 +418,10 @@ __device__ __forceinline__ void regroup_block(const Dev &d, int side, uint32_t e
     const uint32_t head = d.cell_head[idx];
     const uint32_t bkey = d.block_key[id];
     uint32_t link = NONE;
-    if (lane < 16) link = (lane >= 8 ? d.nbr_minus : d.nbr_plus)[id * 8u + (lane & 7u)];
+    if (lane < 16) link = d.nbr_known[id * 16u + lane];
+    // no block id was handed out since launch 2 of the previous substep? Then a neighbour that was not in the table is
+    // still not in it (rim of the active region: the lookups with the longest probe sequences, every substep)
+    const bool no_new_blocks = d.counters[CTR_NPHYS] == d.counters[CTR_NPHYS_SEEN + ((epoch - 1u) & 1u)];
     const GroupLoads grp = block_prefix_loads(d, id, lane);
     if (stamp != epoch) return;  // wave-uniform: not active in this substep
     const bool old_ok = have_old && le == epoch - 1u;
@@ -425,10 +429,11 @@ __device__ __forceinline__ void regroup_block(const Dev &d, int side, uint32_t e
         cs_old = ce_old = 0u;
         link = NONE;
     }
-    // a neighbour linked one substep ago keeps its physical id: it only has to be active now (one round trip instead
-    // of the three of a hash lookup)
+    // a neighbour that was in the table one substep ago keeps its physical id: it only has to be active now (one round
+    // trip instead of the three of a hash lookup)
     uint32_t link_stamp = 0u;
     if (link != NONE) link_stamp = d.block_stamp[link];
+    const bool links_valid = old_ok;
     // ---- stage the new cell ids of the block's previous run (contiguous: cells are consecutive runs); with movers
     // into this block also the particle ids of the run (the merge compares them)
     const uint32_t run0 = __shfl(cs_old, 0), run1 = __shfl(ce_old, 63);
@@ -447,16 +452,20 @@ __device__ __forceinline__ void regroup_block(const Dev &d, int side, uint32_t e
     if (lane < 16) {
         const uint32_t o = lane & 7u;
         const bool minus = lane >= 8;
+        uint32_t known = NONE;
         if ((int)o < NN) {
             if (link != NONE) {
+                known = link;
                 res = link_stamp == epoch ? link : NONE;
-            } else {  // not linked a substep ago (or no previous substep): it may have become active since
+            } else if (!(links_valid && no_new_blocks)) {  // unknown, or the table has grown: look it up
                 const int sgn = minus ? -1 : 1;
                 int nb[3] = {b[0] + sgn * (int)(o & 1u), b[1] + sgn * (int)((o >> 1) & 1u), b[2] + sgn * (int)((o >> 2) & 1u)};
-                if (block_in_key_range<D>(nb)) res = hmap_find(d, pack_key<D>(nb), epoch);
+                if (block_in_key_range<D>(nb)) known = hmap_lookup(d, pack_key<D>(nb));
+                if (known != NONE && d.block_stamp[known] == epoch) res = known;
             }
         }
         (minus ? d.nbr_minus : d.nbr_plus)[id * 8u + o] = res;
+        d.nbr_known[id * 16u + lane] = known;
     }
     WGS_PROF(0)
     // (single wave: LDS accesses of a wave execute in order, the relaxed wavefront-scope atomics below keep the

@@ -106,7 +106,8 @@ struct NodeCdf {        // grid.wgsl:233-240
 enum { CTR_NBLOCKS = 0, CTR_ERRORS = 1, CTR_NPHYS = 2, CTR_NCPIC = 3, CTR_N = 4, CTR_NV = 5,
        CTR_NPREV = 6,  // sharded runs: slots [0, NPREV) are the sorted output of the last substep, [NPREV, N) arrivals
        CTR_NLEAVE = 7,  // sharded runs: particles the last fused G2P launch found outside the slab (Dev::leavers)
-       CTR_COUNT = 8 };
+       CTR_NPHYS_SEEN = 8,  // [8], [9]: the id counter as launch 2 of an even / odd substep saw it (kernels_sort.h regroup_block)
+       CTR_COUNT = 16 };
 enum { ERRBIT_OVERFLOW = 1u, ERRBIT_KEYRANGE = 2u, ERRBIT_SHARD = 4u };
 
 // Everything a kernel needs, passed by value.
@@ -139,6 +140,7 @@ struct Dev {
     uint32_t *active;      // cap: physical ids of the blocks active in this substep, [0, num_active_blocks)
     uint32_t *nbr_plus;    // cap*8: physical ids of b + {0,1}^D (always active)
     uint32_t *nbr_minus;   // cap*8: physical ids of b - {0,1}^D, NONE when inactive
+    uint32_t *nbr_known;   // cap*16: the same 16 neighbours' ids if they are in the table at all (active or not), NONE if absent
     uint32_t *cell_head;   // cap*64: head of the cell's list of movers of this substep (slot + 1; zero outside the sort)
     uint32_t *cell_start;  // cap*64
     uint32_t *cell_cursor; // cap*64: end of the cell's range in perm
