@@ -190,6 +190,7 @@ wgs_status alloc_grid(wgs_data *d) {
     GRID_ALLOC(&dev.nbr_plus, cap * 8);
     GRID_ALLOC(&dev.nbr_minus, cap * 8);
     GRID_ALLOC(&dev.nbr_known, cap * 16);
+    GRID_ALLOC(&dev.act_src, cap * 8);
     GRID_ALLOC(&dev.cell_head, cap * NPB);
     GRID_ALLOC(&dev.chunk_a, nchunk);
     GRID_ALLOC(&dev.chunk_b, nchunk);
@@ -232,7 +233,7 @@ wgs_status grow_grid(wgs_data *d, uint32_t new_cap) {
     Dev &dev = d->dev;
     HIP_TRY(hipStreamSynchronize(d->stream));
     void *old[] = {dev.hkeys, dev.hvals, dev.block_key, dev.block_count, dev.block_stamp, dev.links_epoch, dev.block_acc, dev.active,
-                   dev.block_start, dev.nbr_plus, dev.nbr_minus, dev.nbr_known, dev.cell_head, dev.chunk_a, dev.chunk_b, dev.group_a, dev.group_b,
+                   dev.block_start, dev.nbr_plus, dev.nbr_minus, dev.nbr_known, dev.act_src, dev.cell_head, dev.chunk_a, dev.chunk_b, dev.group_a, dev.group_b,
                    dev.cell_start, dev.cell_cursor, dev.nodes, dev.node_cdf, dev.slab, dev.block_cdf_flag, dev.block_cpic, dev.cpic_list,
                    dev.imp_slab, dev.mesh_min, dev.mesh_aff};
     for (void *p : old) release_alloc(d, p);

@@ -431,8 +431,11 @@ __device__ __forceinline__ void regroup_block(const Dev &d, int side, uint32_t e
     }
     // a neighbour that was in the table one substep ago keeps its physical id: it only has to be active now (one round
     // trip instead of the three of a hash lookup)
-    uint32_t link_stamp = 0u;
-    if (link != NONE) link_stamp = d.block_stamp[link];
+    uint32_t link_stamp = 0u, link_cnt = 0u;
+    if (link != NONE) {
+        link_stamp = d.block_stamp[link];
+        link_cnt = d.block_acc[link];  // particles of that neighbour in this substep (launch 1's total)
+    }
     const bool links_valid = old_ok;
     // ---- stage the new cell ids of the block's previous run (contiguous: cells are consecutive runs); with movers
     // into this block also the particle ids of the run (the merge compares them)
@@ -462,8 +465,10 @@ __device__ __forceinline__ void regroup_block(const Dev &d, int side, uint32_t e
                 int nb[3] = {b[0] + sgn * (int)(o & 1u), b[1] + sgn * (int)((o >> 1) & 1u), b[2] + sgn * (int)((o >> 2) & 1u)};
                 if (block_in_key_range<D>(nb)) known = hmap_lookup(d, pack_key<D>(nb));
                 if (known != NONE && d.block_stamp[known] == epoch) res = known;
+                if (res != NONE) link_cnt = d.block_acc[res];
             }
         }
+        if (res == NONE) link_cnt = 0u;
         (minus ? d.nbr_minus : d.nbr_plus)[id * 8u + o] = res;
         d.nbr_known[id * 16u + lane] = known;
     }
@@ -646,6 +651,8 @@ __device__ __forceinline__ void regroup_block(const Dev &d, int side, uint32_t e
         d.mesh_min[idx] = ~0ull;
         d.mesh_aff[idx] = 0u;
     }
+    // the slabs the grid update gathers this block's nodes from: its "-" neighbours that hold particles
+    if (lane >= 8 && lane < 16) d.act_src[aidx * 8u + (uint32_t)(lane & 7)] = link_cnt > 0u ? res : NONE;
     if (lane == 63) {
         d.active[aidx] = id;           // grid.wgsl:323-334: the active list, in physical-id order
         d.block_start[id] = bstart;    // first_particle
@@ -659,7 +666,8 @@ __device__ __forceinline__ void regroup_block(const Dev &d, int side, uint32_t e
 
 // Launch 2: the first `nscan` workgroups scan, the others regroup (one wave per active block, strided over the
 // physical ids). The scan workgroups have the lowest indices, so they are resident before any wave can wait for them.
-template <int D, bool CDF> __global__ __launch_bounds__(SORT_THREADS) void k_regroup(Dev d, int side, uint32_t epoch, uint32_t nscan, int have_old) {
+// (4 waves per SIMD = 128 VGPRs: with its 36 KB of LDS that is the 4 resident workgroups per CU the launch is sized for)
+template <int D, bool CDF> __global__ __launch_bounds__(SORT_THREADS, 4) void k_regroup(Dev d, int side, uint32_t epoch, uint32_t nscan, int have_old) {
     __shared__ unsigned long long s_wave[SORT_THREADS / 64];
     __shared__ unsigned long long s_bcast;
     __shared__ uint32_t s_in[SORT_THREADS / 64][RUNCAP], s_out[SORT_THREADS / 64][RUNCAP], s_pid[SORT_THREADS / 64][RUNCAP];

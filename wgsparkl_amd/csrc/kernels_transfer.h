@@ -213,8 +213,8 @@ template <int D, int PHASE, bool TWOWAY = false> __global__ __launch_bounds__(25
             int tt[3] = {l[0] + BW * (o & 1), l[1] + BW * ((o >> 1) & 1), l[2] + BW * ((o >> 2) & 1)};
             bool in_tile = tt[0] < TW && tt[1] < TW && (D == 2 || tt[2] < TW);
             if (!in_tile) continue;
-            uint32_t src = d.nbr_minus[b * 8u + o];
-            if (src == NONE || d.block_count[src] == 0) continue;
+            const uint32_t src = d.act_src[(t >> 6) * 8u + o];  // (k_regroup: "-" neighbour with particles, else NONE)
+            if (src == NONE) continue;
             int ti = tt[0] + TW * tt[1] + (D == 3 ? TW * TW * tt[2] : 0);
             srcs[o] = src;
             tis[o] = ti;

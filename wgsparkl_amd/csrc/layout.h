@@ -140,6 +140,8 @@ struct Dev {
     uint32_t *active;      // cap: physical ids of the blocks active in this substep, [0, num_active_blocks)
     uint32_t *nbr_plus;    // cap*8: physical ids of b + {0,1}^D (always active)
     uint32_t *nbr_minus;   // cap*8: physical ids of b - {0,1}^D, NONE when inactive
+    uint32_t *act_src;     // cap*8, by ACTIVE-LIST index: the b - {0,1}^D neighbours that hold particles (the slabs a node of b is
+                           // gathered from), NONE otherwise — what the grid update reads instead of links + counts
     uint32_t *nbr_known;   // cap*16: the same 16 neighbours' ids if they are in the table at all (active or not), NONE if absent
     uint32_t *cell_head;   // cap*64: head of the cell's list of movers of this substep (slot + 1; zero outside the sort)
     uint32_t *cell_start;  // cap*64
