@@ -238,6 +238,27 @@ def test_uniform_material_mode_is_bit_identical(hip_libs, monkeypatch):
         assert np.array_equal(ga[0], gb[0]) and np.array_equal(ga[1], gb[1])
 
 
+def test_g2p_launch_shapes_are_bit_identical(hip_libs, monkeypatch):
+    """The fused G2P advances one chunk of 64 sorted particles per wave, or — from 1.5 M particles on, where the launch is
+    bound by latency x occupancy — two, with both chunks' particle state requested up front (kernels_transfer.h). The
+    large-scene shape forced on small scenes (WGS_DEBUG = 131072) must give the same bits: elastic with the floor
+    (both bodies of the paired launch), plastic, 2D."""
+    makes = (lambda: scenes.neo_hookean_cube(n_side=24, with_floor=True), lambda: scenes.sand_column(nx=12, ny=20, nz=12, with_floor=True),
+             lambda: scenes.elastic_block_2d(nx=50, ny=40))
+    for make in makes:
+        def run():
+            sc = make()
+            sc["particles"].pos[:, 1] -= 5.6 if sc["particles"].dim == 3 else 4.6
+            sc["particles"].vel[:, 0] = 1.5
+            return run_gpu(sc, 25).read_particles()
+        a = run()
+        monkeypatch.setenv("WGS_DEBUG", "131072")
+        b = run()
+        monkeypatch.delenv("WGS_DEBUG")
+        for f in ("pos", "vel", "def_grad", "affine", "cdf_affinity", "dp_state"):
+            assert np.array_equal(getattr(a, f), getattr(b, f)), f
+
+
 def _exploding_cube():
     sc = scenes.neo_hookean_cube(n_side=8)
     ps = sc["particles"]

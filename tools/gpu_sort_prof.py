@@ -4,15 +4,18 @@ sys.path.insert(0, '.'); sys.path.insert(0, 'tests')
 import numpy as np
 from helpers import pipeline
 from wgsparkl_amd import MpmData, scenes
-n_side = int(sys.argv[1]) if len(sys.argv) > 1 else 100
-sc = scenes.neo_hookean_cube(n_side=n_side, with_floor=True)
+if len(sys.argv) > 1 and sys.argv[1] == "c3":
+    sc = scenes.config_scene("c3")
+else:
+    n_side = int(sys.argv[1]) if len(sys.argv) > 1 else 100
+    sc = scenes.neo_hookean_cube(n_side=n_side, with_floor=True)
 pipe = pipeline(3)
 data = MpmData.new(pipe, sc["params"], sc["particles"], sc["colliders"], sc["cell_width"], sc["grid_capacity"], sc["model"])
 ROWS = 8192
 buf = (C.c_ulonglong * (ROWS * 8))()
 pipe.step(data, 20); data.sync()
 names = ["links", "staged", "pass1", "cdf", "pass2", "bstart", "end"]
-for rep in range(3):
+for rep in range(2):
     pipe.lib.wgs_debug_prof(buf)          # reset
     pipe.step(data, 10); data.sync()      # rows hold the clocks of the LAST substep's launch
     pipe.lib.wgs_debug_prof(buf)

@@ -290,7 +290,7 @@ void fill_collider(ColliderDev &c, const wgs_collider &in) {
     for (int k = 0; k < 3; k++) c.com[k] = in.com[k];
 }
 
-constexpr uint32_t WGS_LAUNCH_SHAPE_SWITCHES = 128u | 1024u | 4096u | 8192u | 16384u | 32768u | 65536u;  // WGS_DEBUG bits the shipped library honours
+constexpr uint32_t WGS_LAUNCH_SHAPE_SWITCHES = 128u | 1024u | 4096u | 8192u | 16384u | 32768u | 65536u | 131072u;  // WGS_DEBUG bits the shipped library honours
 constexpr uint32_t P2G_SMALL_BUDGET_MIN_PARTICLES = 600000;  // one-way CPIC P2G body at 168 VGPRs from this size on
 constexpr uint32_t P2G_PAIR_MIN_BLOCKS = 8;  // near-collider blocks from which P2G runs both bodies in one launch
 int grid_for(const wgs_data *d, int blocks_per_cu) { return d->pipeline->num_cus * blocks_per_cu; }
@@ -749,10 +749,12 @@ template <bool TS> wgs_status enqueue_substep(wgs_data *d, int ts_slot, int part
         mark(5);
         if (dev.nv > 0) {
             // ---- "g2p" + "particles_update", fused
-            const int g = (int)(((dev.nv + G2P_THREADS - 1) / G2P_THREADS + 7) / 8) * 8;  // multiple of 8: XCD-aware mapping
+            // one single-wave workgroup per `npass` chunks of 64 sorted particles; multiple of 8: XCD-aware mapping
+            const uint32_t npass = (dev.nv >= G2P_TWO_PASS_MIN_PARTICLES || (dev.dbg & 131072u)) ? 2u : 1u;
+            const int g = (int)(((dev.nv + G2P_THREADS * npass - 1) / (G2P_THREADS * npass) + 7) / 8) * 8;
 #define WGS_LAUNCH_G2P(MODEL, PL, CM)                                                                              \
     hipLaunchKernelGGL((k_g2p_update<D, MODEL, PL, CM>), (CM) == 2 ? dim3(8, grid_for(d, 1) * 3 / 2) : dim3(g), \
-                       dim3(G2P_THREADS), 0, s, dev, side, epoch)
+                       dim3(G2P_THREADS), 0, s, dev, side, epoch, npass)
 #define WGS_LAUNCH_G2P_MP(MODEL, PL)        \
     do {                                    \
         if (d->cpic && !(dev.dbg & 4096u)) {                                                                      \
@@ -763,10 +765,10 @@ template <bool TS> wgs_status enqueue_substep(wgs_data *d, int ts_slot, int part
             /* plastic scenes with a large share of listed blocks: the spill-free variant (kernels_transfer.h) */  \
             if (PL && d->last_ncpic != UINT32_MAX && d->last_ncpic * 5u >= std::max(1u, d->last_nblocks) && !(dev.dbg & 16384u)) \
                 hipLaunchKernelGGL((k_g2p_pair<D, MODEL, PL, (PL) ? 2 : G2P_WAVES_PER_EU>), dim3((uint32_t)g + 8u * nlist), \
-                                   dim3(G2P_THREADS), 0, s, dev, side, epoch, (uint32_t)g, nlist);                \
+                                   dim3(G2P_THREADS), 0, s, dev, side, epoch, (uint32_t)g, nlist, npass);                \
             else                                                                                                  \
                 hipLaunchKernelGGL((k_g2p_pair<D, MODEL, PL>), dim3((uint32_t)g + 8u * nlist), dim3(G2P_THREADS), 0, s, \
-                                   dev, side, epoch, (uint32_t)g, nlist);                                         \
+                                   dev, side, epoch, (uint32_t)g, nlist, npass);                                         \
             mark(6);                                                                                              \
         } else if (d->cpic) {               \
             WGS_LAUNCH_G2P(MODEL, PL, 1);   \
@@ -908,7 +910,8 @@ static wgs_status create_impl(wgs_pipeline *pipeline, const wgs_sim_params *para
     // every substep (no k_rebin), 1024 = node cdf in a launch of its own (k_cdf) instead of k_setup_scatter<CDF>,
     // 4096 = the two G2P bodies as two launches, 8192 = the two P2G bodies always as two launches, 16384 = never the
     // spill-free variant of the plastic G2P pair, 32768 = never the small register budget of the one-way P2G pair,
-    // 65536 = never the uniform-material mode (the per-particle constants always travel with the particle).
+    // 65536 = never the uniform-material mode (the per-particle constants always travel with the particle), 131072 = the
+    // fused G2P always with two chunks per wave (the large-scene launch shape).
     // The ablations that change the RESULTS (64 = G2P moves bytes only, 256 = P2G without its accumulation loop,
     // 512 = P2G without its particle loads) exist only in builds with -DWGS_ABLATE; the shipped library ignores them.
     dev.dbg = getenv("WGS_DEBUG") ? (uint32_t)strtoul(getenv("WGS_DEBUG"), nullptr, 0) : 0u;
@@ -1697,6 +1700,13 @@ wgs_status wgs_debug_scan(wgs_pipeline *pipeline, const uint32_t *values, uint32
 }
 
 #ifdef WGS_ABLATE
+wgs_status wgs_debug_g2p_prof(unsigned long long *out /* WGS_G2P_ROWS * 8 */) {
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_g2p_prof), sizeof(unsigned long long) * WGS_G2P_ROWS * 8));
+    std::vector<unsigned long long> zero((size_t)WGS_G2P_ROWS * 8, 0ull);
+    HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_g2p_prof), zero.data(), sizeof(unsigned long long) * WGS_G2P_ROWS * 8));
+    return WGS_OK;
+}
 wgs_status wgs_debug_p2g_prof(unsigned long long *out /* WGS_P2G_ROWS * 8 */) {
     HIP_TRY(hipDeviceSynchronize());
     HIP_TRY(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_p2g_prof), sizeof(unsigned long long) * WGS_P2G_ROWS * 8));

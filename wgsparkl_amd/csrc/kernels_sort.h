@@ -403,8 +403,8 @@ __device__ inline void block_prefix(const Dev &d, uint32_t epoch, uint32_t id, i
 // links are one epoch old describe its previous runs: that is where the stayers are); otherwise every particle is
 // on a list.
 template <int D, bool CDF>
-__device__ __forceinline__ void regroup_block(const Dev &d, int side, uint32_t epoch, uint32_t id, uint32_t nphys, bool have_old, uint32_t *s_in,
-                                              uint32_t *s_out, uint32_t *s_pid) {
+__device__ __forceinline__ void regroup_block(const Dev &d, int side, uint32_t epoch, uint32_t id, uint32_t nphys, bool have_old, bool no_new_blocks,
+                                              uint32_t *s_in, uint32_t *s_out, uint32_t *s_pid) {
     constexpr int NN = Dim<D>::NNBR;
     const int lane = threadIdx.x & 63;
     const float *in = d.buf[side];
@@ -419,9 +419,6 @@ __device__ __forceinline__ void regroup_block(const Dev &d, int side, uint32_t e
     const uint32_t bkey = d.block_key[id];
     uint32_t link = NONE;
     if (lane < 16) link = d.nbr_known[id * 16u + lane];
-    // no block id was handed out since launch 2 of the previous substep? Then a neighbour that was not in the table is
-    // still not in it (rim of the active region: the lookups with the longest probe sequences, every substep)
-    const bool no_new_blocks = d.counters[CTR_NPHYS] == d.counters[CTR_NPHYS_SEEN + ((epoch - 1u) & 1u)];
     const GroupLoads grp = block_prefix_loads(d, id, lane);
     if (stamp != epoch) return;  // wave-uniform: not active in this substep
     const bool old_ok = have_old && le == epoch - 1u;
@@ -667,7 +664,10 @@ __device__ __forceinline__ void regroup_block(const Dev &d, int side, uint32_t e
 // Launch 2: the first `nscan` workgroups scan, the others regroup (one wave per active block, strided over the
 // physical ids). The scan workgroups have the lowest indices, so they are resident before any wave can wait for them.
 // (4 waves per SIMD = 128 VGPRs: with its 36 KB of LDS that is the 4 resident workgroups per CU the launch is sized for)
-template <int D, bool CDF> __global__ __launch_bounds__(SORT_THREADS, 4) void k_regroup(Dev d, int side, uint32_t epoch, uint32_t nscan, int have_old) {
+#ifndef WGS_REGROUP_WPE
+#define WGS_REGROUP_WPE 4
+#endif
+template <int D, bool CDF> __global__ __launch_bounds__(SORT_THREADS, WGS_REGROUP_WPE) void k_regroup(Dev d, int side, uint32_t epoch, uint32_t nscan, int have_old) {
     __shared__ unsigned long long s_wave[SORT_THREADS / 64];
     __shared__ unsigned long long s_bcast;
     __shared__ uint32_t s_in[SORT_THREADS / 64][RUNCAP], s_out[SORT_THREADS / 64][RUNCAP], s_pid[SORT_THREADS / 64][RUNCAP];
@@ -680,7 +680,11 @@ template <int D, bool CDF> __global__ __launch_bounds__(SORT_THREADS, 4) void k_
     const uint32_t wave = ((blockIdx.x - nscan) * SORT_THREADS + threadIdx.x) >> 6;
     const uint32_t nwaves = ((gridDim.x - nscan) * SORT_THREADS) >> 6;
     const int w = threadIdx.x >> 6;
-    for (uint32_t id = wave; id < nphys; id += nwaves) regroup_block<D, CDF>(d, side, epoch, id, nphys, have_old != 0, s_in[w], s_out[w], s_pid[w]);
+    // no block id was handed out since launch 2 of the previous substep? Then a neighbour that was not in the table is
+    // still not in it (rim of the active region: the lookups with the longest probe sequences, every substep)
+    const bool no_new_blocks = d.counters[CTR_NPHYS] == d.counters[CTR_NPHYS_SEEN + ((epoch - 1u) & 1u)];
+    for (uint32_t id = wave; id < nphys; id += nwaves)
+        regroup_block<D, CDF>(d, side, epoch, id, nphys, have_old != 0, no_new_blocks, s_in[w], s_out[w], s_pid[w]);
 }
 
 // Test hook (wgs_debug_scan): the scan workgroups, and workgroups that finish it per block exactly like the
