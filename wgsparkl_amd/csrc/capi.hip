@@ -752,10 +752,10 @@ template <bool TS> wgs_status enqueue_substep(wgs_data *d, int ts_slot, int part
             // one single-wave workgroup per `npass` chunks of 64 sorted particles; multiple of 8: XCD-aware mapping
             const uint32_t npass = (dev.nv >= G2P_TWO_PASS_MIN_PARTICLES || (dev.dbg & 131072u)) ? 2u : 1u;
             const int g = (int)(((dev.nv + G2P_THREADS * npass - 1) / (G2P_THREADS * npass) + 7) / 8) * 8;
-#define WGS_LAUNCH_G2P(MODEL, PL, CM)                                                                              \
-    hipLaunchKernelGGL((k_g2p_update<D, MODEL, PL, CM>), (CM) == 2 ? dim3(8, grid_for(d, 1) * 3 / 2) : dim3(g), \
-                       dim3(G2P_THREADS), 0, s, dev, side, epoch, npass)
-#define WGS_LAUNCH_G2P_MP(MODEL, PL)        \
+#define WGS_LAUNCH_G2P(MODEL, PL, CM, NP)                                                                          \
+    hipLaunchKernelGGL((k_g2p_update<D, MODEL, PL, CM, NP>), (CM) == 2 ? dim3(8, grid_for(d, 1) * 3 / 2) : dim3(g), \
+                       dim3(G2P_THREADS), 0, s, dev, side, epoch)
+#define WGS_LAUNCH_G2P_NP(MODEL, PL, NP)    \
     do {                                    \
         if (d->cpic && !(dev.dbg & 4096u)) {                                                                      \
             /* both bodies in one launch (k_g2p_pair) */                                                          \
@@ -764,19 +764,24 @@ template <bool TS> wgs_status enqueue_substep(wgs_data *d, int ts_slot, int part
             const uint32_t nlist = d->last_ncpic == UINT32_MAX ? full : std::min(full, std::max(32u, 2u * d->last_ncpic)); \
             /* plastic scenes with a large share of listed blocks: the spill-free variant (kernels_transfer.h) */  \
             if (PL && d->last_ncpic != UINT32_MAX && d->last_ncpic * 5u >= std::max(1u, d->last_nblocks) && !(dev.dbg & 16384u)) \
-                hipLaunchKernelGGL((k_g2p_pair<D, MODEL, PL, (PL) ? 2 : G2P_WAVES_PER_EU>), dim3((uint32_t)g + 8u * nlist), \
-                                   dim3(G2P_THREADS), 0, s, dev, side, epoch, (uint32_t)g, nlist, npass);                \
+                hipLaunchKernelGGL((k_g2p_pair<D, MODEL, PL, (PL) ? 2 : G2P_WAVES_PER_EU, NP>), dim3((uint32_t)g + 8u * nlist), \
+                                   dim3(G2P_THREADS), 0, s, dev, side, epoch, (uint32_t)g, nlist);                \
             else                                                                                                  \
-                hipLaunchKernelGGL((k_g2p_pair<D, MODEL, PL>), dim3((uint32_t)g + 8u * nlist), dim3(G2P_THREADS), 0, s, \
-                                   dev, side, epoch, (uint32_t)g, nlist, npass);                                         \
+                hipLaunchKernelGGL((k_g2p_pair<D, MODEL, PL, G2P_WAVES_PER_EU, NP>), dim3((uint32_t)g + 8u * nlist), dim3(G2P_THREADS), 0, s, \
+                                   dev, side, epoch, (uint32_t)g, nlist);                                         \
             mark(6);                                                                                              \
         } else if (d->cpic) {               \
-            WGS_LAUNCH_G2P(MODEL, PL, 1);   \
+            WGS_LAUNCH_G2P(MODEL, PL, 1, NP);   \
             mark(6);                        \
-            WGS_LAUNCH_G2P(MODEL, PL, 2);   \
+            WGS_LAUNCH_G2P(MODEL, PL, 2, 1);   \
         } else {                            \
-            WGS_LAUNCH_G2P(MODEL, PL, 0);   \
+            WGS_LAUNCH_G2P(MODEL, PL, 0, NP);   \
         }                                   \
+    } while (0)
+#define WGS_LAUNCH_G2P_MP(MODEL, PL)                    \
+    do {                                                \
+        if (npass == 2u) WGS_LAUNCH_G2P_NP(MODEL, PL, 2); \
+        else WGS_LAUNCH_G2P_NP(MODEL, PL, 1);           \
     } while (0)
             const int sel = (dev.model == WGS_MODEL_NEO_HOOKEAN ? 2 : 0) | (d->plastic ? 1 : 0);
             switch (sel) {
@@ -786,6 +791,7 @@ template <bool TS> wgs_status enqueue_substep(wgs_data *d, int ts_slot, int part
                 default: WGS_LAUNCH_G2P_MP(1, true); break;
             }
 #undef WGS_LAUNCH_G2P_MP
+#undef WGS_LAUNCH_G2P_NP
 #undef WGS_LAUNCH_G2P
         }
         if (!(d->cpic && dev.nv > 0)) mark(6);  // (collider simulations: recorded between the two G2P launches)

@@ -317,13 +317,14 @@ __device__ unsigned long long g_g2p_prof[WGS_G2P_ROWS][8];
 // chunks a block spans, and only that block's particles are processed; the launch is nearly free while no
 // particle is near a collider.
 #define G2P_DONE continue;
-// Chunks of 64 sorted particles per wave of the main body (kernel argument `npass`, g2p_body.inc): 1 while the two particle
+// Chunks of 64 sorted particles per wave of the main body (template parameter NPASS, g2p_body.inc): 1 while the two particle
 // buffers fit the 256 MB Infinity Cache (the launch then runs at HBM-roofline speed for its real traffic and a longer
 // wave life only costs), 2 beyond — there the kernel is bound by latency x occupancy and twice the bytes in flight per
 // wave buy 12-15 % (4.1 M particles: 184 -> 161 us, 16 M: 761 -> 647 us; 1 M: 39.0 -> 41.7 us). Same results either way.
 constexpr uint32_t G2P_TWO_PASS_MIN_PARTICLES = 1500000;
-template <int D, int MODEL, bool PLASTIC, int CMODE>
-__global__ __launch_bounds__(G2P_THREADS, G2P_WAVES_PER_EU) void k_g2p_update(Dev d, int side, uint32_t epoch, uint32_t npass) {
+template <int D, int MODEL, bool PLASTIC, int CMODE, int NPASS = 1>
+__global__ __launch_bounds__(G2P_THREADS, G2P_WAVES_PER_EU) void k_g2p_update(Dev d, int side, uint32_t epoch) {
+    constexpr uint32_t npass = NPASS;  // (a template parameter: as a kernel argument the second pass's registers spilled in the one-pass launch)
     __shared__ float4 s_node[Dim<D>::TILE];
     __shared__ NodeCdf s_cdf[CMODE == 2 ? Dim<D>::TILE : 1];
 #define G2P_CMODE CMODE
@@ -350,8 +351,9 @@ __global__ __launch_bounds__(G2P_THREADS, G2P_WAVES_PER_EU) void k_g2p_update(De
 // ~350 B per lane under that cap; with 2 (256 VGPRs, no spills) a scene whose near-collider blocks are a third of all
 // blocks (4 M sand between a floor and four walls) runs its G2P 16 % faster, while scenes with few such blocks lose
 // 5-12 % to the lower occupancy of the main body: capi.hip picks by the share of listed blocks the host last saw.
-template <int D, int MODEL, bool PLASTIC, int WPE = G2P_WAVES_PER_EU>
-__global__ __launch_bounds__(G2P_THREADS, WPE) void k_g2p_pair(Dev d, int side, uint32_t epoch, uint32_t nmain, uint32_t nlist, uint32_t npass) {
+template <int D, int MODEL, bool PLASTIC, int WPE = G2P_WAVES_PER_EU, int NPASS = 1>
+__global__ __launch_bounds__(G2P_THREADS, WPE) void k_g2p_pair(Dev d, int side, uint32_t epoch, uint32_t nmain, uint32_t nlist) {
+    constexpr uint32_t npass = NPASS;
     __shared__ float4 s_node[Dim<D>::TILE];
     __shared__ NodeCdf s_cdf[Dim<D>::TILE];
     if (blockIdx.x >= 8u * nlist) {
