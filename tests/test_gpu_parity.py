@@ -200,6 +200,35 @@ def test_reference_prefix_sum_vectors_through_the_hip_scan(hip_libs, oracle_libs
         assert tot == int(v.sum())
 
 
+def test_dense_blocks_take_the_global_memory_paths_of_the_sort(hip_libs, oracle_libs):
+    """A wave of the sort's second launch stages a block's previous run and its new order in LDS, 768 entries each
+    (kernels_sort.h RUNCAP); denser blocks go through the same code on global memory. 27 particles per cell = 1728 per
+    block, moving fast enough to change cells and blocks every few substeps: against the oracle (cells and per-block
+    membership exact, fields to tolerance), deterministic, and bit-identical to full binning on every substep."""
+    h = 1.0
+    n = 36
+    ax = (np.arange(n, dtype=np.float64) + 0.5) * (h / 3.0) + 6.0
+    pos = np.stack(np.meshgrid(ax, ax, ax, indexing="ij"), -1).reshape(-1, 3)
+    rng = np.random.default_rng(77)
+    pos = (pos + rng.uniform(-0.04, 0.04, pos.shape)).astype(np.float32)
+    ps = ParticleSet.uniform(pos, h / 6.0, 50.0, ElasticCoefficients.from_young_modulus(1.0e5, 0.3), phase=ParticlePhase(1.0, -1.0))
+    ps.vel[:] = rng.normal(0.0, 40.0, ps.vel.shape).astype(np.float32)            # ~0.04 cells per substep
+    sc = dict(particles=ps, params=SimulationParams(gravity=(0.0, -9.81, 0.0), dt=1.0e-3), colliders=[], cell_width=h,
+              grid_capacity=1024, model=MODEL_NEO_HOOKEAN)
+    k = 12
+    data = run_gpu(sc, k)
+    st32, st64 = run_oracle(sc, k, np.float32), run_oracle(sc, k, np.float64)
+    vid, first, num, ids = data.read_blocks()
+    assert num.max() > 768, "the scene must exceed the LDS stage"
+    check_blocks(data, st32)
+    check_grid(data, st32, st64)
+    check_fields(data, st32, st64)
+    a = data.read_particles()
+    b = run_gpu(sc, k).read_particles()
+    for f in ("pos", "vel", "def_grad", "affine"):
+        assert np.array_equal(getattr(a, f), getattr(b, f)), f
+
+
 def test_determinism(hip_libs):
     sc = cloud_scene(n=30000, seed=11)
     a = run_gpu(sc, 5).read_particles()
