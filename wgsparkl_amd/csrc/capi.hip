@@ -107,7 +107,8 @@ struct wgs_data {
     uint64_t device_bytes = 0;
     uint32_t sticky_errors = 0;
     uint32_t last_nblocks = 0;
-    uint32_t last_ncpic = UINT32_MAX;  // near-collider list length at the last wgs_sync (sizes the list half of k_g2p_pair)
+    uint32_t last_ncpic = UINT32_MAX;  // near-collider list length at the last wgs_sync (picks the P2G launch shape and G2P's register budget)
+    uint32_t last_nvisit = UINT32_MAX; // visit-list length at the last wgs_sync (sizes the list half of k_g2p_pair)
     uint32_t capacity = 0;      // particle slots allocated
     uint32_t *shard_counts = nullptr;  // device scratch for pack kernels
     std::vector<void *> allocs;
@@ -204,6 +205,8 @@ wgs_status alloc_grid(wgs_data *d) {
     GRID_ALLOC(&dev.block_cdf_flag, cap);
     GRID_ALLOC(&dev.block_cpic, cap);
     GRID_ALLOC(&dev.cpic_list, cap);
+    dev.visit_cap = dev.npad / 512u + 2u * cap + 16u;
+    GRID_ALLOC(&dev.visit_list, (size_t)dev.visit_cap * 8);
     if (d->two_way) GRID_ALLOC(&dev.imp_slab, cap * Dim<D>::TILE * (D == 3 ? 2 : 1));
     if (dev.mesh_min) {
         GRID_ALLOC(&dev.mesh_min, cap * NPB);
@@ -234,7 +237,7 @@ wgs_status grow_grid(wgs_data *d, uint32_t new_cap) {
     HIP_TRY(hipStreamSynchronize(d->stream));
     void *old[] = {dev.hkeys, dev.hvals, dev.block_key, dev.block_count, dev.block_stamp, dev.links_epoch, dev.block_acc, dev.active,
                    dev.block_start, dev.nbr_plus, dev.nbr_minus, dev.nbr_known, dev.act_src, dev.cell_head, dev.chunk_a, dev.chunk_b, dev.group_a, dev.group_b,
-                   dev.cell_start, dev.cell_cursor, dev.nodes, dev.node_cdf, dev.slab, dev.block_cdf_flag, dev.block_cpic, dev.cpic_list,
+                   dev.cell_start, dev.cell_cursor, dev.nodes, dev.node_cdf, dev.slab, dev.block_cdf_flag, dev.block_cpic, dev.cpic_list, dev.visit_list,
                    dev.imp_slab, dev.mesh_min, dev.mesh_aff};
     for (void *p : old) release_alloc(d, p);
     dev.imp_slab = nullptr;  // (alloc_grid re-creates what was in use: two_way / mesh_min say so)
@@ -249,6 +252,7 @@ wgs_status grow_grid(wgs_data *d, uint32_t new_cap) {
     HIP_TRY(hipMemsetAsync(dev.counters + CTR_NPHYS, 0, sizeof(uint32_t), d->stream));
     d->prev_sorted = false;      // block ids start over: the next substep bins every particle through the hash map
     d->last_ncpic = UINT32_MAX;
+    d->last_nvisit = UINT32_MAX;
     d->grid_grown++;
     return WGS_OK;
 }
@@ -559,6 +563,8 @@ wgs_status fetch_counters(wgs_data *d) {
     HIP_TRY(hipStreamSynchronize(d->stream));
     d->last_nblocks = host[CTR_NBLOCKS] < d->dev.cap ? host[CTR_NBLOCKS] : d->dev.cap;
     d->last_ncpic = host[CTR_NCPIC] < d->dev.cap ? host[CTR_NCPIC] : d->dev.cap;
+    d->last_nvisit = 0;  // the longest of the eight lists
+    for (int k = 0; k < 8; k++) d->last_nvisit = std::max(d->last_nvisit, std::min(host[CTR_NVISIT + 32 * k], d->dev.visit_cap));
     d->sticky_errors |= host[CTR_ERRORS];
     if (host[CTR_NBLOCKS] > d->dev.cap) d->sticky_errors |= ERRBIT_OVERFLOW;
     if (host[CTR_NPHYS] > d->dev.cap / 4u * 3u) d->force_rehash = true;
@@ -627,6 +633,9 @@ template <bool TS> wgs_status enqueue_substep(wgs_data *d, int ts_slot, int part
         }
     };
     const uint32_t epoch = (uint32_t)(d->substeps + 1);
+    // chunks of 64 sorted particles per wave of the fused G2P (kernels_transfer.h); the sort files the visit list by it
+    dev.g2p_npass = dev.nv >= G2P_MANY_PASS_MIN_PARTICLES ? (uint32_t)G2P_MANY_PASSES
+                    : (dev.nv >= G2P_TWO_PASS_MIN_PARTICLES || (dev.dbg & 131072u)) ? 2u : 1u;
     // Steady state: the buffer is in the sorted order of the previous substep, whose block ids, cell ids
     // (perm_cell) and neighbour links are still valid, so the particles are re-binned RELATIVE to their old
     // block (k_rebin: no hash lookups except for the few particles that changed block). The full k_bin runs
@@ -750,24 +759,31 @@ template <bool TS> wgs_status enqueue_substep(wgs_data *d, int ts_slot, int part
         if (dev.nv > 0) {
             // ---- "g2p" + "particles_update", fused
             // one single-wave workgroup per `npass` chunks of 64 sorted particles; multiple of 8: XCD-aware mapping
-            const uint32_t npass = (dev.nv >= G2P_TWO_PASS_MIN_PARTICLES || (dev.dbg & 131072u)) ? 2u : 1u;
+            const uint32_t npass = dev.g2p_npass;
             const int g = (int)(((dev.nv + G2P_THREADS * npass - 1) / (G2P_THREADS * npass) + 7) / 8) * 8;
+#ifndef WGS_PLASTIC_WPE_DENSE
+#define WGS_PLASTIC_WPE_DENSE 2
+#endif
+#ifndef WGS_PLASTIC_WPE
+#define WGS_PLASTIC_WPE G2P_WAVES_PER_EU
+#endif
 #define WGS_LAUNCH_G2P(MODEL, PL, CM, NP)                                                                          \
-    hipLaunchKernelGGL((k_g2p_update<D, MODEL, PL, CM, NP>), (CM) == 2 ? dim3(8, grid_for(d, 1) * 3 / 2) : dim3(g), \
+    hipLaunchKernelGGL((k_g2p_update<D, MODEL, PL, CM, NP>), (CM) == 2 ? dim3(8 * (grid_for(d, 1) * 3 / 2)) : dim3(g), \
                        dim3(G2P_THREADS), 0, s, dev, side, epoch)
 #define WGS_LAUNCH_G2P_NP(MODEL, PL, NP)    \
     do {                                    \
-        if (d->cpic && !(dev.dbg & 4096u)) {                                                                      \
+        if (d->cpic && !(dev.dbg & 4096u)) {                                                               \
             /* both bodies in one launch (k_g2p_pair) */                                                          \
-            /* list workgroups: 2 x the list length the host last saw (unknown: the whole chip) */                 \
+            /* list waves (8 x nlist; they stride over the runs of the visit list): 2 x the runs the host last saw */ \
+            /* (unknown: a wave and a half per SIMD) */                                                           \
             const uint32_t full = (uint32_t)grid_for(d, 1) * 3u / 2u;                                             \
-            const uint32_t nlist = d->last_ncpic == UINT32_MAX ? full : std::min(full, std::max(32u, 2u * d->last_ncpic)); \
+            const uint32_t nlist = d->last_nvisit == UINT32_MAX ? full : std::min(full, std::max(8u, 2u * ((d->last_nvisit + (NP) - 1u) / (NP)))); \
             /* plastic scenes with a large share of listed blocks: the spill-free variant (kernels_transfer.h) */  \
             if (PL && d->last_ncpic != UINT32_MAX && d->last_ncpic * 5u >= std::max(1u, d->last_nblocks) && !(dev.dbg & 16384u)) \
-                hipLaunchKernelGGL((k_g2p_pair<D, MODEL, PL, (PL) ? 2 : G2P_WAVES_PER_EU, NP>), dim3((uint32_t)g + 8u * nlist), \
+                hipLaunchKernelGGL((k_g2p_pair<D, MODEL, PL, (PL) ? WGS_PLASTIC_WPE_DENSE : G2P_WAVES_PER_EU, NP>), dim3((uint32_t)g + 8u * nlist), \
                                    dim3(G2P_THREADS), 0, s, dev, side, epoch, (uint32_t)g, nlist);                \
             else                                                                                                  \
-                hipLaunchKernelGGL((k_g2p_pair<D, MODEL, PL, G2P_WAVES_PER_EU, NP>), dim3((uint32_t)g + 8u * nlist), dim3(G2P_THREADS), 0, s, \
+                hipLaunchKernelGGL((k_g2p_pair<D, MODEL, PL, (PL) ? WGS_PLASTIC_WPE : G2P_WAVES_PER_EU, NP>), dim3((uint32_t)g + 8u * nlist), dim3(G2P_THREADS), 0, s, \
                                    dev, side, epoch, (uint32_t)g, nlist);                                         \
             mark(6);                                                                                              \
         } else if (d->cpic) {               \
@@ -780,7 +796,8 @@ template <bool TS> wgs_status enqueue_substep(wgs_data *d, int ts_slot, int part
     } while (0)
 #define WGS_LAUNCH_G2P_MP(MODEL, PL)                    \
     do {                                                \
-        if (npass == 2u) WGS_LAUNCH_G2P_NP(MODEL, PL, 2); \
+        if (npass == (uint32_t)G2P_MANY_PASSES) WGS_LAUNCH_G2P_NP(MODEL, PL, G2P_MANY_PASSES); \
+        else if (npass == 2u) WGS_LAUNCH_G2P_NP(MODEL, PL, 2); \
         else WGS_LAUNCH_G2P_NP(MODEL, PL, 1);           \
     } while (0)
             const int sel = (dev.model == WGS_MODEL_NEO_HOOKEAN ? 2 : 0) | (d->plastic ? 1 : 0);

@@ -82,6 +82,24 @@ __device__ inline uint32_t hmap_find(const Dev &d, uint32_t key, uint32_t epoch)
 }
 
 // the block's physical id whether it is active or not (NONE: not in the table)
+// One visit-list entry per chunk of 64 sorted particles that holds particles of the listed block `id` (its run in the
+// sorted order is [start, start + count), count > 0). Called by one whole wave. Consecutive groups of g2p_npass chunks
+// (what one wave of the fused G2P advances in a row) go to the eight lists in turn: every XCD gets an even share of
+// the visits, and a group stays together so that its later chunks find the block's node tile staged. One atomic per
+// group, all groups of the block at once (one lane each). The order inside a list does not matter: every particle is
+// advanced exactly once, by the visit of its chunk for its block.
+__device__ inline void append_visits(const Dev &d, uint32_t id, uint32_t start, uint32_t count, int lane) {
+    const uint32_t np = d.g2p_npass;
+    const uint32_t c0 = start >> 6, c1 = (start + count - 1u) >> 6, g0 = c0 / np, ng = c1 / np - g0 + 1u;
+    for (uint32_t t = (uint32_t)lane; t < ng; t += 64u) {
+        const uint32_t g = g0 + t, k = g & 7u;
+        const uint32_t cs = max(c0, g * np), ce = min(c1, g * np + np - 1u), n = ce - cs + 1u;
+        const uint32_t slot = atomicAdd(&d.counters[CTR_NVISIT + 32u * k], n);
+        for (uint32_t e = 0; e < n; e++)
+            if (slot + e < d.visit_cap) d.visit_list[(size_t)k * d.visit_cap + slot + e] = make_uint2(id, cs + e);
+    }
+}
+
 __device__ inline uint32_t hmap_lookup(const Dev &d, uint32_t key) {
     uint32_t slot = hash_key(key) & d.hmask;
     for (uint32_t probe = 0; probe <= d.hmask; ++probe) {
@@ -245,11 +263,26 @@ template <int D> __device__ inline bool jacobi_rotate(float *a, float *v, int p,
         gamma += a[p * D + r] * a[q * D + r];
     }
     // rotation angle zeroing the (p,q) inner product; nothing to do when already orthogonal
+    // The rotation angle only steers the iteration (any angle close to the exact one converges the same way, and the
+    // singular values and vectors are read off the rotated columns afterwards), so it is computed with the hardware's
+    // 1-ulp reciprocal / square root / reciprocal square root instead of the correctly rounded sequences: a rotation
+    // drops from ~120 to ~70 VALU instructions, and the Drucker-Prager G2P is bound by exactly this dependent chain.
+    // What must stay tight is c^2 + s^2 = 1: c is one rsq of 1 + t^2 and s = c t, so the pair is off unit length by
+    // ~1 ulp per rotation, the same order as the rounding of c and s themselves.
+#ifndef WGS_SVD_IEEE
+    float zeta = (beta - alpha) * __builtin_amdgcn_rcpf(2.0f * gamma);
+    float t = copysignf(__builtin_amdgcn_rcpf(fabsf(zeta) + __builtin_amdgcn_sqrtf(fmaf(zeta, zeta, 1.0f))), zeta);
+#else
     float zeta = (beta - alpha) / (2.0f * gamma);
     float t = copysignf(1.0f, zeta) / (fabsf(zeta) + sqrtf(1.0f + zeta * zeta));
+#endif
     const bool skip = !live || !(fabsf(gamma) > 1.0e-30f) || !(gamma * gamma > 1.0e-15f * alpha * beta) || !(t == t);
     if (!skip) {
+#ifndef WGS_SVD_IEEE
+        float c = __builtin_amdgcn_rsqf(fmaf(t, t, 1.0f));
+#else
         float c = 1.0f / sqrtf(1.0f + t * t);
+#endif
         float s = c * t;
 #pragma unroll
         for (int r = 0; r < D; r++) {
@@ -282,6 +315,7 @@ template <int D> __device__ inline void svd(const float *F, Svd<D> &out) {
         // the vectors, later sweeps would chase fp32 noise —, so its result depends on its own matrix only; the
         // wave leaves the loop when all its lanes are frozen: 3 sweeps for the deformations met in practice.
         bool live = true;
+#pragma unroll 1
         for (int sweep = 0; sweep < 5; sweep++) {
             bool rotated = jacobi_rotate<3>(a, out.v, 0, 1, live);
             rotated = jacobi_rotate<3>(a, out.v, 0, 2, live) || rotated;

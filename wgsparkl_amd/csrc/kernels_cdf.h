@@ -414,6 +414,7 @@ template <int D> __global__ __launch_bounds__(CDF_THREADS) void k_cdf(Dev d, int
             d.block_cpic[b] = any ? 1u : 0u;
             if (any && cnt > 0) d.cpic_list[atomicAdd(&d.counters[CTR_NCPIC], 1u)] = b;  // few blocks
         }
+        if (any && cnt > 0 && tid < 64) append_visits(d, b, d.block_start[b], cnt, tid);  // (the first wave of the workgroup)
         // (3: the particle cdf of the listed blocks runs in the prologue of the CPIC P2G launch, three waves per block)
     }
 }

@@ -75,7 +75,7 @@ template <int D, int TAIL> __global__ __launch_bounds__(SORT_THREADS) void k_bin
     const float *in = d.buf[side];
     const int tid = threadIdx.x, lane = tid & 63;
     if (tid < TOUCH_SET) s_keys[tid] = NONE;
-    if (blockIdx.x == 0 && tid == 0) d.counters[CTR_NCPIC] = 0;  // near-collider list of this substep (k_regroup appends)
+    if (blockIdx.x == 0 && tid < 9) d.counters[tid == 8 ? (int)CTR_NCPIC : (int)CTR_NVISIT + 32 * tid] = 0;  // near-collider lists of this substep (k_regroup appends)
     __syncthreads();
     const uint32_t first = tail ? d.counters[CTR_NPREV] : 0u;
     const uint32_t i = first + blockIdx.x * SORT_THREADS + tid;
@@ -189,7 +189,7 @@ template <int D> __global__ __launch_bounds__(SORT_THREADS) void k_rebin(Dev d, 
     const float *in = d.buf[side];
     const int tid = threadIdx.x, lane = tid & 63;
     const uint32_t i = blockIdx.x * SORT_THREADS + tid;
-    if (blockIdx.x == 0 && tid == 0) d.counters[CTR_NCPIC] = 0;  // near-collider list of this substep (k_regroup appends)
+    if (blockIdx.x == 0 && tid < 9) d.counters[tid == 8 ? (int)CTR_NCPIC : (int)CTR_NVISIT + 32 * tid] = 0;  // near-collider lists of this substep (k_regroup appends)
     // sharded runs: the residents only (arrivals have no previous cell: k_bin's tail pass), minus the slots
     // vacated by particles that migrated away
     const bool in_range = i < (d.sharded ? min(d.counters[CTR_NPREV], d.counters[CTR_N]) : num_slots(d));
@@ -515,6 +515,7 @@ __device__ __forceinline__ void regroup_block(const Dev &d, int side, uint32_t e
     }
     const uint32_t btotal = __shfl(inc, 63);
     const uint32_t lstart = inc - total;  // start of this cell's run inside the block
+    bool listed = false;  // near a collider and holding particles: on the lists of the CPIC bodies of P2G / G2P
     WGS_PROF(2)
     // ---- node cdf tile + block class (independent of the scan: placed before the wait for it)
     if (CDF WGS_ABLATE_AND(!(d.dbg & (1u << 21)))) {
@@ -561,6 +562,7 @@ __device__ __forceinline__ void regroup_block(const Dev &d, int side, uint32_t e
             d.block_cpic[id] = any ? 1u : 0u;
             if (any && btotal > 0u) d.cpic_list[atomicAdd(&d.counters[CTR_NCPIC], 1u)] = id;  // few blocks
         }
+        listed = any && btotal > 0u;
     }
     WGS_PROF(3)
     // ---- pass 2: merge in ascending particle id. Stayers are in id order already; the next arrival is selected
@@ -657,6 +659,7 @@ __device__ __forceinline__ void regroup_block(const Dev &d, int side, uint32_t e
         d.links_epoch[id] = epoch;     // the neighbour links and cell runs written above are those of this substep
         d.block_cdf_flag[id] = 0;      // (block_acc is cleared by the grid update: the waves of this group read it)
     }
+    if (listed) append_visits(d, id, bstart, btotal, lane);
     WGS_PROF(6)
     WGS_PROF_END()
 }

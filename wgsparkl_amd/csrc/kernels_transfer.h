@@ -301,9 +301,18 @@ constexpr int G2P_THREADS = 64;
 // stage clocks of the fused G2P main body (tools/gpu_g2p_prof.py): one row per chunk of 64 sorted particles
 constexpr int WGS_G2P_ROWS = 16384;
 __device__ unsigned long long g_g2p_prof[WGS_G2P_ROWS][8];
-#define G2P_PROF(k) if (threadIdx.x == 0 && G2P_CMODE != 2 && chunk < WGS_G2P_ROWS) g_g2p_prof[chunk][k] = wall_clock64();
+// rows [0, R/2): main body, by chunk; [R/2, 3R/4): visits of the list walk (CMODE 2), by position in the visit list;
+// [3R/4, R): one row per list wave — [0] start, [5] end, [1] chunks visited
+#define G2P_PROF(k)                                                                                                   \
+    if (threadIdx.x == 0) {                                                                                           \
+        if (G2P_CMODE != 2 && chunk < WGS_G2P_ROWS / 2) g_g2p_prof[chunk][k] = wall_clock64();                        \
+        if (G2P_CMODE == 2 && run * npass + (uint32_t)pass < WGS_G2P_ROWS / 4)                                        \
+            g_g2p_prof[WGS_G2P_ROWS / 2 + run * npass + (uint32_t)pass][k] = wall_clock64();                          \
+    }
+#define G2P_PROF_LIST(k, v) if (threadIdx.x == 0 && G2P_CMODE == 2 && blockIdx.x < WGS_G2P_ROWS / 4) g_g2p_prof[WGS_G2P_ROWS * 3 / 4 + blockIdx.x][k] = (v);
 #else
 #define G2P_PROF(k)
+#define G2P_PROF_LIST(k, v)
 #endif
 #ifndef G2P_WAVES_PER_EU
 #define G2P_WAVES_PER_EU 3
@@ -322,6 +331,17 @@ __device__ unsigned long long g_g2p_prof[WGS_G2P_ROWS][8];
 // wave life only costs), 2 beyond — there the kernel is bound by latency x occupancy and twice the bytes in flight per
 // wave buy 12-15 % (4.1 M particles: 184 -> 161 us, 16 M: 761 -> 647 us; 1 M: 39.0 -> 41.7 us). Same results either way.
 constexpr uint32_t G2P_TWO_PASS_MIN_PARTICLES = 1500000;
+#ifndef WGS_G2P_LIST_PASSES
+#define WGS_G2P_LIST_PASSES 2
+#endif
+#ifndef WGS_G2P_MANY_PASSES
+#define WGS_G2P_MANY_PASSES 4
+#endif
+#ifndef WGS_G2P_MANY_PASS_MIN
+#define WGS_G2P_MANY_PASS_MIN 3000000
+#endif
+constexpr int G2P_MANY_PASSES = WGS_G2P_MANY_PASSES;
+constexpr uint32_t G2P_MANY_PASS_MIN_PARTICLES = WGS_G2P_MANY_PASS_MIN;
 template <int D, int MODEL, bool PLASTIC, int CMODE, int NPASS = 1>
 __global__ __launch_bounds__(G2P_THREADS, G2P_WAVES_PER_EU) void k_g2p_update(Dev d, int side, uint32_t epoch) {
     constexpr uint32_t npass = NPASS;  // (a template parameter: as a kernel argument the second pass's registers spilled in the one-pass launch)
@@ -329,15 +349,11 @@ __global__ __launch_bounds__(G2P_THREADS, G2P_WAVES_PER_EU) void k_g2p_update(De
     __shared__ NodeCdf s_cdf[CMODE == 2 ? Dim<D>::TILE : 1];
 #define G2P_CMODE CMODE
 #define G2P_BX blockIdx.x
-#define G2P_BY blockIdx.y
 #define G2P_GX gridDim.x
-#define G2P_GY gridDim.y
 #include "g2p_body.inc"
 #undef G2P_CMODE
 #undef G2P_BX
-#undef G2P_BY
 #undef G2P_GX
-#undef G2P_GY
 }
 
 // Collider simulations: the body of CMODE 2 (walk of the near-collider block list) and the body of CMODE 1 (blocks
@@ -360,27 +376,22 @@ __global__ __launch_bounds__(G2P_THREADS, WPE) void k_g2p_pair(Dev d, int side, 
         const uint32_t widx = blockIdx.x - 8u * nlist;
 #define G2P_CMODE 1
 #define G2P_BX widx
-#define G2P_BY 0u
 #define G2P_GX nmain
-#define G2P_GY 1u
 #include "g2p_body.inc"
 #undef G2P_CMODE
 #undef G2P_BX
-#undef G2P_BY
 #undef G2P_GX
-#undef G2P_GY
-    } else {
+    } else {  // the 8 * nlist waves of the visit list
+        // (runs of at most two entries: the CPIC body has no registers left for the deeper prefetch of the main body —
+        // with four, the non-plastic pair spilled 232 B per lane instead of 96 and 16 M particles on a floor lost 5 %)
+        constexpr uint32_t npass = NPASS < WGS_G2P_LIST_PASSES ? NPASS : WGS_G2P_LIST_PASSES;
 #define G2P_CMODE 2
-#define G2P_BX (blockIdx.x & 7u)
-#define G2P_BY (blockIdx.x >> 3)
-#define G2P_GX 8u
-#define G2P_GY nlist
+#define G2P_BX blockIdx.x
+#define G2P_GX (8u * nlist)
 #include "g2p_body.inc"
 #undef G2P_CMODE
 #undef G2P_BX
-#undef G2P_BY
 #undef G2P_GX
-#undef G2P_GY
     }
 }
 #undef G2P_DONE

@@ -109,7 +109,8 @@ enum { CTR_NBLOCKS = 0, CTR_ERRORS = 1, CTR_NPHYS = 2, CTR_NCPIC = 32, CTR_N = 4
        CTR_NPREV = 6,  // sharded runs: slots [0, NPREV) are the sorted output of the last substep, [NPREV, N) arrivals
        CTR_NLEAVE = 7,  // sharded runs: particles the last fused G2P launch found outside the slab (Dev::leavers)
        CTR_NPHYS_SEEN = 8,  // [8], [9]: the id counter as launch 2 of an even / odd substep saw it (kernels_sort.h regroup_block)
-       CTR_COUNT = 48 };
+       CTR_NVISIT = 64,  // [64 + 32 k], k = 0..7: length of the visit list of XCD k (Dev::visit_list), one cache line each
+       CTR_COUNT = 320 };
 enum { ERRBIT_OVERFLOW = 1u, ERRBIT_KEYRANGE = 2u, ERRBIT_SHARD = 4u };
 
 // Everything a kernel needs, passed by value.
@@ -156,6 +157,11 @@ struct Dev {
     uint32_t *block_cdf_flag; // cap: block has a node with non-zero affinity
     uint32_t *block_cpic;     // cap: some node of the block's (BW+2)^D tile has non-zero affinity
     uint32_t *cpic_list;      // cap: particle-bearing blocks with block_cpic set, [0, counters[CTR_NCPIC])
+    uint2 *visit_list;        // 8 x visit_cap: (listed block, chunk of 64 sorted particles that holds some of its particles); list k, at
+                              // [k * visit_cap, + counters[CTR_NVISIT + 32 k]), is the one the CPIC body of the fused G2P advances on
+                              // XCD k (g2p_body.inc); device_math.h append_visits deals the chunks to the lists
+    uint32_t visit_cap;       // per list (an eighth of the chunks + 2 per block would do; a block is visited once per chunk it spans)
+    uint32_t g2p_npass;       // chunks per wave of the fused G2P of this substep (defines the eighths; set by the host per substep)
     uint32_t *counters;    // CTR_COUNT
     const SimParamsDev *sp;
     ColliderDev *colliders;  // poses / velocities are integrated on the device (kernels_bodies.h)
@@ -193,6 +199,12 @@ struct Dev {
 
 __device__ inline uint32_t num_slots(const Dev &d) { return d.sharded ? d.counters[CTR_N] : d.n; }
 __device__ inline uint32_t num_valid(const Dev &d) { return d.sharded ? d.counters[CTR_NV] : d.nv; }
+// Chunks of 64 sorted particles per XCD eighth of the fused G2P: waves advance `npass` consecutive chunks, an XCD gets
+// `per_xcd` consecutive waves' worth (g2p_body.inc; the sort files the visit list by the same rule).
+__device__ inline uint32_t g2p_waves_per_xcd(const Dev &d, uint32_t npass) {
+    const uint32_t span = 64u * npass;
+    return ((num_valid(d) + span - 1u) / span + 7u) >> 3;
+}
 
 // Quad access = (one uniform 64-bit buffer base in SGPRs) + (32-bit per-lane byte offset):
 // `global_load_dwordx4 v[..], v_off, s[base:base+1]`. Valid while one ping-pong buffer is
