@@ -107,6 +107,7 @@ struct wgs_data {
     uint64_t device_bytes = 0;
     uint32_t sticky_errors = 0;
     uint32_t last_nblocks = 0;
+    uint32_t seen_nblocks = 0;         // active blocks as last seen by the host, wgs_sync or the pinned watch (0: not yet): sizes the P2G grid
     uint32_t last_ncpic = UINT32_MAX;  // near-collider list length at the last wgs_sync (picks the P2G launch shape and G2P's register budget)
     uint32_t last_nvisit = UINT32_MAX; // visit-list length at the last wgs_sync (sizes the list half of k_g2p_pair)
     uint32_t capacity = 0;      // particle slots allocated
@@ -272,6 +273,7 @@ wgs_status maintain_grid(wgs_data *d) {
     d->watch_skips = 0;
     d->watch_pending = false;
     const uint32_t nblocks = d->watch[CTR_NBLOCKS], nphys = d->watch[CTR_NPHYS], cap = d->dev.cap;
+    d->seen_nblocks = std::min(nblocks, cap);
     if (d->auto_grow && nblocks > cap / 2u && cap < (1u << 24)) return grow_grid(d, cap * 2u);
     if (nphys > cap / 4u * 3u) d->force_rehash = true;
     return WGS_OK;
@@ -296,6 +298,12 @@ void fill_collider(ColliderDev &c, const wgs_collider &in) {
 
 constexpr uint32_t WGS_LAUNCH_SHAPE_SWITCHES = 128u | 1024u | 4096u | 8192u | 16384u | 32768u | 65536u | 131072u;  // WGS_DEBUG bits the shipped library honours
 constexpr uint32_t P2G_SMALL_BUDGET_MIN_PARTICLES = 600000;  // one-way CPIC P2G body at 168 VGPRs from this size on
+#ifndef WGS_REGROUP_ROUNDS
+#define WGS_REGROUP_ROUNDS 4u
+#endif
+#ifndef WGS_GU_WG_PER_CU
+#define WGS_GU_WG_PER_CU 8
+#endif
 constexpr uint32_t P2G_PAIR_MIN_BLOCKS = 8;  // near-collider blocks from which P2G runs both bodies in one launch
 int grid_for(const wgs_data *d, int blocks_per_cu) { return d->pipeline->num_cus * blocks_per_cu; }
 
@@ -562,6 +570,7 @@ wgs_status fetch_counters(wgs_data *d) {
     HIP_TRY(hipMemcpyAsync(host, d->dev.counters, sizeof(host), hipMemcpyDeviceToHost, d->stream));
     HIP_TRY(hipStreamSynchronize(d->stream));
     d->last_nblocks = host[CTR_NBLOCKS] < d->dev.cap ? host[CTR_NBLOCKS] : d->dev.cap;
+    d->seen_nblocks = d->last_nblocks;
     d->last_ncpic = host[CTR_NCPIC] < d->dev.cap ? host[CTR_NCPIC] : d->dev.cap;
     d->last_nvisit = 0;  // the longest of the eight lists
     for (int k = 0; k < 8; k++) d->last_nvisit = std::max(d->last_nvisit, std::min(host[CTR_NVISIT + 32 * k], d->dev.visit_cap));
@@ -699,7 +708,7 @@ template <bool TS> wgs_status enqueue_substep(wgs_data *d, int ts_slot, int part
             {
                 const uint32_t nscan = (dev.cap + SCAN_CHUNK - 1) / SCAN_CHUNK;
                 // one resident round: 4 workgroups per CU (127 VGPRs, 36 KB of LDS), the scan workgroups among them
-                const uint32_t nreg = std::max(1u, std::min((dev.cap + 3u) / 4u, (uint32_t)grid_for(d, 4) - std::min(nscan, (uint32_t)grid_for(d, 2))));
+                const uint32_t nreg = std::max(1u, std::min((dev.cap + 3u) / 4u, WGS_REGROUP_ROUNDS * ((uint32_t)grid_for(d, 4) - std::min(nscan, (uint32_t)grid_for(d, 2)))));
                 const dim3 g(nscan + nreg);
                 if (fused_cdf) hipLaunchKernelGGL((k_regroup<D, true>), g, dim3(SORT_THREADS), 0, s, dev, side, epoch, nscan, use_rebin ? 1 : 0);
                 else hipLaunchKernelGGL((k_regroup<D, false>), g, dim3(SORT_THREADS), 0, s, dev, side, epoch, nscan, use_rebin ? 1 : 0);
@@ -718,14 +727,20 @@ template <bool TS> wgs_status enqueue_substep(wgs_data *d, int ts_slot, int part
         mark(3);
         if (n > 0) {
             // ---- "p2g"
-            const dim3 p2g_grid(grid_for(d, 5)), p2g_block(P2GCfg<D>::NW * 64);
+            // Workgroups per body: about one per two entries of the block list (as the host last saw it), between 8 and
+            // 32 per CU. A workgroup strides over the list, and the dispatcher balances better than a fixed stride does:
+            // blocks differ in cost, and with 5 per CU — one resident round and a quarter — the quarter started when the
+            // first workgroups retired (C5, 16 M particles: P2G 472 -> 346 us; C2: 35.6 -> 31.8 us). Same results for
+            // any grid: a block's slab is the work of one workgroup.
+            const uint32_t p2g_wgs = std::min((uint32_t)grid_for(d, 32), std::max((uint32_t)grid_for(d, 8), (d->seen_nblocks / 2u + 255u) & ~255u));
+            const dim3 p2g_grid(p2g_wgs), p2g_block(P2GCfg<D>::NW * 64);
             // Large one-way collider simulations ALWAYS run the paired launch, with the CPIC body cut to 168 VGPRs: the
             // plain body then keeps its occupancy, so the pair costs nothing while the list is empty, and the choice
             // does not follow the host's syncs (the two budgets differ in the last bit here and there).
             const bool big_one_way = !d->two_way && n >= P2G_SMALL_BUDGET_MIN_PARTICLES && !(dev.dbg & 32768u);
             if (d->cpic && (big_one_way || (d->last_ncpic != UINT32_MAX && d->last_ncpic >= P2G_PAIR_MIN_BLOCKS)) && !(dev.dbg & 8192u)) {
                 // many blocks near colliders (as of the last wgs_sync): both bodies in one launch (k_p2g_pair)
-                const dim3 pair_grid(2u * (uint32_t)grid_for(d, 5));
+                const dim3 pair_grid(2u * p2g_wgs);
                 if (d->two_way) hipLaunchKernelGGL((k_p2g_pair<D, true>), pair_grid, p2g_block, 0, s, dev, side, epoch);
                 else if (big_one_way) hipLaunchKernelGGL((k_p2g_pair<D, false, 3>), pair_grid, p2g_block, 0, s, dev, side, epoch);
                 else hipLaunchKernelGGL((k_p2g_pair<D, false>), pair_grid, p2g_block, 0, s, dev, side, epoch);
@@ -742,18 +757,18 @@ template <bool TS> wgs_status enqueue_substep(wgs_data *d, int ts_slot, int part
         mark(4);
         // sharded runs: the interface layers are gathered by wgs_shard_pack_halos (fused protocol); the per-face
         // wgs_shard_pack_halo needs the gather-only pass
-        if (part == 1 && n > 0 && !d->fused_halo) hipLaunchKernelGGL((k_grid_update<D, 1>), dim3(grid_for(d, 4)), dim3(256), 0, s, dev);
+        if (part == 1 && n > 0 && !d->fused_halo) hipLaunchKernelGGL((k_grid_update<D, 1>), dim3(grid_for(d, WGS_GU_WG_PER_CU)), dim3(256), 0, s, dev);
     }
     if (part != 1) {
         if (n > 0) {
             // ---- "grid_update"
             if (part == 0 && d->two_way)
-                hipLaunchKernelGGL((k_grid_update<D, 0, true>), dim3(grid_for(d, 4)), dim3(256), 0, s, dev);
-            else if (part == 0) hipLaunchKernelGGL((k_grid_update<D, 0>), dim3(grid_for(d, 4)), dim3(256), 0, s, dev);
-            else if (d->fused_halo && d->two_way) hipLaunchKernelGGL((k_grid_update<D, 3, true>), dim3(grid_for(d, 4)), dim3(256), 0, s, dev);
-            else if (d->fused_halo) hipLaunchKernelGGL((k_grid_update<D, 3>), dim3(grid_for(d, 4)), dim3(256), 0, s, dev);
+                hipLaunchKernelGGL((k_grid_update<D, 0, true>), dim3(grid_for(d, WGS_GU_WG_PER_CU)), dim3(256), 0, s, dev);
+            else if (part == 0) hipLaunchKernelGGL((k_grid_update<D, 0>), dim3(grid_for(d, WGS_GU_WG_PER_CU)), dim3(256), 0, s, dev);
+            else if (d->fused_halo && d->two_way) hipLaunchKernelGGL((k_grid_update<D, 3, true>), dim3(grid_for(d, WGS_GU_WG_PER_CU)), dim3(256), 0, s, dev);
+            else if (d->fused_halo) hipLaunchKernelGGL((k_grid_update<D, 3>), dim3(grid_for(d, WGS_GU_WG_PER_CU)), dim3(256), 0, s, dev);
             else if (d->two_way) return fail(WGS_ERR_UNSUPPORTED, "two-way coupling on sharded data needs the fused halo protocol (wgs_shard_register_buffers / wgs_shard_attach)");
-            else hipLaunchKernelGGL((k_grid_update<D, 2>), dim3(grid_for(d, 4)), dim3(256), 0, s, dev);
+            else hipLaunchKernelGGL((k_grid_update<D, 2>), dim3(grid_for(d, WGS_GU_WG_PER_CU)), dim3(256), 0, s, dev);
         }
         mark(5);
         if (dev.nv > 0) {
