@@ -338,7 +338,7 @@ constexpr uint32_t G2P_TWO_PASS_MIN_PARTICLES = 1500000;
 #define WGS_G2P_MANY_PASSES 4
 #endif
 #ifndef WGS_G2P_MANY_PASS_MIN
-#define WGS_G2P_MANY_PASS_MIN 3000000
+#define WGS_G2P_MANY_PASS_MIN 2500000
 #endif
 constexpr int G2P_MANY_PASSES = WGS_G2P_MANY_PASSES;
 constexpr uint32_t G2P_MANY_PASS_MIN_PARTICLES = WGS_G2P_MANY_PASS_MIN;
