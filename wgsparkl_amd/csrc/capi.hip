@@ -205,7 +205,7 @@ wgs_status alloc_grid(wgs_data *d) {
     GRID_ALLOC(&dev.slab, cap * Dim<D>::TILE);
     GRID_ALLOC(&dev.block_cdf_flag, cap);
     GRID_ALLOC(&dev.block_cpic, cap);
-    GRID_ALLOC(&dev.cpic_list, cap);
+    GRID_ALLOC(&dev.cpic_list, (size_t)cap * 8);
     dev.visit_cap = dev.npad / 512u + 2u * cap + 16u;
     GRID_ALLOC(&dev.visit_list, (size_t)dev.visit_cap * 8);
     if (d->two_way) GRID_ALLOC(&dev.imp_slab, cap * Dim<D>::TILE * (D == 3 ? 2 : 1));
@@ -571,7 +571,9 @@ wgs_status fetch_counters(wgs_data *d) {
     HIP_TRY(hipStreamSynchronize(d->stream));
     d->last_nblocks = host[CTR_NBLOCKS] < d->dev.cap ? host[CTR_NBLOCKS] : d->dev.cap;
     d->seen_nblocks = d->last_nblocks;
-    d->last_ncpic = host[CTR_NCPIC] < d->dev.cap ? host[CTR_NCPIC] : d->dev.cap;
+    d->last_ncpic = 0;  // the eight lists together
+    for (int k = 0; k < 8; k++) d->last_ncpic += std::min(host[CTR_NCPIC + 32 * k], d->dev.cap);
+    d->last_ncpic = std::min(d->last_ncpic, d->dev.cap);
     d->last_nvisit = 0;  // the longest of the eight lists
     for (int k = 0; k < 8; k++) d->last_nvisit = std::max(d->last_nvisit, std::min(host[CTR_NVISIT + 32 * k], d->dev.visit_cap));
     d->sticky_errors |= host[CTR_ERRORS];

@@ -75,7 +75,7 @@ template <int D, int TAIL> __global__ __launch_bounds__(SORT_THREADS) void k_bin
     const float *in = d.buf[side];
     const int tid = threadIdx.x, lane = tid & 63;
     if (tid < TOUCH_SET) s_keys[tid] = NONE;
-    if (blockIdx.x == 0 && tid < 9) d.counters[tid == 8 ? (int)CTR_NCPIC : (int)CTR_NVISIT + 32 * tid] = 0;  // near-collider lists of this substep (k_regroup appends)
+    if (blockIdx.x == 0 && tid < 16) d.counters[(tid < 8 ? (int)CTR_NCPIC : (int)CTR_NVISIT - 256) + 32 * tid] = 0;  // near-collider lists of this substep (k_regroup appends)
     __syncthreads();
     const uint32_t first = tail ? d.counters[CTR_NPREV] : 0u;
     const uint32_t i = first + blockIdx.x * SORT_THREADS + tid;
@@ -189,7 +189,7 @@ template <int D> __global__ __launch_bounds__(SORT_THREADS) void k_rebin(Dev d, 
     const float *in = d.buf[side];
     const int tid = threadIdx.x, lane = tid & 63;
     const uint32_t i = blockIdx.x * SORT_THREADS + tid;
-    if (blockIdx.x == 0 && tid < 9) d.counters[tid == 8 ? (int)CTR_NCPIC : (int)CTR_NVISIT + 32 * tid] = 0;  // near-collider lists of this substep (k_regroup appends)
+    if (blockIdx.x == 0 && tid < 16) d.counters[(tid < 8 ? (int)CTR_NCPIC : (int)CTR_NVISIT - 256) + 32 * tid] = 0;  // near-collider lists of this substep (k_regroup appends)
     // sharded runs: the residents only (arrivals have no previous cell: k_bin's tail pass), minus the slots
     // vacated by particles that migrated away
     const bool in_range = i < (d.sharded ? min(d.counters[CTR_NPREV], d.counters[CTR_N]) : num_slots(d));
@@ -560,7 +560,7 @@ __device__ __forceinline__ void regroup_block(const Dev &d, int side, uint32_t e
         const bool any = __ballot(mine != 0u) != 0ull;
         if (lane == 0) {
             d.block_cpic[id] = any ? 1u : 0u;
-            if (any && btotal > 0u) d.cpic_list[atomicAdd(&d.counters[CTR_NCPIC], 1u)] = id;  // few blocks
+            if (any && btotal > 0u) d.cpic_list[(size_t)(id & 7u) * d.cap + atomicAdd(&d.counters[CTR_NCPIC + 32u * (id & 7u)], 1u)] = id;
         }
         listed = any && btotal > 0u;
     }

@@ -103,14 +103,15 @@ struct NodeCdf {        // grid.wgsl:233-240
 };
 
 // Counter slots in Dev::counters
-// (CTR_NCPIC sits in a cache line of its own: thousands of waves add to it in launch 2 of a collider-heavy scene while every
-// wave of that launch reads the counters of the first line; sharing a line made those reads queue behind the atomics)
-enum { CTR_NBLOCKS = 0, CTR_ERRORS = 1, CTR_NPHYS = 2, CTR_NCPIC = 32, CTR_N = 4, CTR_NV = 5,
+// (the list counters sit in cache lines of their own: thousands of waves add to them in launch 2 of a collider-heavy scene while
+// every wave of that launch reads the counters of the first line; sharing a line made those reads queue behind the atomics)
+enum { CTR_NBLOCKS = 0, CTR_ERRORS = 1, CTR_NPHYS = 2, CTR_N = 4, CTR_NV = 5,
        CTR_NPREV = 6,  // sharded runs: slots [0, NPREV) are the sorted output of the last substep, [NPREV, N) arrivals
        CTR_NLEAVE = 7,  // sharded runs: particles the last fused G2P launch found outside the slab (Dev::leavers)
        CTR_NPHYS_SEEN = 8,  // [8], [9]: the id counter as launch 2 of an even / odd substep saw it (kernels_sort.h regroup_block)
        CTR_NVISIT = 64,  // [64 + 32 k], k = 0..7: length of the visit list of XCD k (Dev::visit_list), one cache line each
-       CTR_COUNT = 320 };
+       CTR_NCPIC = 320,  // [320 + 32 k], k = 0..7: length of list k of the near-collider blocks (Dev::cpic_list), one cache line each
+       CTR_COUNT = 576 };
 enum { ERRBIT_OVERFLOW = 1u, ERRBIT_KEYRANGE = 2u, ERRBIT_SHARD = 4u };
 
 // Everything a kernel needs, passed by value.
@@ -156,7 +157,8 @@ struct Dev {
     float4 *slab;          // cap*TILE: per-block tile (block + its "+1" rim): momentum after P2G, velocity after the grid update
     uint32_t *block_cdf_flag; // cap: block has a node with non-zero affinity
     uint32_t *block_cpic;     // cap: some node of the block's (BW+2)^D tile has non-zero affinity
-    uint32_t *cpic_list;      // cap: particle-bearing blocks with block_cpic set, [0, counters[CTR_NCPIC])
+    uint32_t *cpic_list;      // 8 x cap: particle-bearing blocks with block_cpic set; list k = (block id & 7) at [k * cap, + counters[CTR_NCPIC + 32 k]):
+                              // eight lists because thousands of returning atomics on ONE counter serialise in the fabric
     uint2 *visit_list;        // 8 x visit_cap: (listed block, chunk of 64 sorted particles that holds some of its particles); list k, at
                               // [k * visit_cap, + counters[CTR_NVISIT + 32 k]), is the one the CPIC body of the fused G2P advances on
                               // XCD k (g2p_body.inc); device_math.h append_visits deals the chunks to the lists
