@@ -28,7 +28,12 @@ constexpr int P2G_J = 4;
 // stage clocks of P2G (timing experiments, tools/gpu_p2g_prof.py): one row per active-list index of the plain body
 constexpr int WGS_P2G_ROWS = 8192;
 __device__ unsigned long long g_p2g_prof[WGS_P2G_ROWS][8];
-#define P2G_PROF(k) if (threadIdx.x == 0 && filter != 2 && a < WGS_P2G_ROWS) g_p2g_prof[a][k] = wall_clock64();
+// rows [0, R/2): plain body, by list position; [R/2, R): CPIC body over the near-collider lists (8 x R/16 rows)
+#define P2G_PROF(k)                                                                                               \
+    if (threadIdx.x == 0) {                                                                                       \
+        if (filter != 2 && a < WGS_P2G_ROWS / 2) g_p2g_prof[a][k] = wall_clock64();                               \
+        if (filter == 2 && a < WGS_P2G_ROWS / 16) g_p2g_prof[WGS_P2G_ROWS / 2 + (P2G_BLK & 7u) * (WGS_P2G_ROWS / 16) + a][k] = wall_clock64(); \
+    }
 #else
 #define P2G_PROF(k)
 #endif
