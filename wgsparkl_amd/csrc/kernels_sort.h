@@ -543,6 +543,11 @@ __device__ __forceinline__ void regroup_block(const Dev &d, int side, uint32_t e
                 near |= (inside || !(n2 > reach * reach)) ? (1u << i) : 0u;
             }
         }
+        if (near == 0u) {
+            // no collider in reach of the tile (nearly every block): its own 64 nodes get the "far" cdf — lane = node —
+            // and the rim, which belongs to the neighbours, is theirs to write
+            d.node_cdf[(size_t)id * NPB + (uint32_t)lane] = NodeCdf{1.0e10f, 0u, NONE, 0u};
+        } else
         for (int n = lane; n < ((TILE + 63) / 64) * 64; n += 64) {
             int t[3] = {n % TW, (n / TW) % TW, D == 3 ? n / (TW * TW) : 0};
             const int o = (t[0] >= BW ? 1 : 0) | (t[1] >= BW ? 2 : 0) | (t[2] >= BW ? 4 : 0);
@@ -551,8 +556,7 @@ __device__ __forceinline__ void regroup_block(const Dev &d, int side, uint32_t e
                 float pt[D];
 #pragma unroll
                 for (int k = 0; k < D; k++) pt[k] = (float)(b[k] * BW + t[k]) * d.h;
-                const NodeCdf far_cdf = {1.0e10f, 0u, NONE, 0u};
-                const NodeCdf c = near ? node_cdf_eval<D>(d, pt, near) : far_cdf;
+                const NodeCdf c = node_cdf_eval<D>(d, pt, near);
                 if (o == 0) d.node_cdf[(size_t)id * NPB + (t[0] + (t[1] << BS) + (D == 3 ? (t[2] << (2 * BS)) : 0))] = c;
                 mine |= c.affinities;
             }
