@@ -97,6 +97,7 @@ __device__ inline void append_visits(const Dev &d, uint32_t id, uint32_t start, 
         const uint32_t slot = atomicAdd(&d.counters[CTR_NVISIT + 32u * k], n);
         for (uint32_t e = 0; e < n; e++)
             if (slot + e < d.visit_cap) d.visit_list[(size_t)k * d.visit_cap + slot + e] = make_uint2(id, cs + e);
+            else atomicOr(&d.counters[CTR_ERRORS], ERRBIT_OVERFLOW);  // (cannot happen within the capacity the lists are sized for; never silently)
     }
 }
 
