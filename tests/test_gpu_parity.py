@@ -229,6 +229,37 @@ def test_dense_blocks_take_the_global_memory_paths_of_the_sort(hip_libs, oracle_
         assert np.array_equal(getattr(a, f), getattr(b, f)), f
 
 
+def test_visit_list_many_listed_blocks_per_chunk(hip_libs, oracle_libs, monkeypatch):
+    """The CPIC body of the fused G2P advances a visit list: one entry per (block near a collider, chunk of 64 sorted
+    particles holding some of its particles), dealt to eight lists (kernels_sort.h / device_math.h append_visits). A thin,
+    sparse sheet of particles over a floor — two or three particles per block, a few hundred listed blocks, so every chunk
+    holds dozens of listed blocks and is visited once for each — next to a compact clump (blocks spanning several chunks):
+    against the oracle, and bit-identical with two and with one chunk per wave of the main body (other list groupings)."""
+    h = 1.0
+    rng = np.random.default_rng(91)
+    sheet = np.stack([rng.uniform(4.0, 90.0, 700), rng.uniform(2.3, 3.4, 700), rng.uniform(4.0, 90.0, 700)], -1)
+    ax = (np.arange(16, dtype=np.float64) + 0.5) * (h / 2.0) + 40.0
+    clump = np.stack(np.meshgrid(ax, (np.arange(10) + 0.5) * (h / 2.0) + 2.3, ax, indexing="ij"), -1).reshape(-1, 3)
+    pos = np.concatenate([sheet, clump + rng.uniform(-0.05, 0.05, clump.shape)]).astype(np.float32)
+    ps = ParticleSet.uniform(pos, h / 4.0, 1000.0, ElasticCoefficients.from_young_modulus(2.0e5, 0.3), phase=ParticlePhase(1.0, -1.0))
+    ps.vel[:] = rng.normal(0.0, 1.0, ps.vel.shape).astype(np.float32)
+    ps.vel[:, 1] -= 3.0
+    sc = dict(particles=ps, params=SimulationParams(gravity=(0.0, -9.81, 0.0), dt=1.0e-3),
+              colliders=[Collider.cuboid((1000.0, 2.0, 1000.0), (0.0, 0.0, 0.0))], cell_width=h, grid_capacity=4096, model=MODEL_NEO_HOOKEAN)
+    k = 12
+    data = run_gpu(sc, k)
+    st = data.stats()
+    assert st["num_near_collider_blocks"] > 300 and st["num_near_collider_blocks"] * 64 > ps.n   # far more listed blocks than chunks
+    st32, st64 = run_oracle(sc, k, np.float32), run_oracle(sc, k, np.float64)
+    check_blocks(data, st32)
+    got, same = compare_cpic(data, st32, st64, 3, CPIC_GRID_V_TOL, CPIC_PART_TOL, min_same=0.995)
+    assert (got.cdf_affinity & 1).sum() > 500
+    monkeypatch.setenv("WGS_DEBUG", "131072")
+    b = run_gpu(sc, k).read_particles()
+    for f in ("pos", "vel", "def_grad", "affine", "cdf_affinity"):
+        assert np.array_equal(getattr(got, f), getattr(b, f)), f
+
+
 def test_determinism(hip_libs):
     sc = cloud_scene(n=30000, seed=11)
     a = run_gpu(sc, 5).read_particles()
