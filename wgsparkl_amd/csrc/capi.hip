@@ -645,7 +645,8 @@ template <bool TS> wgs_status enqueue_substep(wgs_data *d, int ts_slot, int part
     };
     const uint32_t epoch = (uint32_t)(d->substeps + 1);
     // chunks of 64 sorted particles per wave of the fused G2P (kernels_transfer.h); the sort files the visit list by it
-    dev.g2p_npass = dev.nv >= G2P_MANY_PASS_MIN_PARTICLES ? (uint32_t)G2P_MANY_PASSES
+    // (2D: the body keeps no state of the chunk after the next one — at most two chunks per wave)
+    dev.g2p_npass = (D == 3 && dev.nv >= G2P_MANY_PASS_MIN_PARTICLES) ? (uint32_t)G2P_MANY_PASSES
                     : (dev.nv >= G2P_TWO_PASS_MIN_PARTICLES || (dev.dbg & 131072u)) ? 2u : 1u;
     // Steady state: the buffer is in the sorted order of the previous substep, whose block ids, cell ids
     // (perm_cell) and neighbour links are still valid, so the particles are re-binned RELATIVE to their old
