@@ -797,7 +797,7 @@ template <bool TS> wgs_status enqueue_substep(wgs_data *d, int ts_slot, int part
             const uint32_t full = (uint32_t)grid_for(d, 1) * 3u / 2u;                                             \
             const uint32_t nlist = d->last_nvisit == UINT32_MAX ? full : std::min(full, std::max(8u, 2u * ((d->last_nvisit + (NP) - 1u) / (NP)))); \
             /* plastic scenes with a large share of listed blocks: the spill-free variant (kernels_transfer.h) */  \
-            if (PL && d->last_ncpic != UINT32_MAX && d->last_ncpic * 5u >= std::max(1u, d->last_nblocks) && !(dev.dbg & 16384u)) \
+            if (PL && d->last_ncpic != UINT32_MAX && d->last_ncpic * 2u >= std::max(1u, d->last_nblocks) && !(dev.dbg & 16384u)) \
                 hipLaunchKernelGGL((k_g2p_pair<D, MODEL, PL, (PL) ? WGS_PLASTIC_WPE_DENSE : G2P_WAVES_PER_EU, NP>), dim3((uint32_t)g + 8u * nlist), \
                                    dim3(G2P_THREADS), 0, s, dev, side, epoch, (uint32_t)g, nlist);                \
             else                                                                                                  \

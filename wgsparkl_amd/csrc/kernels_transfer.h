@@ -369,9 +369,11 @@ __global__ __launch_bounds__(G2P_THREADS, G2P_WAVES_PER_EU) void k_g2p_update(De
 // dependent kernel boundary costs even when the list is empty. `nlist` follows the list length the host last saw
 // (wgs_sync), so an empty list costs a few hundred workgroups that exit at once.
 // WPE (waves per SIMD the register budget is cut for): 3 everywhere, except that the Drucker-Prager CPIC body spills
-// ~350 B per lane under that cap; with 2 (256 VGPRs, no spills) a scene whose near-collider blocks are a third of all
-// blocks (4 M sand between a floor and four walls) runs its G2P 16 % faster, while scenes with few such blocks lose
-// 5-12 % to the lower occupancy of the main body: capi.hip picks by the share of listed blocks the host last saw.
+// ~350 B per lane under that cap; with 2 (256 VGPRs, no spills) the list half runs faster and the main half slower
+// (lower occupancy). capi.hip picks 2 when half of the active blocks or more are listed, as of the host's last look.
+// (With the list half as it was in the middle of round 2 — chunk lanes on XCDs, 27-term stencil for every particle —
+// a third of the blocks listed was already enough: 4 M sand between walls 16 % faster; since the visit lists and the
+// per-particle choice of the stencil that scene is 4.5 % faster with 3: 362-371 -> 346-351 us.)
 template <int D, int MODEL, bool PLASTIC, int WPE = G2P_WAVES_PER_EU, int NPASS = 1>
 __global__ __launch_bounds__(G2P_THREADS, WPE) void k_g2p_pair(Dev d, int side, uint32_t epoch, uint32_t nmain, uint32_t nlist) {
     constexpr uint32_t npass = NPASS;
