@@ -273,8 +273,15 @@ wgs_status maintain_grid(wgs_data *d) {
     d->watch_skips = 0;
     d->watch_pending = false;
     const uint32_t nblocks = d->watch[CTR_NBLOCKS], nphys = d->watch[CTR_NPHYS], cap = d->dev.cap;
+    // The observation is up to three calls old (two skips + the call that made it): a scene that is growing is judged by
+    // where it will be by then at the rate of its last two observations, not by where it was.
+    const uint32_t rate = nblocks > d->seen_nblocks && d->seen_nblocks != 0u ? nblocks - d->seen_nblocks : 0u;
     d->seen_nblocks = std::min(nblocks, cap);
-    if (d->auto_grow && nblocks > cap / 2u && cap < (1u << 24)) return grow_grid(d, cap * 2u);
+    if (d->auto_grow && (uint64_t)nblocks + 3ull * rate > cap / 2u && cap < (1u << 24)) {
+        uint32_t new_cap = cap * 2u;
+        while ((uint64_t)nblocks + 3ull * rate > new_cap / 2u && new_cap < (1u << 24)) new_cap *= 2u;
+        return grow_grid(d, new_cap);
+    }
     if (nphys > cap / 4u * 3u) d->force_rehash = true;
     return WGS_OK;
 }
@@ -689,12 +696,20 @@ template <bool TS> wgs_status enqueue_substep(wgs_data *d, int ts_slot, int part
             hipLaunchKernelGGL(k_rigid_transform<D>, dim3(grid_for(d, 1)), dim3(256), 0, s, dev);
         if (n > 0) {
             if (use_rebin) {
-                if (!d->residents_binned) hipLaunchKernelGGL(k_rebin<D>, dim3(pgrid), dim3(SORT_THREADS), 0, s, dev, side, epoch);
-                if (dev.sharded && d->tail_known && d->tail_slots > 0) {  // the particles that arrived from the neighbours: append + bin
-                    const dim3 tg((d->tail_slots + SORT_THREADS - 1) / SORT_THREADS);
-                    if (d->append_pending) hipLaunchKernelGGL((k_bin<D, 2>), tg, dim3(SORT_THREADS), 0, s, dev, side, epoch, d->mig);
-                    else hipLaunchKernelGGL((k_bin<D, 1>), tg, dim3(SORT_THREADS), 0, s, dev, side, epoch, MigIn{});
+                const bool tail = dev.sharded && d->tail_known && d->tail_slots > 0;  // particles arrived from the neighbours: append + bin
+                const dim3 tg((d->tail_slots + SORT_THREADS - 1) / SORT_THREADS);
+                if (!d->residents_binned && tail) {  // both in one launch (k_rebin_tail)
+                    const dim3 both((uint32_t)pgrid + tg.x);
+                    if (d->append_pending) hipLaunchKernelGGL((k_rebin_tail<D, 2>), both, dim3(SORT_THREADS), 0, s, dev, side, epoch, d->mig, (uint32_t)pgrid);
+                    else hipLaunchKernelGGL((k_rebin_tail<D, 1>), both, dim3(SORT_THREADS), 0, s, dev, side, epoch, MigIn{}, (uint32_t)pgrid);
                     d->append_pending = false;
+                } else {
+                    if (!d->residents_binned) hipLaunchKernelGGL(k_rebin<D>, dim3(pgrid), dim3(SORT_THREADS), 0, s, dev, side, epoch);
+                    if (tail) {
+                        if (d->append_pending) hipLaunchKernelGGL((k_bin<D, 2>), tg, dim3(SORT_THREADS), 0, s, dev, side, epoch, d->mig);
+                        else hipLaunchKernelGGL((k_bin<D, 1>), tg, dim3(SORT_THREADS), 0, s, dev, side, epoch, MigIn{});
+                        d->append_pending = false;
+                    }
                 }
             } else {
                 wgs_status fst = flush_append(d);  // (the full pass reads the appended particles from the buffer)

@@ -68,26 +68,27 @@ struct MigIn {
     const float *in_lo, *in_hi, *out_lo, *out_hi;
     uint32_t cap;
 };
-template <int D, int TAIL> __global__ __launch_bounds__(SORT_THREADS) void k_bin(Dev d, int side, uint32_t epoch, MigIn mig) {
+// (body as a function of the workgroup index `bid`: k_bin runs it alone, k_rebin_tail behind the re-binning workgroups)
+template <int D, int TAIL> __device__ __forceinline__ void bin_body(const Dev &d, int side, uint32_t epoch, const MigIn &mig, uint32_t bid) {
     constexpr int tail = TAIL;  // 0 = every slot, 1 = the arrivals (already appended), 2 = append + bin the arrivals
     constexpr int BS = Dim<D>::BSHIFT, BW = Dim<D>::BW, NN = Dim<D>::NNBR;
     __shared__ uint32_t s_keys[TOUCH_SET], s_ids[TOUCH_SET];
     const float *in = d.buf[side];
     const int tid = threadIdx.x, lane = tid & 63;
     if (tid < TOUCH_SET) s_keys[tid] = NONE;
-    if (blockIdx.x == 0 && tid < 16) d.counters[(tid < 8 ? (int)CTR_NCPIC : (int)CTR_NVISIT - 256) + 32 * tid] = 0;  // near-collider lists of this substep (k_regroup appends)
+    if (bid == 0u && tid < 16) d.counters[(tid < 8 ? (int)CTR_NCPIC : (int)CTR_NVISIT - 256) + 32 * tid] = 0;  // near-collider lists of this substep (k_regroup appends)
     __syncthreads();
     const uint32_t first = tail ? d.counters[CTR_NPREV] : 0u;
-    const uint32_t i = first + blockIdx.x * SORT_THREADS + tid;
+    const uint32_t i = first + bid * SORT_THREADS + tid;
     uint32_t slots_end = num_slots(d);
     if constexpr (TAIL == 2) {
         constexpr int NQ = Pl<D>::NQ, RF = Pl<D>::NQ * 4 + 2;  // record = quads, pid, cdf epoch (kernels_shard.h)
         auto cnt = [&](const float *b) { return b ? min(reinterpret_cast<const uint32_t *>(b)[0], mig.cap) : 0u; };
         const uint32_t n_lo = cnt(mig.in_lo), n_hi = cnt(mig.in_hi);
         const uint32_t arrivals = min(n_lo + n_hi, d.n - first);  // d.n = allocated capacity in sharded mode
-        if (n_lo + n_hi > arrivals && blockIdx.x == 0 && tid == 0) atomicOr(&d.counters[CTR_ERRORS], ERRBIT_SHARD);
+        if (n_lo + n_hi > arrivals && bid == 0u && tid == 0) atomicOr(&d.counters[CTR_ERRORS], ERRBIT_SHARD);
         slots_end = first + arrivals;
-        if (blockIdx.x == 0 && tid == 0) {  // nothing else in this launch reads these two
+        if (bid == 0u && tid == 0) {  // nothing else in this launch reads these two
             d.counters[CTR_N] = slots_end;
             d.counters[CTR_NV] = first - cnt(mig.out_lo) - cnt(mig.out_hi) + arrivals;
         }
@@ -177,6 +178,9 @@ template <int D, int TAIL> __global__ __launch_bounds__(SORT_THREADS) void k_bin
         if (cid != NONE) push_mover(d, cid, i);
     }
 }
+template <int D, int TAIL> __global__ __launch_bounds__(SORT_THREADS) void k_bin(Dev d, int side, uint32_t epoch, MigIn mig) {
+    bin_body<D, TAIL>(d, side, epoch, mig, blockIdx.x);
+}
 
 // Steady-state launch 1 (sort.wgsl:26-36,89-99 for a buffer that is the sorted output of the previous
 // substep): slot i held cell perm_cell[i] of block b = perm_cell[i] >> 6 one substep ago, particles move
@@ -184,12 +188,12 @@ template <int D, int TAIL> __global__ __launch_bounds__(SORT_THREADS) void k_bin
 // b * 64 + new local cell and the blocks to activate are b's neighbour links of the previous substep —
 // no hash lookup, no LDS set. Only particles that changed block go through the hash map, and only particles
 // that changed CELL are pushed on a list.
-template <int D> __global__ __launch_bounds__(SORT_THREADS) void k_rebin(Dev d, int side, uint32_t epoch) {
+template <int D> __device__ __forceinline__ void rebin_body(const Dev &d, int side, uint32_t epoch, uint32_t bid) {
     constexpr int BS = Dim<D>::BSHIFT, BW = Dim<D>::BW, NN = Dim<D>::NNBR;
     const float *in = d.buf[side];
     const int tid = threadIdx.x, lane = tid & 63;
-    const uint32_t i = blockIdx.x * SORT_THREADS + tid;
-    if (blockIdx.x == 0 && tid < 16) d.counters[(tid < 8 ? (int)CTR_NCPIC : (int)CTR_NVISIT - 256) + 32 * tid] = 0;  // near-collider lists of this substep (k_regroup appends)
+    const uint32_t i = bid * SORT_THREADS + tid;
+    if (bid == 0u && tid < 16) d.counters[(tid < 8 ? (int)CTR_NCPIC : (int)CTR_NVISIT - 256) + 32 * tid] = 0;  // near-collider lists of this substep (k_regroup appends)
     // sharded runs: the residents only (arrivals have no previous cell: k_bin's tail pass), minus the slots
     // vacated by particles that migrated away
     const bool in_range = i < (d.sharded ? min(d.counters[CTR_NPREV], d.counters[CTR_N]) : num_slots(d));
@@ -247,6 +251,17 @@ template <int D> __global__ __launch_bounds__(SORT_THREADS) void k_rebin(Dev d, 
         d.cellid[i] = cid;
         if (cid != NONE && cid != old) push_mover(d, cid, i);
     }
+}
+template <int D> __global__ __launch_bounds__(SORT_THREADS) void k_rebin(Dev d, int side, uint32_t epoch) {
+    rebin_body<D>(d, side, epoch, blockIdx.x);
+}
+// Sharded steady state: the residents re-binned (first `nrebin` workgroups) and the particles that arrived from the
+// neighbours appended + binned (the others) in ONE launch — a dependent launch costs ~4.5 us whatever it does, and the
+// two touch different slots (shared state only through atomics; CTR_N only grows in this launch and the re-binning
+// workgroups bound their range by min(CTR_NPREV, CTR_N)).
+template <int D, int TAIL> __global__ __launch_bounds__(SORT_THREADS) void k_rebin_tail(Dev d, int side, uint32_t epoch, MigIn mig, uint32_t nrebin) {
+    if (blockIdx.x < nrebin) rebin_body<D>(d, side, epoch, blockIdx.x);
+    else bin_body<D, TAIL>(d, side, epoch, mig, blockIdx.x - nrebin);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
