@@ -208,6 +208,7 @@ wgs_status alloc_grid(wgs_data *d) {
     GRID_ALLOC(&dev.cpic_list, (size_t)cap * 8);
     dev.visit_cap = dev.npad / 512u + 2u * cap + 16u;
     GRID_ALLOC(&dev.visit_list, (size_t)dev.visit_cap * 8);
+    if (dev.sharded) GRID_ALLOC(&dev.halo_list, (size_t)cap * 2);
     if (d->two_way) GRID_ALLOC(&dev.imp_slab, cap * Dim<D>::TILE * (D == 3 ? 2 : 1));
     if (dev.mesh_min) {
         GRID_ALLOC(&dev.mesh_min, cap * NPB);
@@ -238,7 +239,7 @@ wgs_status grow_grid(wgs_data *d, uint32_t new_cap) {
     HIP_TRY(hipStreamSynchronize(d->stream));
     void *old[] = {dev.hkeys, dev.hvals, dev.block_key, dev.block_count, dev.block_stamp, dev.links_epoch, dev.block_acc, dev.active,
                    dev.block_start, dev.nbr_plus, dev.nbr_minus, dev.nbr_known, dev.act_src, dev.cell_head, dev.chunk_a, dev.chunk_b, dev.group_a, dev.group_b,
-                   dev.cell_start, dev.cell_cursor, dev.nodes, dev.node_cdf, dev.slab, dev.block_cdf_flag, dev.block_cpic, dev.cpic_list, dev.visit_list,
+                   dev.cell_start, dev.cell_cursor, dev.nodes, dev.node_cdf, dev.slab, dev.block_cdf_flag, dev.block_cpic, dev.cpic_list, dev.visit_list, dev.halo_list,
                    dev.imp_slab, dev.mesh_min, dev.mesh_aff};
     for (void *p : old) release_alloc(d, p);
     dev.imp_slab = nullptr;  // (alloc_grid re-creates what was in use: two_way / mesh_min say so)
@@ -1198,9 +1199,8 @@ wgs_status wgs_shard_pack_halos(wgs_data *d, void *buf_lo, void *buf_hi, uint32_
     HIP_TRY(hipSetDevice(d->pipeline->device));
     if ((buf_lo && !hdr_registered(d, buf_lo)) || (buf_hi && !hdr_registered(d, buf_hi)))
         hipLaunchKernelGGL(k_clear_headers, dim3(1), dim3(64), 0, d->stream, static_cast<uint32_t *>(buf_lo), static_cast<uint32_t *>(buf_hi));
-    hipLaunchKernelGGL(k_pack_halos<D>, dim3(grid_for(d, 4)), dim3(64), 0, d->stream, d->dev, d->dev.shard_lo,
-                       static_cast<float4 *>(buf_lo), d->dev.shard_hi, static_cast<float4 *>(buf_hi), capacity_records,
-                       d->fused_halo ? 1 : 0);
+    hipLaunchKernelGGL(k_pack_halos<D>, dim3(2u * std::max(64u, std::min(capacity_records, 2048u))), dim3(64), 0, d->stream, d->dev,
+                       static_cast<float4 *>(buf_lo), static_cast<float4 *>(buf_hi), capacity_records, d->fused_halo ? 1 : 0);
     HIP_TRY(hipGetLastError());
     return WGS_OK;
 }

@@ -70,17 +70,17 @@ template <int D> __global__ __launch_bounds__(64) void k_pack_halo(Dev d, int la
 // `gather`: the node sums are not in nodes[] yet (no separate gather pass ran): compute them here from the slabs and
 // leave them in nodes[] for k_add_halo / the PHASE 3 grid update.
 template <int D> __device__ inline float4 gather_slabs(const Dev &d, uint32_t b, uint32_t ln);  // kernels_transfer.h
-template <int D> __global__ __launch_bounds__(64) void k_pack_halos(Dev d, int layer_lo, float4 *buf_lo, int layer_hi, float4 *buf_hi, uint32_t cap,
-                                                                      int gather) {
+template <int D> __global__ __launch_bounds__(64) void k_pack_halos(Dev d, float4 *buf_lo, float4 *buf_hi, uint32_t cap, int gather) {
     using H = HaloCfg<D>;
-    const uint32_t B = min(d.counters[CTR_NBLOCKS], d.cap);
     const int lane = threadIdx.x;
-    for (uint32_t a = blockIdx.x; a < B; a += gridDim.x) {
-        const uint32_t b = d.active[a];
-        int bc[3] = {0, 0, 0};
-        unpack_key<D>(d.block_key[b], bc);
-        float4 *buf = (buf_lo && bc[0] == layer_lo) ? buf_lo : ((buf_hi && bc[0] == layer_hi) ? buf_hi : nullptr);  // wave-uniform
-        if (gather && (bc[0] == layer_lo || bc[0] == layer_hi) && lane < H::NODES) {
+    // the active blocks of the two layers were listed by launch 2 of the sort (one wave per entry here: even workgroups
+    // walk layer_lo's list, odd ones layer_hi's) — scanning the whole active list for them took 11 us at 4000 blocks
+    const uint32_t sd = blockIdx.x & 1u;
+    const uint32_t nl = min(d.counters[CTR_NHALO + 32u * sd], d.cap);
+    for (uint32_t a = blockIdx.x >> 1; a < nl; a += gridDim.x >> 1) {
+        const uint32_t b = d.halo_list[(size_t)sd * d.cap + a];
+        float4 *buf = sd == 0u ? buf_lo : buf_hi;  // wave-uniform; null: no neighbour on that side (the sums are still gathered)
+        if (gather && lane < H::NODES) {
             const uint32_t ln = halo_node<D>(lane);
             d.nodes[(size_t)b * NPB + ln] = gather_slabs<D>(d, b, ln);  // (read back below by the same lane)
         }

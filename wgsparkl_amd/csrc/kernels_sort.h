@@ -77,6 +77,7 @@ template <int D, int TAIL> __device__ __forceinline__ void bin_body(const Dev &d
     const int tid = threadIdx.x, lane = tid & 63;
     if (tid < TOUCH_SET) s_keys[tid] = NONE;
     if (bid == 0u && tid < 16) d.counters[(tid < 8 ? (int)CTR_NCPIC : (int)CTR_NVISIT - 256) + 32 * tid] = 0;  // near-collider lists of this substep (k_regroup appends)
+    if (bid == 0u && tid >= 16 && tid < 18) d.counters[(int)CTR_NHALO + 32 * (tid - 16)] = 0;  // interface-layer lists (sharded runs)
     __syncthreads();
     const uint32_t first = tail ? d.counters[CTR_NPREV] : 0u;
     const uint32_t i = first + bid * SORT_THREADS + tid;
@@ -194,6 +195,7 @@ template <int D> __device__ __forceinline__ void rebin_body(const Dev &d, int si
     const int tid = threadIdx.x, lane = tid & 63;
     const uint32_t i = bid * SORT_THREADS + tid;
     if (bid == 0u && tid < 16) d.counters[(tid < 8 ? (int)CTR_NCPIC : (int)CTR_NVISIT - 256) + 32 * tid] = 0;  // near-collider lists of this substep (k_regroup appends)
+    if (bid == 0u && tid >= 16 && tid < 18) d.counters[(int)CTR_NHALO + 32 * (tid - 16)] = 0;  // interface-layer lists (sharded runs)
     // sharded runs: the residents only (arrivals have no previous cell: k_bin's tail pass), minus the slots
     // vacated by particles that migrated away
     const bool in_range = i < (d.sharded ? min(d.counters[CTR_NPREV], d.counters[CTR_N]) : num_slots(d));
@@ -679,6 +681,10 @@ __device__ __forceinline__ void regroup_block(const Dev &d, int side, uint32_t e
         d.block_cdf_flag[id] = 0;      // (block_acc is cleared by the grid update: the waves of this group read it)
     }
     if (listed) append_visits(d, id, bstart, btotal, lane);
+    if (d.sharded && lane == 0 && (b[0] == d.shard_lo || b[0] == d.shard_hi)) {  // interface layers of the slab (k_pack_halos)
+        const uint32_t sd = b[0] == d.shard_lo ? 0u : 1u;
+        d.halo_list[(size_t)sd * d.cap + atomicAdd(&d.counters[CTR_NHALO + 32u * sd], 1u)] = id;
+    }
     WGS_PROF(6)
     WGS_PROF_END()
 }

@@ -111,7 +111,8 @@ enum { CTR_NBLOCKS = 0, CTR_ERRORS = 1, CTR_NPHYS = 2, CTR_N = 4, CTR_NV = 5,
        CTR_NPHYS_SEEN = 8,  // [8], [9]: the id counter as launch 2 of an even / odd substep saw it (kernels_sort.h regroup_block)
        CTR_NVISIT = 64,  // [64 + 32 k], k = 0..7: length of the visit list of XCD k (Dev::visit_list), one cache line each
        CTR_NCPIC = 320,  // [320 + 32 k], k = 0..7: length of list k of the near-collider blocks (Dev::cpic_list), one cache line each
-       CTR_COUNT = 576 };
+       CTR_NHALO = 576,  // [576], [608]: sharded runs, length of the lists of active blocks in block layer shard_lo / shard_hi (Dev::halo_list)
+       CTR_COUNT = 640 };
 enum { ERRBIT_OVERFLOW = 1u, ERRBIT_KEYRANGE = 2u, ERRBIT_SHARD = 4u };
 
 // Everything a kernel needs, passed by value.
@@ -162,6 +163,7 @@ struct Dev {
     uint2 *visit_list;        // 8 x visit_cap: (listed block, chunk of 64 sorted particles that holds some of its particles); list k, at
                               // [k * visit_cap, + counters[CTR_NVISIT + 32 k]), is the one the CPIC body of the fused G2P advances on
                               // XCD k (g2p_body.inc); device_math.h append_visits deals the chunks to the lists
+    uint32_t *halo_list;      // sharded runs, 2 x cap: the active blocks of the two interface layers (what k_pack_halos gathers and packs)
     uint32_t visit_cap;       // per list (an eighth of the chunks + 2 per block would do; a block is visited once per chunk it spans)
     uint32_t g2p_npass;       // chunks per wave of the fused G2P of this substep (defines the eighths; set by the host per substep)
     uint32_t *counters;    // CTR_COUNT
