@@ -278,9 +278,11 @@ wgs_status maintain_grid(wgs_data *d) {
     // where it will be by then at the rate of its last two observations, not by where it was.
     const uint32_t rate = nblocks > d->seen_nblocks && d->seen_nblocks != 0u ? nblocks - d->seen_nblocks : 0u;
     d->seen_nblocks = std::min(nblocks, cap);
-    if (d->auto_grow && (uint64_t)nblocks + 3ull * rate > cap / 2u && cap < (1u << 24)) {
+    // (half full: grow, as before; or on course to be three quarters full by the time the next look can act)
+    const uint64_t ahead = (uint64_t)nblocks + 3ull * rate;
+    if (d->auto_grow && (nblocks > cap / 2u || ahead > cap / 4u * 3u) && cap < (1u << 24)) {
         uint32_t new_cap = cap * 2u;
-        while ((uint64_t)nblocks + 3ull * rate > new_cap / 2u && new_cap < (1u << 24)) new_cap *= 2u;
+        while (ahead > new_cap / 4u * 3u && new_cap < (1u << 24)) new_cap *= 2u;
         return grow_grid(d, new_cap);
     }
     if (nphys > cap / 4u * 3u) d->force_rehash = true;
