@@ -665,6 +665,7 @@ template <bool TS> wgs_status enqueue_substep(wgs_data *d, int ts_slot, int part
     const bool rehash = d->substeps % d->rehash_period == 0 || (d->force_rehash && part != 2 && part != 3);
     if (rehash && part != 2 && part != 3) d->force_rehash = false;
     const bool fused_cdf = d->cpic && dev.n_rigid == 0 && !(dev.dbg & 1024u);  // (mesh cdfs are only complete after k_p2g_cdf)
+    if (part != 2) dev.listed_in_perm = fused_cdf ? 1u : 0u;  // (part 2 of a sharded substep consumes what its part 1 wrote)
     // (sharded data stepped with wgs_step: nobody arrived since the last substep, the residents are all there is)
     const bool use_rebin = d->prev_sorted && !rehash && !(dev.dbg & 128u) && (!dev.sharded || d->tail_known || part == 3 || part == 0);
     if (dev.sharded && d->needs_compact && part != 2) {

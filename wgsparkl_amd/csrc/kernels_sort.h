@@ -204,6 +204,7 @@ template <int D> __device__ __forceinline__ void rebin_body(const Dev &d, int si
     uint32_t myid = NONE, local = 0, old = NONE;
     if (valid) {
         old = d.perm_cell[i];  // NONE only after a grid overflow: take the hash path then
+        if (old != NONE) old &= ~CELL_LISTED;
         const uint32_t ob = old >> 6;
         const uint32_t okey = old != NONE ? d.block_key[ob] : 0u;
         int c[D], nb[3] = {0, 0, 0};
@@ -532,6 +533,7 @@ __device__ __forceinline__ void regroup_block(const Dev &d, int side, uint32_t e
     }
     const uint32_t btotal = __shfl(inc, 63);
     const uint32_t lstart = inc - total;  // start of this cell's run inside the block
+    uint32_t pc_flag = 0u;  // CELL_LISTED for the perm_cell entries of a block near a collider
     bool listed = false;  // near a collider and holding particles: on the lists of the CPIC bodies of P2G / G2P
     WGS_PROF(2)
     // ---- node cdf tile + block class (independent of the scan: placed before the wait for it)
@@ -584,6 +586,7 @@ __device__ __forceinline__ void regroup_block(const Dev &d, int side, uint32_t e
             if (any && btotal > 0u) d.cpic_list[(size_t)(id & 7u) * d.cap + atomicAdd(&d.counters[CTR_NCPIC + 32u * (id & 7u)], 1u)] = id;
         }
         listed = any && btotal > 0u;
+        pc_flag = any ? CELL_LISTED : 0u;
     }
     WGS_PROF(3)
     // ---- pass 2: merge in ascending particle id. Stayers are in id order already; the next arrival is selected
@@ -600,7 +603,7 @@ __device__ __forceinline__ void regroup_block(const Dev &d, int side, uint32_t e
             __hip_atomic_store(&s_out[out], ((uint32_t)lane << 26) | src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
         } else {
             d.perm[bstart + out] = src;
-            d.perm_cell[bstart + out] = idx;
+            d.perm_cell[bstart + out] = idx | pc_flag;
         }
         out++;
     };
@@ -661,7 +664,7 @@ __device__ __forceinline__ void regroup_block(const Dev &d, int side, uint32_t e
         for (uint32_t t = lane; t < btotal; t += 64) {
             const uint32_t v = __hip_atomic_load(&s_out[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
             d.perm[bstart + t] = v & 0x03ffffffu;
-            d.perm_cell[bstart + t] = id * NPB + (v >> 26);
+            d.perm_cell[bstart + t] = (id * NPB + (v >> 26)) | pc_flag;
         }
     // ---- new runs, reset of what this substep consumed
     d.cell_start[idx] = bstart + lstart;

@@ -114,6 +114,10 @@ enum { CTR_NBLOCKS = 0, CTR_ERRORS = 1, CTR_NPHYS = 2, CTR_N = 4, CTR_NV = 5,
        CTR_NHALO = 576,  // [576], [608]: sharded runs, length of the lists of active blocks in block layer shard_lo / shard_hi (Dev::halo_list)
        CTR_COUNT = 640 };
 enum { ERRBIT_OVERFLOW = 1u, ERRBIT_KEYRANGE = 2u, ERRBIT_SHARD = 4u };
+// Bit 31 of a perm_cell entry (block ids stay below 2^24): the particle's block is near a collider. Written by launch 2 of the
+// sort when it computes the block classes itself; the fused G2P then knows which body a particle belongs to from the sort
+// entry it loads anyway, instead of a dependent block_cpic lookup in the middle of every chunk.
+constexpr uint32_t CELL_LISTED = 0x80000000u;
 
 // Everything a kernel needs, passed by value.
 struct Dev {
@@ -165,6 +169,7 @@ struct Dev {
                               // XCD k (g2p_body.inc); device_math.h append_visits deals the chunks to the lists
     uint32_t *halo_list;      // sharded runs, 2 x cap: the active blocks of the two interface layers (what k_pack_halos gathers and packs)
     uint32_t visit_cap;       // per list (an eighth of the chunks + 2 per block would do; a block is visited once per chunk it spans)
+    uint32_t listed_in_perm;  // this substep's perm_cell entries carry CELL_LISTED (launch 2 of the sort computed the block classes)
     uint32_t g2p_npass;       // chunks per wave of the fused G2P of this substep (defines the eighths; set by the host per substep)
     uint32_t *counters;    // CTR_COUNT
     const SimParamsDev *sp;
