@@ -571,14 +571,21 @@ class NativeComm:
         import torch
         self.lib, self.rank, self.world = pipeline.lib, rank, world
         uid = C.create_string_buffer(128)
+        failure = None
         if rank == 0:
-            _ffi.check(self.lib, self.lib.wgs_comm_get_unique_id(uid))
+            try:
+                _ffi.check(self.lib, self.lib.wgs_comm_get_unique_id(uid))
+            except Exception as e:  # noqa: BLE001 — the other ranks are waiting in the broadcast below: send them zeros
+                failure = e
+                uid = C.create_string_buffer(128)
         if world > 1:
             t = torch.tensor(list(uid.raw), dtype=torch.uint8)
             if dist.get_backend() == "nccl":
                 t = t.to(torch.device("cuda", pipeline.device))
             dist.broadcast(t, 0)
             uid = C.create_string_buffer(bytes(t.cpu().numpy().tobytes()), 128)
+        if failure is not None or not any(uid.raw):
+            raise RuntimeError(f"no RCCL unique id from rank 0 ({failure})")   # on every rank alike
         h = C.c_void_p()
         _ffi.check(self.lib, self.lib.wgs_comm_create(pipeline._h, uid, rank, world, int(flags), C.byref(h)))
         self._h = h
