@@ -811,10 +811,11 @@ template <bool TS> wgs_status enqueue_substep(wgs_data *d, int ts_slot, int part
     do {                                    \
         if (d->cpic && !(dev.dbg & 4096u)) {                                                               \
             /* both bodies in one launch (k_g2p_pair) */                                                          \
-            /* list waves (8 x nlist; they stride over the runs of the visit list): 2 x the runs the host last saw */ \
+            /* list waves (8 x nlist; the waves of an XCD stride over the runs of its visit list): 2 x the runs of the */ \
+            /* longest list as the host last saw it */                                                             \
             /* (unknown: a wave and a half per SIMD) */                                                           \
             const uint32_t full = (uint32_t)grid_for(d, 1) * 3u / 2u;                                             \
-            const uint32_t nlist = d->last_nvisit == UINT32_MAX ? full : std::min(full, std::max(8u, 2u * ((d->last_nvisit + (NP) - 1u) / (NP)))); \
+            const uint32_t nlist = d->last_nvisit == UINT32_MAX ? full : std::min(full, std::max(8u, 2u * ((d->last_nvisit + std::min<uint32_t>(NP, WGS_G2P_LIST_PASSES) - 1u) / std::min<uint32_t>(NP, WGS_G2P_LIST_PASSES)))); \
             /* plastic scenes with a large share of listed blocks: the spill-free variant (kernels_transfer.h) */  \
             if (PL && d->last_ncpic != UINT32_MAX && d->last_ncpic * 2u >= std::max(1u, d->last_nblocks) && !(dev.dbg & 16384u)) \
                 hipLaunchKernelGGL((k_g2p_pair<D, MODEL, PL, (PL) ? WGS_PLASTIC_WPE_DENSE : G2P_WAVES_PER_EU, NP>), dim3((uint32_t)g + 8u * nlist), \
