@@ -231,6 +231,23 @@ wgs_status wgs_read_body_poses(wgs_data *data, wgs_pose *poses, wgs_velocity *ve
 /* positions is the only particle buffer the reference creates COPY_SRC (src/solver/particle3d.rs:197-201).
  * out: num_particles * WGS_DIM floats, in the caller's original particle order. Blocking. */
 wgs_status wgs_read_positions(wgs_data *data, float *out);
+/* Optional interop view (SURVEY §8b "Ownership": no borrowed device pointers escape except through this call): where the
+ * current particle state lives on the device, for a renderer or a coupling code that reads positions without a host round
+ * trip (the reference hands its `positions` buffer to the testbed's render pass the same way, src/solver/particle3d.rs:197-201,
+ * src_testbed/step.rs:144-163). One float4 per slot — the first WGS_DIM floats are the position — in the SORTED order of the last
+ * substep; particle_ids[slot] is the caller's index of the particle in that slot. Read-only; valid until the next call that
+ * steps, sets, restores or destroys `data`. Work enqueued on `hip_stream` before this call is what produced the contents:
+ * synchronise, or enqueue the reader behind it. Not blocking. Single-domain data. */
+typedef struct {
+    const float *position_quads;   /* capacity * 4 floats */
+    const uint32_t *particle_ids;  /* capacity */
+    uint32_t count;                /* slots in use = number of particles */
+    uint32_t capacity;
+    uint32_t dim;                  /* WGS_DIM of the library */
+    uint32_t reserved;
+    void *hip_stream;              /* hipStream_t of `data` */
+} wgs_device_ptrs;
+wgs_status wgs_get_device_ptrs(wgs_data *data, wgs_device_ptrs *out);
 /* Full particle state in the caller's original order (tests / checkpoint). Blocking. */
 wgs_status wgs_read_particles(wgs_data *data, wgs_particle *out, wgs_plastic_state *plastic_out /* may be NULL */);
 /* Render hand-off: src_testbed/prep_vertex_buffer{2,3}d.wgsl `main`, the compute pass the testbed

@@ -131,6 +131,19 @@ pub struct wgs_stats {
     pub grid_growths: u32,
 }
 
+/// Optional interop view of the particle state on the device (`wgs_get_device_ptrs`).
+#[repr(C)]
+#[derive(Copy, Clone)]
+pub struct wgs_device_ptrs {
+    pub position_quads: *const f32,
+    pub particle_ids: *const u32,
+    pub count: u32,
+    pub capacity: u32,
+    pub dim: u32,
+    pub reserved: u32,
+    pub hip_stream: *mut c_void,
+}
+
 #[repr(C)]
 pub struct wgs_comm {
     _private: [u8; 0],
@@ -159,6 +172,7 @@ extern "C" {
         d: *mut wgs_data, poses: *mut wgs_pose, vels: *mut wgs_velocity, coms: *mut f32, n: usize,
     ) -> wgs_status;
     pub fn wgs_read_positions(d: *mut wgs_data, out: *mut f32) -> wgs_status;
+    pub fn wgs_get_device_ptrs(d: *mut wgs_data, out: *mut wgs_device_ptrs) -> wgs_status;
     pub fn wgs_read_particles(d: *mut wgs_data, out: *mut wgs_particle, plastic: *mut wgs_plastic_state) -> wgs_status;
     pub fn wgs_prep_vertex_buffer(d: *mut wgs_data, mode: u32, instances: *mut wgs_instance) -> wgs_status;
     pub fn wgs_prep_vertex_buffer_device(d: *mut wgs_data, mode: u32, device_instances: *mut wgs_instance) -> wgs_status;

@@ -260,6 +260,32 @@ def test_visit_list_many_listed_blocks_per_chunk(hip_libs, oracle_libs, monkeypa
         assert np.array_equal(getattr(got, f), getattr(b, f)), f
 
 
+def test_device_ptrs_view_matches_the_read_back(hip_libs):
+    """wgs_get_device_ptrs (the optional interop view of SURVEY 8b): the position quads and particle ids it points at, copied
+    straight from device memory, are the positions wgs_read_positions returns — in sorted order, labelled by the ids."""
+    import ctypes as C
+    from helpers import pipeline
+    from wgsparkl_amd import MpmData, _ffi
+    sc = scenes.neo_hookean_cube(n_side=16, with_floor=True)
+    pipe = pipeline(3)
+    data = MpmData.new(pipe, sc["params"], sc["particles"], sc["colliders"], sc["cell_width"], sc["grid_capacity"], sc["model"])
+    pipe.step(data, 7)
+    data.sync()
+    view = _ffi.DevicePtrs()
+    _ffi.check(pipe.lib, pipe.lib.wgs_get_device_ptrs(data._h, C.byref(view)))
+    n = sc["particles"].n
+    assert view.count == n and view.capacity >= n and view.dim == 3 and view.position_quads and view.particle_ids
+    hip = C.CDLL("libamdhip64.so")
+    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    quads = np.empty((n, 4), np.float32)
+    ids = np.empty(n, np.uint32)
+    assert hip.hipMemcpy(quads.ctypes.data, view.position_quads, quads.nbytes, 2) == 0      # hipMemcpyDeviceToHost
+    assert hip.hipMemcpy(ids.ctypes.data, view.particle_ids, ids.nbytes, 2) == 0
+    assert np.array_equal(np.sort(ids), np.arange(n, dtype=np.uint32))
+    pos = data.read_particles().pos
+    assert np.array_equal(quads[:, :3], pos[ids])
+
+
 def test_determinism(hip_libs):
     sc = cloud_scene(n=30000, seed=11)
     a = run_gpu(sc, 5).read_particles()

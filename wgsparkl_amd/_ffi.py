@@ -18,7 +18,7 @@ PASS_NAMES = ("update rigid particles", "grid sort", "grid_update_cdf", "p2g_cdf
 EXPORTS = (
     "wgs_last_error", "wgs_dim", "wgs_pipeline_create", "wgs_pipeline_destroy", "wgs_data_create",
     "wgs_data_destroy", "wgs_set_constitutive_model", "wgs_step", "wgs_sync", "wgs_set_sim_params",
-    "wgs_set_collider_poses", "wgs_set_body_velocities", "wgs_set_body_mass_properties", "wgs_read_body_poses", "wgs_set_plastic_state", "wgs_read_timing_overhead", "wgs_set_rigid_particles", "wgs_prep_vertex_buffer", "wgs_prep_vertex_buffer_device", "wgs_read_positions", "wgs_read_particles",
+    "wgs_set_collider_poses", "wgs_set_body_velocities", "wgs_set_body_mass_properties", "wgs_read_body_poses", "wgs_set_plastic_state", "wgs_read_timing_overhead", "wgs_set_rigid_particles", "wgs_prep_vertex_buffer", "wgs_prep_vertex_buffer_device", "wgs_read_positions", "wgs_get_device_ptrs", "wgs_read_particles",
     "wgs_read_grid", "wgs_read_blocks", "wgs_read_timings", "wgs_get_stats",
     # multi-GPU (x-slab decomposition; new design, no reference counterpart)
     "wgs_data_create_sharded", "wgs_shard_halo_record_bytes", "wgs_shard_particle_record_bytes",
@@ -109,6 +109,12 @@ def make_types(D: int):
     return type("Types", (), ns)
 
 
+class DevicePtrs(C.Structure):
+    """wgs_device_ptrs (include/wgsparkl_hip.h): the optional interop view of the particle state on the device."""
+    _fields_ = [("position_quads", C.c_void_p), ("particle_ids", C.c_void_p), ("count", C.c_uint32), ("capacity", C.c_uint32),
+                ("dim", C.c_uint32), ("reserved", C.c_uint32), ("hip_stream", C.c_void_p)]
+
+
 _LIBS = {}
 
 
@@ -148,6 +154,7 @@ def load(dim: int):
     lib.wgs_set_body_mass_properties.argtypes = [vp, C.POINTER(T.MassProperties), C.c_size_t]
     lib.wgs_read_body_poses.argtypes = [vp, C.POINTER(T.Pose), C.POINTER(T.Velocity), C.POINTER(C.c_float), C.c_size_t]
     lib.wgs_read_positions.argtypes = [vp, C.POINTER(C.c_float)]
+    lib.wgs_get_device_ptrs.argtypes = [vp, C.POINTER(DevicePtrs)]
     lib.wgs_read_particles.argtypes = [vp, C.POINTER(T.Particle), C.POINTER(T.PlasticState)]
     lib.wgs_set_plastic_state.argtypes = [vp, C.POINTER(T.PlasticState)]
     lib.wgs_set_rigid_particles.argtypes = [vp, C.POINTER(C.c_float), vp, C.c_size_t, C.POINTER(C.c_float),

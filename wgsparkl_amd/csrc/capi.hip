@@ -1571,6 +1571,20 @@ wgs_status wgs_read_positions(wgs_data *d, float *out) {
     return WGS_OK;
 }
 
+wgs_status wgs_get_device_ptrs(wgs_data *d, wgs_device_ptrs *out) {
+    if (!d || !out) return fail(WGS_ERR_INVALID_ARGUMENT, "NULL argument");
+    if (d->dev.sharded) return fail(WGS_ERR_UNSUPPORTED, "sharded wgs_data: use wgs_shard_export");
+    const float *buf = d->dev.buf[d->side];
+    out->position_quads = buf + (size_t)Pl<D>::XM * 4 * d->dev.npad;
+    out->particle_ids = reinterpret_cast<const uint32_t *>(buf) + (size_t)Pl<D>::NQ * 4 * d->dev.npad;  // (layout.h ldpid)
+    out->count = d->dev.n;
+    out->capacity = d->dev.npad;
+    out->dim = D;
+    out->reserved = 0;
+    out->hip_stream = d->stream;
+    return WGS_OK;
+}
+
 wgs_status wgs_read_particles(wgs_data *d, wgs_particle *out, wgs_plastic_state *plastic_out) {
     if (!d || !out) return fail(WGS_ERR_INVALID_ARGUMENT, "NULL argument");
     if (d->dev.sharded) return fail(WGS_ERR_UNSUPPORTED, "sharded wgs_data: use wgs_shard_export");
