@@ -132,6 +132,12 @@ class MpmData {
         check(wgs_read_positions(h_, out.data()));
         return out;
     }
+    // the optional interop view: device pointers to the position quads + ids of the current state (sorted order) and their stream
+    wgs_device_ptrs device_ptrs() {
+        wgs_device_ptrs v{};
+        check(wgs_get_device_ptrs(h_, &v));
+        return v;
+    }
     std::vector<wgs_particle> read_particles() {
         std::vector<wgs_particle> out(n_);
         check(wgs_read_particles(h_, out.data(), nullptr));

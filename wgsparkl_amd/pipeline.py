@@ -278,6 +278,13 @@ class MpmData:
         _ffi.check(self.lib, self.lib.wgs_read_positions(self._h, out.ctypes.data_as(C.POINTER(C.c_float))))
         return out
 
+    def device_ptrs(self):
+        """`wgs_get_device_ptrs`: where the current particle state lives on the device (position quads + particle ids in
+        sorted order, and the HIP stream that produces them) — the optional interop view, for readers on the same device."""
+        v = _ffi.DevicePtrs()
+        _ffi.check(self.lib, self.lib.wgs_get_device_ptrs(self._h, C.byref(v)))
+        return v
+
     def read_particles(self) -> ParticleSet:
         T = self.T
         words = C.sizeof(T.Particle) // 4
