@@ -219,7 +219,8 @@ wgs_status wgs_set_body_mass_properties(wgs_data *data, const wgs_mass_propertie
  * the collider's LOCAL frame, per sample the vertex ids of the triangle (2D: segment, vertex[2] unused) it was
  * taken from and its collider. Every substep then runs `update rigid particles`, the rigid-particle block marks
  * and `p2g_cdf` (src/solver/rigid_particle_update.wgsl, src/grid/sort.wgsl:38-86, src/solver/p2g_cdf.wgsl).
- * Copies its inputs; n == 0 removes them. Blocking; single-domain data. */
+ * Copies its inputs; n == 0 removes them. Blocking. On sharded data every rank passes ALL samples (the node cdfs are a
+ * function of position and colliders: the two ranks of a face compute the same values for the nodes they share). */
 typedef struct { uint32_t vertex[3]; uint32_t collider; } wgs_sample_ids;   /* GpuSampleIds */
 wgs_status wgs_set_rigid_particles(wgs_data *data, const float *local_points /* n*DIM */, const wgs_sample_ids *ids, size_t n,
                                    const float *local_vertices /* nv*DIM */, const uint32_t *vertex_collider_ids, size_t nv);

@@ -1130,6 +1130,34 @@ def test_native_lockstep_matches_single_domain(hip_libs, world, dim, monkeypatch
         assert ((bx >= lo) & (bx < hi)).all()
 
 
+@pytest.mark.parametrize("name", ["mesh_floor3d", "polyline2d"])
+def test_mesh_colliders_on_sharded_data(hip_libs, name):
+    """Mesh colliders (rigid-particle samples) on slabs: every slab holds every sample, the node cdfs of the
+    nodes two slabs share are computed by both from the same inputs. Two slabs in lockstep against the single-domain run of
+    the golden scene: the same particles on the same side of the mesh, fields to fp32 round-off."""
+    from helpers import pipeline
+    from wgsparkl_amd.sharded import native_lockstep
+    make, k = _CASES[name]
+    sc = make()
+    dim = sc["particles"].dim
+    ref = run_gpu(sc, k).read_particles()
+    pipe = pipeline(dim)
+    shards, _ = _native_slabs(sc, 2, pipe)
+    assert min(s.num_particles() for s in shards) > 0
+    native_lockstep(pipe, shards, k)
+    for s in shards:
+        s.sync()
+    outs = [s.export() for s in shards]
+    ids = np.concatenate([o["ids"] for o in outs])
+    assert np.array_equal(np.sort(ids), np.arange(sc["particles"].n, dtype=np.uint32))
+    order = np.argsort(ids)
+    assert (ref.cdf_affinity != 0).sum() > 10, "the scene must feel its mesh"
+    for f, tol in (("pos", 1e-5), ("vel", 5e-5), ("def_grad", 1e-5)):
+        err = rel_rms(np.concatenate([o[f] for o in outs])[order], getattr(ref, f))
+        report_margin(f"sharded mesh {f}", err, tol)
+        assert err < tol, (f, err)
+
+
 def test_native_sharded_step_over_rccl_one_rank(hip_libs):
     """wgs_comm_* + wgs_shard_attach + wgs_sharded_step with a real RCCL communicator. A second rank on the same GPU
     is refused by RCCL, so: (a) world = 1 without neighbours must reproduce wgs_step on single-domain data;

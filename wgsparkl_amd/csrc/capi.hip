@@ -1476,7 +1476,8 @@ wgs_status wgs_set_rigid_particles(wgs_data *d, const float *local_points, const
     if (!d) return fail(WGS_ERR_INVALID_ARGUMENT, "NULL argument");
     if (n && (!local_points || !ids || !local_vertices || !vertex_collider_ids || !nv))
         return fail(WGS_ERR_INVALID_ARGUMENT, "NULL argument");
-    if (d->dev.sharded) return fail(WGS_ERR_UNSUPPORTED, "mesh colliders on sharded data");
+    // (sharded data: every rank holds every sample — the node cdfs are a function of position and colliders, both ranks of a
+    // face compute the same values for the nodes they share, nothing about them is exchanged)
     if (n > 0xffffffffull || nv > 0xffffffffull) return fail(WGS_ERR_INVALID_ARGUMENT, "too many samples");
     for (size_t i = 0; i < n; i++) {
         if (ids[i].collider >= d->dev.n_colliders) return fail(WGS_ERR_INVALID_ARGUMENT, "sample of an unknown collider");

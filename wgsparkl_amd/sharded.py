@@ -640,6 +640,16 @@ class NativeShard:
             _ffi.check(self.lib, self.lib.wgs_set_body_mass_properties(self._h, arr, len(colliders)))
         _ffi.check(self.lib, self.lib.wgs_shard_attach(self._h, comm._h if comm is not None else None, 1 if has_lower else 0,
                                                          1 if has_upper else 0, int(halo_capacity_blocks), int(migrant_capacity)))
+        # mesh colliders: sampled on the host like GpuRigidParticles::from_rapier; every rank holds every sample
+        from .sampling import build_rigid_particles
+        rb = build_rigid_particles(colliders, D, float(cell_width))
+        if rb is not None:
+            F32 = np.float32
+            pts, ids = np.ascontiguousarray(rb["local_pts"], F32), np.ascontiguousarray(rb["ids"], np.uint32)
+            vtx, vcol = np.ascontiguousarray(rb["local_vtx"], F32), np.ascontiguousarray(rb["vtx_collider"], np.uint32)
+            fp, up = C.POINTER(C.c_float), C.POINTER(C.c_uint32)
+            _ffi.check(self.lib, self.lib.wgs_set_rigid_particles(self._h, pts.ctypes.data_as(fp), ids.ctypes.data_as(C.c_void_p), len(pts),
+                                                                  vtx.ctypes.data_as(fp), vcol.ctypes.data_as(up), len(vtx)))
         self.part_rec = self.lib.wgs_shard_particle_record_bytes() // 4
         self.hdr = self.lib.wgs_shard_buffer_header_bytes() // 4
 
