@@ -5,10 +5,11 @@ Default workload (BASELINE.json configs[1]): wgsparkl3d neo-Hook
 particles (8 per cell) in a 128^3-cell domain, floor cuboid, fp32, synthetic lattice + jitter. One "step" = one
 substep of MpmPipeline::queue_step (sort -> P2G -> grid update -> fused G2P + particle update), inputs resident in HBM.
 
-  python bench.py --gpus N --steps K --warmup W [--config c2|c3|c5] [--scaling weak|strong]
+  python bench.py --gpus N --steps K --warmup W [--config c2|c3|c4|c5] [--scaling weak|strong]
 
 --config: c2 (default, the headline), c3 = Drucker-Prager sand column, 4M, standing between the floor and four walls,
-c5 = pressure-only neo-Hookean fluid block, 16M (BASELINE.json configs[2], configs[4]).
+c4 = corotated cube on the floor hit by a kinematic rotating cuboid, 8M, c5 = pressure-only neo-Hookean fluid block, 16M
+(BASELINE.json configs[2], configs[3], configs[4]).
 N > 1: one process per GPU, x-slab domain decomposition; per substep each rank swaps the partial node sums of the
 interface layers and the migrating particles with its two neighbours — RCCL point-to-point issued from inside the
 library (wgs_sharded_step, include/wgsparkl_hip.h), no collective on the data path. --scaling weak (default): N
@@ -38,7 +39,7 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--config", choices=("c2", "c3", "c5"), default="c2")
+    ap.add_argument("--config", choices=("c2", "c3", "c4", "c5"), default="c2")
     ap.add_argument("--scaling", choices=("weak", "strong"), default="weak")
     ap.add_argument("--n-side", type=int, default=None, help="particles per cube edge (c2: 100 -> 1M, the named config)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -284,6 +285,21 @@ def main():
             from wgsparkl_amd.sharded import FixedExchange
             env["exchange"] = FixedExchange(dist, rank, world)
 
+    # ---- N > 1: the decomposition validates itself before anything is timed (a small bar on all ranks through
+    # wgs_sharded_step against the single-domain run of the same bar on rank 0: ids exact, pos / vel rel RMS < 1e-5)
+    validation_sharded = None
+    if sharded_path and world > 1 and env["native"]:
+        from wgsparkl_amd.selfcheck import bar_check
+        validation_sharded = bar_check(pipe, dist, env["comm"], world, rank)
+        if not validation_sharded["ok"]:
+            if rank == 0:
+                emit({"metric": "particle-steps/sec", "value": None, "unit": "particle-steps/s", "n_gpus": world, "validation_sharded": validation_sharded,
+                      "error": "the sharded run disagrees with the single-domain run: nothing was timed"})
+                print("bench.py: wgs_sharded_step on %d ranks disagrees with the single-domain run: %s" % (world, validation_sharded), file=sys.stderr)
+            dist.barrier()
+            dist.destroy_process_group()
+            sys.exit(3)
+
     # ---- the headline workload
     default_workload = args.config == "c2" and args.n_side in (None, 100) and args.scaling == "weak" and not args.no_floor
     if not sharded_path and args.config == "c2":
@@ -323,6 +339,7 @@ def main():
             "roofline": rl,
             "pass_ms_per_step": main_res["pass_ms_per_step"],
             "build": {"info": build_info, "WGS_DEBUG": dbg_env, "transport_note": transport_note},
+            "validation_sharded": validation_sharded,
             "notes": "the hash table of block ids is rebuilt (k_bin instead of k_rebin, ~+0.25 ms once at this size) on the first substep, every "
                      "1024 substeps and whenever three quarters of the ids are handed out; none of these falls inside this timed region",
         }
@@ -379,8 +396,28 @@ def main():
         r = measure(env, sc, world, rank, k, w, KERNEL_ELASTIC)
         if rank == 0:
             extra["c5_strong"] = slim(r, sc["name"] + (f", cut into {world} x-slabs (strong scaling: fixed 16 M global)" if world > 1 else ", one GPU"))
-            out["extra"] = extra
         del sc
+        if sharded_path and world > 1:
+            # the headline's own 1 M cube cut N ways (BASELINE.json's metric read as strong scaling). A slab must be at
+            # least two blocks wide (kernels_shard.h): 12.5 block columns cut 8 ways are not, so N = 8 has no such leg
+            sc = scenes.config_scene("c2", world, rank, "strong")
+            cuts = sc["partition"].cuts
+            if all(cuts[i + 1] - cuts[i] >= 2 for i in range(1, world - 1)):      # interior slabs
+                r = measure(env, sc, world, rank, k, w, KERNEL_ELASTIC)
+                if rank == 0:
+                    extra["c2_strong"] = slim(r, sc["name"] + f", cut into {world} x-slabs (strong scaling: fixed 1 M global)")
+            elif rank == 0:
+                extra["c2_strong"] = {"skipped": f"the 50-cell cube cut into {world} x-slabs leaves slabs narrower than the two blocks the halo protocol needs"}
+            del sc
+        if sharded_path and world == 4:
+            # BASELINE.json configs[3]: 8 M corotated + kinematic rotating cuboid on 4 GPUs (x-slabs)
+            sc = scenes.config_scene("c4", world, rank, "strong")
+            r = measure(env, sc, world, rank, k, w, KERNEL_ELASTIC)
+            if rank == 0:
+                extra["c4_strong"] = slim(r, sc["name"] + ", cut into 4 x-slabs")
+            del sc
+        if rank == 0:
+            out["extra"] = extra
 
     if rank == 0:
         emit(out)

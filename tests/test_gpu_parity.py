@@ -151,6 +151,28 @@ def test_2d_block(hip_libs, oracle_libs):
     check_fields(data, st32, st64)
 
 
+@pytest.mark.parametrize("landed", [False, True])
+def test_c1_configs0_as_written(hip_libs, oracle_libs, landed):
+    """BASELINE.json configs[0] at its full size: the 2D elastic block of 100 x 100 = 10 000 particles (4 per cell,
+    crates/wgsparkl2d/examples/elasticity2.rs:33-55 conventions) over the floor cuboid, 100 substeps, against the fp64
+    oracle with the CPIC tolerances (the floor makes it a collider simulation). As written the block is still falling
+    after 100 substeps; `landed` lowers it onto the floor so that the same 100 substeps go through contact."""
+    sc = scenes.elastic_block_2d(nx=100, ny=100, with_floor=True)
+    assert sc["particles"].n == 10_000
+    if landed:
+        sc["particles"].pos[:, 1] -= 5.0
+        sc["particles"].vel[:, 1] = -2.0
+    k = 100
+    data = run_gpu(sc, k)
+    st32 = run_oracle(sc, k, np.float32)
+    st64 = run_oracle(sc, k, np.float64)
+    check_blocks(data, st32)
+    got, same = compare_cpic(data, st32, st64, 2, CPIC_GRID_V_TOL, CPIC_PART_TOL, min_same=0.998)
+    if landed:
+        assert (got.cdf_affinity & 1).sum() >= 300, "the floor must be felt"
+        assert np.abs(got.def_grad - np.eye(2, dtype=np.float32).reshape(-1)).max() > 1e-3, "the block must deform"
+
+
 def test_empty_and_single(hip_libs, oracle_libs):
     sc = cloud_scene(n=1)
     data = run_gpu(sc, 2)

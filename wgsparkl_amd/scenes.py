@@ -244,8 +244,8 @@ def fluid_block(nx=256, ny=250, nz=250, world=1, rank=None, jitter=0.05, cell_wi
 
 def config_scene(config="c2", world=1, rank=None, scaling="weak", n_side=None, jitter=0.05):
     """The BASELINE.json configs as (possibly sharded) scenes for bench.py: `c2` neo-Hookean cube (1 M), `c3`
-    Drucker-Prager sand column standing between the floor and four walls (4 M), `c5` pressure-only neo-Hookean fluid
-    block (16 M). world > 1: "strong" cuts the named size into `world` x-slabs, "weak" puts `world` copies side by
+    Drucker-Prager sand column standing between the floor and four walls (4 M), `c4` corotated cube + kinematic rotating
+    cuboid (8 M), `c5` pressure-only neo-Hookean fluid block (16 M). world > 1: "strong" cuts the named size into `world` x-slabs, "weak" puts `world` copies side by
     side along x (fixed work per GPU). With `rank` given only that rank's slab is generated. Particles are identified
     by their index in the global lattice and jittered by a hash of it, so every decomposition simulates the same scene."""
     h = 1.0
@@ -277,6 +277,22 @@ def config_scene(config="c2", world=1, rank=None, scaling="weak", n_side=None, j
                      Collider.cuboid((100000.0, 1000.0, t), (0.0, 0.0, z0 - t)), Collider.cuboid((100000.0, 1000.0, t), (0.0, 0.0, z1 + t))]
         name = f"wgsparkl3d Drucker-Prager sand column, {nx * mult}x{ny}x{nz} particles, 256^3-cell domain, standing between the floor and four walls"
         bpp = 216.0
+    elif config == "c4":
+        # BASELINE.json configs[3]: corotated elastic cube resting on the floor, hit by one kinematic rotating cuboid — a body
+        # whose velocity the host sets and whose pose the device integrates every substep (the pattern of
+        # crates/wgsparkl3d/examples/sand3.rs:95-103); same geometry as corotated_cube_with_paddle, by global lattice
+        # index so that it can be cut into x-slabs (every rank holds every collider).
+        n = 200 if n_side is None else n_side
+        counts, origin = (n * mult, n, n), (20.0 * h, 2.4 * h, 20.0 * h)
+        model, elastic = MODEL_COROTATED, ElasticCoefficients.from_young_modulus(1.0e7, 0.2)
+        plast, phase = None, ParticlePhase(1.0, FLT_MAX)
+        sx, side = counts[0] * h / 2.0, n * h / 2.0
+        colliders = [Collider.cuboid((100000.0 * h, 2.0 * h, 1000.0 * h), (0.0, 0.0, 0.0)),
+                     Collider.cuboid((2.0 * h, side / 2.0, side / 3.0), (origin[0] + sx + 2.2 * h, origin[1] + side / 2.0, origin[2] + side / 2.0),
+                                     angvel=(0.0, 0.8, 0.0), linvel=(-2.0, 0.0, 0.0))]
+        name = (f"wgsparkl3d corotated elastic cube on the floor + kinematic rotating cuboid (rigid-body collision), {n * mult}x{n}x{n} particles, "
+                "256^3-cell domain")
+        bpp = 160.0
     else:
         raise ValueError(f"unknown config {config!r}")
     pos, gid, part = _slab_block(counts, origin, h, jitter, world, rank)
