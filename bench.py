@@ -10,9 +10,11 @@ substep of MpmPipeline::queue_step (sort -> P2G -> grid update -> fused G2P + pa
 --config: c2 (default, the headline), c3 = Drucker-Prager sand column, 4M, standing between the floor and four walls,
 c4 = corotated cube on the floor hit by a kinematic rotating cuboid, 8M, c5 = pressure-only neo-Hookean fluid block, 16M
 (BASELINE.json configs[2], configs[3], configs[4]).
-N > 1: one process per GPU, x-slab domain decomposition; per substep each rank swaps the partial node sums of the
-interface layers and the migrating particles with its two neighbours — RCCL point-to-point issued from inside the
-library (wgs_sharded_step, include/wgsparkl_hip.h), no collective on the data path. --scaling weak (default): N
+N > 1: one process per GPU, x-slab domain decomposition; per substep each rank swaps ONE message with each of its two
+neighbours — the partial node sums of the interface layers and the particles changing owner — over RCCL point-to-point
+issued from inside the library (wgs_sharded_step, include/wgsparkl_hip.h), no collective on the data path. Before
+anything is timed the decomposition validates itself against a single-domain run (validation_sharded; exit 3 on a
+mismatch). --scaling weak (default): N
 copies of the config side by side along x (fixed work per GPU); strong: the named size cut into N slabs (north_star's
 16M target: --config c5 --scaling strong). Without flags, the line also carries `extra` legs: the same cube after it
 landed on the floor, c3, and c5 (strong over the N GPUs), each with its own G2P roofline figure.
@@ -108,37 +110,29 @@ class Leg:
             self.handle = self.data._h
             self.parallelism = "1 GPU"
             return
-        from wgsparkl_amd.sharded import GpuShard, NativeShard
+        from wgsparkl_amd.sharded import NativeShard, uniform_material_of
         lo, hi = scene["partition"].block_range(rank)
         ny = int(round((float(ps.pos[:, 1].max()) - float(ps.pos[:, 1].min())) * 2.0 / scene["cell_width"])) + 1 if ps.n else 1
         nz = int(round((float(ps.pos[:, 2].max()) - float(ps.pos[:, 2].min())) * 2.0 / scene["cell_width"])) + 1 if ps.n else 1
         # Messages travel at their full capacity (no size handshake), so the capacities are sized from the workload: a
-        # face touches at most (ny / 8 + 3) x (nz / 8 + 3) blocks (+ margin); a handful of particles cross a cut per
-        # substep while the body falls along y. An overflow is reported by wgs_sync and by the particle count below.
-        kw = dict(particle_capacity=int(ps.n * 1.25) + 4096, model=scene["model"], halo_capacity_blocks=(ny // 8 + 3) * (nz // 8 + 3) + 32,
-                  migrant_capacity=max(512, (ny * nz) // 32))
-        args = (pipe, scene["params"], ps, scene["global_ids"], scene["colliders"], scene["cell_width"], scene["grid_capacity"], lo, hi,
-                rank > 0, rank < world - 1)
-        if env["native"]:
-            from wgsparkl_amd.sharded import uniform_material_of
-            # every rank generates particles of the same single material (scenes.py): the constants become kernel
-            # arguments on sharded data too, like wgs_data_create decides by itself for a single domain
-            self.data = NativeShard(*args, comm=env["comm"], uniform_material=uniform_material_of(ps), **kw)
-            self.parallelism = f"{world} x-slabs, halo + migration over RCCL send/recv inside wgs_sharded_step"
-        else:
-            self.data = GpuShard(*args, **kw)
-            self.parallelism = f"{world} x-slabs, halo + migration over torch.distributed p2p (python-driven protocol)"
+        # face touches at most (ny / 8 + 3) x (nz / 8 + 3) blocks, each sends one record (one x-layer pair) and the
+        # blocks migrating particles touch a few more (+ 50 % + margin); a handful of particles cross a cut per substep
+        # while the body falls along y. An overflow is reported by wgs_sync and by the particle count below.
+        face = (ny // 8 + 3) * (nz // 8 + 3)
+        # every rank generates particles of the same single material (scenes.py): the constants become kernel
+        # arguments on sharded data too, like wgs_data_create decides by itself for a single domain
+        self.data = NativeShard(pipe, scene["params"], ps, scene["global_ids"], scene["colliders"], scene["cell_width"], scene["grid_capacity"],
+                                lo, hi, rank > 0, rank < world - 1, particle_capacity=int(ps.n * 1.25) + 4096, model=scene["model"],
+                                halo_capacity_records=face + face // 2 + 64, migrant_capacity=max(512, (ny * nz) // 32), comm=env["comm"],
+                                uniform_material=uniform_material_of(ps))
+        self.parallelism = f"{world} x-slabs, one message per neighbour and substep (node sums + migrating particles) over RCCL send/recv inside wgs_sharded_step"
         self.handle = self.data._h
 
     def run(self, k):
         if not self.sharded:
             self.env["pipe"].step(self.data, k)
-        elif self.env["native"]:
-            self.data.step(k)
         else:
-            from wgsparkl_amd.sharded import substep_phases
-            for _ in range(k):
-                substep_phases(self.data, self.env["exchange"])
+            self.data.step(k)
 
     def timed(self, steps, warmup):
         env = self.env
@@ -233,16 +227,10 @@ def main():
     # WGS_BENCH_FORCE_SHARDED=1: the N > 1 code path (process group, sharded data, wgs_sharded_step) with however many
     # ranks were launched, even one — a functional check for 1-GPU boxes
     sharded_path = world > 1 or force_sharded
-    one_gpu = os.environ.get("WGS_BENCH_ONE_GPU") == "1"   # all ranks on cuda:0 over gloo: functional test of the exchanges
     if sharded_path:
         import torch.distributed as dist
-        if one_gpu:
-            local_rank = 0
         torch.cuda.set_device(local_rank)
-        if one_gpu:
-            dist.init_process_group("gloo")
-        else:
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     dev_index = local_rank if sharded_path else 0
     device = f"cuda:{dev_index}"
 
@@ -260,35 +248,29 @@ def main():
     if "WGS_ABLATE" in build_info and os.environ.get("WGS_BENCH_ALLOW_ABLATE") != "1":
         print("bench.py: the library was built with -DWGS_ABLATE (ablation switches compiled in): not a product build", file=sys.stderr)
         sys.exit(2)
-    env = dict(torch=torch, dist=dist, pipe=pipe, barrier=barrier, device=device, force_sharded=force_sharded, native=False, comm=None,
-               exchange=None)
+    env = dict(torch=torch, dist=dist, pipe=pipe, barrier=barrier, device=device, force_sharded=force_sharded, comm=None)
     transport_note = None
     if sharded_path:
-        # The substep protocol runs inside the library over RCCL (wgs_sharded_step). WGS_EXCHANGE=torch, a gloo process
-        # group (one-GPU functional mode) or a failing communicator fall back to the python-driven protocol over
-        # torch.distributed point-to-point — on every rank or none.
-        want_native = os.environ.get("WGS_EXCHANGE", "rccl") == "rccl" and dist.get_backend() == "nccl"
-        comm = None
-        if want_native:
-            try:
-                from wgsparkl_amd.sharded import NativeComm
-                comm = NativeComm(pipe, dist, rank, world)
-            except Exception as e:  # noqa: BLE001 — any failure here means "use the torch transport", on every rank
-                transport_note = f"wgs_comm_create failed ({e}); python-driven protocol over torch.distributed"
-                print(f"[bench rank {rank}] {transport_note}", file=sys.stderr)
-                comm = None
-        ok = torch.tensor([1 if comm is not None else 0], device=device if dist.get_backend() == "nccl" else "cpu", dtype=torch.int32)
-        dist.all_reduce(ok, op=dist.ReduceOp.MIN)      # all ranks or none
-        if int(ok.item()) == 1:
-            env["native"], env["comm"] = True, comm
-        else:
-            from wgsparkl_amd.sharded import FixedExchange
-            env["exchange"] = FixedExchange(dist, rank, world)
+        # The substep protocol runs inside the library over RCCL (wgs_sharded_step); torch.distributed only makes the
+        # process group of this harness and hands the 128-byte unique id around. No communicator, no run: on every rank.
+        comm, why = None, ""
+        try:
+            from wgsparkl_amd.sharded import NativeComm
+            comm = NativeComm(pipe, dist, rank, world)
+        except Exception as e:  # noqa: BLE001 — reported below, after all ranks agreed
+            why = str(e)
+        ok = torch.tensor([1 if comm is not None else 0], device=device, dtype=torch.int32)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if int(ok.item()) != 1:
+            print(f"[bench rank {rank}] wgs_comm_create failed on some rank ({why or 'not this one'}): no multi-GPU run", file=sys.stderr)
+            dist.destroy_process_group()
+            sys.exit(4)
+        env["comm"] = comm
 
     # ---- N > 1: the decomposition validates itself before anything is timed (a small bar on all ranks through
     # wgs_sharded_step against the single-domain run of the same bar on rank 0: ids exact, pos / vel rel RMS < 1e-5)
     validation_sharded = None
-    if sharded_path and world > 1 and env["native"]:
+    if sharded_path and world > 1:
         from wgsparkl_amd.selfcheck import bar_check
         validation_sharded = bar_check(pipe, dist, env["comm"], world, rank)
         if not validation_sharded["ok"]:
@@ -374,7 +356,7 @@ def main():
             sys.exit(3)
 
     # ---- extra legs (default command only): other states of the solver, each with its own G2P roofline figure
-    if not args.no_extra and default_workload and not one_gpu:
+    if not args.no_extra and default_workload:
         extra = {}
         k, w = min(args.steps, 50), 5
         slim = lambda r, name: {"workload": name, "value": r["value"], "unit": "particle-steps/s", "ms_per_step": r["ms_per_step"],

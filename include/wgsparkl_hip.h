@@ -313,84 +313,66 @@ wgs_status wgs_debug_scan(wgs_pipeline *pipeline, const uint32_t *values, uint32
 /* ---------------------------------------------------------------------------------------------
  * Multi-GPU (x-slab domain decomposition). NEW DESIGN: the reference is single-GPU (one wgpu::Device,
  * src/pipeline.rs:176-193; SURVEY.md sections 5 and 8e). One process per GPU owns the particles whose
- * associated block has bx in [block_lo, block_hi). The host (wgsparkl_amd/sharded.py, or any MPI-like
- * driver) moves the packed device buffers between neighbours (RCCL send/recv over xGMI).
- * One substep:  step_begin -> pack_halo(both faces) -> exchange -> add_halo -> step_end ->
- *               pack_migrants -> exchange -> add_migrants   (no host synchronisation anywhere).
+ * associated block has bx in [block_lo, block_hi) — its core range — and ONE neighbour exchange per substep
+ * (wgsparkl_amd/csrc/kernels_shard.h): after P2G both neighbours swap the partial (momentum, mass) sums of the node
+ * layers they share, and in the SAME message the records of the particles that left the sender's core range in the
+ * previous substep; the old owner still transfers such a particle to the grid in this substep, the new owner runs its
+ * G2P + particle update from the message and keeps it. No host synchronisation anywhere inside a substep.
  * `global_ids` are the particles' ids in the global scene (the canonical summation order is by id, so a
- * sharded run reproduces the single-GPU sums). All ranks must pass the same `force_plastic`. */
+ * sharded run reproduces the single-GPU sums). All ranks must pass the same `force_plastic`.
+ * The caller replays the reference contract — one call per frame, src_testbed/step.rs:122-128:
+ *   rank 0: wgs_comm_get_unique_id(id) -> the host broadcasts the 128 bytes (MPI, torch.distributed, a file ...)
+ *   every rank: wgs_comm_create(pipeline, id, rank, world, 0, &comm)      (ncclCommInitRank; rank r talks to r-1, r+1)
+ *               wgs_data_create_sharded(...); wgs_shard_attach(data, comm, 0, 0, halo_cap, mig_cap)
+ *   per frame:  wgs_sharded_step(pipeline, data, num_substeps); ... wgs_sync(data)
+ * RCCL point-to-point is the transport, bound at run time with dlopen("librccl.so.1"): the library has no link-time
+ * dependency on RCCL and single-GPU users never load it. */
 wgs_status wgs_data_create_sharded(wgs_pipeline *pipeline, const wgs_sim_params *params,
                                    const wgs_particle *particles, size_t num_particles, const uint32_t *global_ids,
                                    const wgs_collider *colliders, size_t num_colliders, float cell_width,
                                    uint32_t grid_capacity, uint32_t particle_capacity, int32_t block_lo,
                                    int32_t block_hi, int32_t force_plastic, wgs_data **out);
-uint32_t wgs_shard_halo_record_bytes(void);      /* key + partial sums of the two interface node layers of a block */
-uint32_t wgs_shard_particle_record_bytes(void);  /* full particle state */
-uint32_t wgs_shard_buffer_header_bytes(void);    /* every exchange buffer = header ([count,-,-,-]) + capacity records */
-/* Run this wgs_data on the caller's HIP stream (e.g. the stream RCCL work is ordered on), so that kernels
- * and neighbour messages need no host synchronisation between them. The handle does not take ownership. */
+/* Sizes of the records a message holds (for choosing the capacities of wgs_shard_attach and reading wgs_shard_export):
+ * a halo record = key + the partial sums of ONE x-layer pair of a block (2 * BW^(D-1) nodes); a particle record = the
+ * quads of wgsparkl_amd/csrc/layout.h + persistent id + cdf epoch — in uniform-material mode (wgs_set_uniform_material;
+ * 3D) the fourth word of its first quad holds F[8] instead of the mass and its F2 quad is not maintained. */
+uint32_t wgs_shard_halo_record_bytes(void);
+uint32_t wgs_shard_particle_record_bytes(void);
+uint32_t wgs_shard_buffer_header_bytes(void);    /* every message / export buffer = header + records */
+/* Run this wgs_data on the caller's HIP stream, so that its kernels are ordered with the caller's own work without host
+ * synchronisation. The handle does not take ownership; the stream must outlive it. */
 wgs_status wgs_set_stream(wgs_data *data, void *hip_stream);
-/* All of the following are ASYNCHRONOUS (stream-ordered) and fixed-capacity: buffers are device memory of
- * header + capacity_records * record bytes; the record count travels in the header. Overflowing a buffer or
- * the particle capacity is reported by the next wgs_sync(). */
-/* Optional: the four outgoing message buffers this rank reuses every substep (halo to the lower / upper neighbour,
- * migrants to the lower / upper neighbour; NULL where there is none). Their record counts are then reset inside
- * the substep instead of by a launch of their own in every wgs_shard_pack_*. */
-wgs_status wgs_shard_register_buffers(wgs_data *data, void *halo_out_lo, void *halo_out_hi, void *mig_out_lo, void *mig_out_hi);
-/* wgs_shard_pack_halo for both faces / wgs_shard_add_halo for both neighbours in ONE launch each (NULL = no neighbour) */
-wgs_status wgs_shard_pack_halos(wgs_data *data, void *buf_lo, void *buf_hi, uint32_t capacity_records);
-wgs_status wgs_shard_add_halos(wgs_data *data, const void *in_lo, const void *in_hi, uint32_t capacity_records);
-/* Optional, before wgs_shard_add_migrants of the previous substep's migration: re-bins the particles that stayed,
- * so that this pass overlaps the migration messages still in flight; wgs_shard_step_begin then bins the arrivals
- * only. A no-op on the substeps that need the full pass. */
-wgs_status wgs_shard_bin_residents(wgs_pipeline *pipeline, wgs_data *data);
-/* sort, CDF, P2G, gather of the partial node sums */
-wgs_status wgs_shard_step_begin(wgs_pipeline *pipeline, wgs_data *data);
-/* partial sums of the active blocks of layer `layer_bx` (= this rank's block_hi, or its block_lo) */
-wgs_status wgs_shard_pack_halo(wgs_data *data, int32_t layer_bx, void *device_buf, uint32_t capacity_records);
-/* add a neighbour's partial sums */
-wgs_status wgs_shard_add_halo(wgs_data *data, const void *device_buf, uint32_t capacity_records);
-/* grid update + fused G2P / particle update */
-wgs_status wgs_shard_step_end(wgs_pipeline *pipeline, wgs_data *data);
-/* particles that left [block_lo, block_hi): those that crossed the lower face -> dev_lo, the upper face -> dev_hi */
-wgs_status wgs_shard_pack_migrants(wgs_data *data, void *dev_lo, void *dev_hi, uint32_t capacity_records);
-/* append the particles received from the lower / upper neighbour (either may be NULL) and update the device-side
- * counts; out_lo / out_hi are the buffers this rank packed in the same round (NULL where there is no neighbour) */
-wgs_status wgs_shard_add_migrants(wgs_data *data, const void *in_lo, const void *in_hi, const void *out_lo,
-                                  const void *out_hi, uint32_t capacity_records);
-/* full records of every particle currently owned (read-back of a sharded run; BLOCKING) */
+/* full records of every particle this rank holds (read-back of a sharded run; BLOCKING). Between two calls of
+ * wgs_sharded_step a rank also holds the particles that left its core range in the last substep: they are handed over
+ * with the next substep's message, every particle is held by exactly one rank at any time. */
 wgs_status wgs_shard_export(wgs_data *data, void *device_buf, uint32_t capacity_records, uint32_t *count);
 
-
-/* ---- One call per frame on sharded data (what src_testbed/step.rs:122-128 does on one device) --------------------
- * The whole substep protocol above — step_begin, pack_halos, exchange, add_halos, step_end, pack_migrants, exchange,
- * add_migrants — driven from inside the library, RCCL point-to-point as the transport (bound at run time with
- * dlopen("librccl.so.1"): the library has no link-time dependency on RCCL). One process per GPU:
- *   rank 0: wgs_comm_get_unique_id(id) -> the host broadcasts the 128 bytes (MPI, torch.distributed, a file ...)
- *   every rank: wgs_comm_create(pipeline, id, rank, world, 0, &comm)      (ncclCommInitRank; rank r talks to r-1, r+1)
- *               wgs_data_create_sharded(...); wgs_shard_attach(data, comm, 0, 0, halo_cap, mig_cap)
- *   per frame:  wgs_sharded_step(pipeline, data, num_substeps); ... wgs_sync(data)
- * Message buffers are owned by the wgs_data, fixed capacity (records per face), sent whole (no size handshake); an
- * overflow is reported by the next wgs_sync. Two-way coupled (dynamic) bodies: every rank accumulates the fixed-point
- * impulses of its own particles (src/solver/p2g.wgsl:142-155) and the 16 x 8 int32 sums are all-reduced before
- * integrate_bodies (src/solver/rigid_impulses.wgsl:94-137) — integers, so the result does not depend on the order. */
 #define WGS_COMM_ID_BYTES 128          /* ncclUniqueId */
 #define WGS_COMM_SELF_NEIGHBOURS 1     /* flag: the rank is its own lower and upper neighbour (one-GPU timing proxy of an interior rank) */
 typedef struct wgs_comm wgs_comm;
 wgs_status wgs_comm_get_unique_id(uint8_t id[WGS_COMM_ID_BYTES]);
 wgs_status wgs_comm_create(wgs_pipeline *pipeline, const uint8_t id[WGS_COMM_ID_BYTES], int32_t rank, int32_t world,
                            int32_t flags, wgs_comm **out);
+/* Every wgs_data attached to the communicator must have been synchronised (wgs_sync) or destroyed before. */
 void wgs_comm_destroy(wgs_comm *comm);
-/* Allocates and registers the four outgoing and four incoming message buffers of this slab. With a communicator the
- * neighbours are the ranks next to comm's (has_lower / has_upper are ignored); comm == NULL = a slab of a lockstep
- * group inside one process (wgs_sharded_step_lockstep), or a slab without neighbours. */
+/* Allocates the message buffers of this slab (one outgoing, one incoming per neighbour; owned by the wgs_data, fixed
+ * capacity, sent whole: no size handshake; an overflow is reported by the next wgs_sync). Call before the first step.
+ * With a communicator the neighbours are the ranks next to comm's (has_lower / has_upper are ignored); comm == NULL = a
+ * slab of a lockstep group inside one process (wgs_sharded_step_lockstep), or a slab without neighbours.
+ * `halo_capacity_records`: halo records per message — about twice the active blocks of a face of the slab (every block
+ * of the interface layer sends one x-layer pair, the blocks migrating particles touch a few more);
+ * `migrant_capacity`: particles that can cross one face in one substep. A slab with TWO neighbours must be at least
+ * 3 blocks wide. Two-way coupled (dynamic) bodies: every rank accumulates the fixed-point impulses of its own
+ * particles (src/solver/p2g.wgsl:142-155) and the 16 x 8 int32 sums are all-reduced before integrate_bodies
+ * (src/solver/rigid_impulses.wgsl:94-137) — integers, so the result does not depend on the order. */
 wgs_status wgs_shard_attach(wgs_data *data, wgs_comm *comm, int32_t has_lower, int32_t has_upper,
-                            uint32_t halo_capacity_blocks, uint32_t migrant_capacity);
+                            uint32_t halo_capacity_records, uint32_t migrant_capacity);
 /* `num_substeps` whole substeps of this rank's slab, asynchronous (MpmPipeline::queue_step + encode x N + submit,
  * src/pipeline.rs:195-281, for one slab of the decomposition). Every rank must call it with the same count. */
 wgs_status wgs_sharded_step(wgs_pipeline *pipeline, wgs_data *data, uint32_t num_substeps);
 /* The same phases for `num_slabs` slabs that live in ONE process on ONE device (passed in x order, attached with
- * comm == NULL), device-to-device copies as the transport: decomposition tests on a single GPU. */
+ * comm == NULL), device-to-device copies as the transport: decomposition tests on a single GPU. For the duration of
+ * the call the group's work is ordered on slab 0's stream; afterwards every slab's own stream waits for it. */
 wgs_status wgs_sharded_step_lockstep(wgs_pipeline *pipeline, wgs_data **slabs, uint32_t num_slabs, uint32_t num_substeps);
 
 #ifdef __cplusplus

@@ -239,7 +239,7 @@ class OracleState:
             "node_cdf_closest": np.zeros(nn, np.uint32), "impulses": np.zeros(16 * (D + (1 if D == 2 else 3)), np.int32),
         }
         # rigid particles of the mesh colliders (sampled on the host like the reference does)
-        from wgsparkl_amd.sampling import build_rigid_particles
+        from oracle.ref_sampling import build_rigid_particles
         rb = build_rigid_particles(colliders, D, float(cell_width))
         self.R = None
         if rb is not None:

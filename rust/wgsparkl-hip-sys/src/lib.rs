@@ -211,25 +211,9 @@ extern "C" {
     ) -> wgs_status;
     pub fn wgs_comm_destroy(c: *mut wgs_comm);
     pub fn wgs_shard_attach(
-        d: *mut wgs_data, comm: *mut wgs_comm, has_lower: i32, has_upper: i32, halo_capacity_blocks: u32, migrant_capacity: u32,
+        d: *mut wgs_data, comm: *mut wgs_comm, has_lower: i32, has_upper: i32, halo_capacity_records: u32, migrant_capacity: u32,
     ) -> wgs_status;
     pub fn wgs_sharded_step(p: *mut wgs_pipeline, d: *mut wgs_data, num_substeps: u32) -> wgs_status;
     pub fn wgs_sharded_step_lockstep(p: *mut wgs_pipeline, slabs: *mut *mut wgs_data, num_slabs: u32, num_substeps: u32) -> wgs_status;
-    // the per-phase view of the same protocol (a host that brings its own transport)
-    pub fn wgs_shard_register_buffers(
-        d: *mut wgs_data, halo_out_lo: *mut c_void, halo_out_hi: *mut c_void, mig_out_lo: *mut c_void, mig_out_hi: *mut c_void,
-    ) -> wgs_status;
-    pub fn wgs_shard_bin_residents(p: *mut wgs_pipeline, d: *mut wgs_data) -> wgs_status;
-    pub fn wgs_shard_step_begin(p: *mut wgs_pipeline, d: *mut wgs_data) -> wgs_status;
-    pub fn wgs_shard_pack_halos(d: *mut wgs_data, buf_lo: *mut c_void, buf_hi: *mut c_void, capacity_records: u32) -> wgs_status;
-    pub fn wgs_shard_add_halos(d: *mut wgs_data, in_lo: *const c_void, in_hi: *const c_void, capacity_records: u32) -> wgs_status;
-    pub fn wgs_shard_pack_halo(d: *mut wgs_data, layer_bx: i32, device_buf: *mut c_void, capacity_records: u32) -> wgs_status;
-    pub fn wgs_shard_add_halo(d: *mut wgs_data, device_buf: *const c_void, capacity_records: u32) -> wgs_status;
-    pub fn wgs_shard_step_end(p: *mut wgs_pipeline, d: *mut wgs_data) -> wgs_status;
-    pub fn wgs_shard_pack_migrants(d: *mut wgs_data, dev_lo: *mut c_void, dev_hi: *mut c_void, capacity_records: u32) -> wgs_status;
-    pub fn wgs_shard_add_migrants(
-        d: *mut wgs_data, in_lo: *const c_void, in_hi: *const c_void, out_lo: *const c_void, out_hi: *const c_void,
-        capacity_records: u32,
-    ) -> wgs_status;
     pub fn wgs_shard_export(d: *mut wgs_data, device_buf: *mut c_void, capacity_records: u32, count: *mut u32) -> wgs_status;
 }

@@ -1,74 +1,100 @@
-"""CPU checker backend for the multi-GPU protocol of wgsparkl_amd/sharded.py: the same phases
-(step_begin / pack_halo / add_halo / step_end / pack_migrants / add_migrants) on top of the C oracle,
-so that the decomposition can be exercised under torch.distributed(gloo) without a GPU.
-TEST INFRASTRUCTURE ONLY."""
+"""CPU checker of the multi-GPU substep protocol (wgsparkl_amd/csrc/kernels_shard.h, capi_sharded.inc) — the SAME
+protocol restated on top of the C oracle's passes, so that the decomposition can be exercised under
+torch.distributed (gloo) without a GPU, in fp64, against the single-domain oracle run:
+
+  sort .. P2G over everything the rank holds (its core particles + the GUESTS that left the core range one substep ago)
+  | message per neighbour = partial node sums of the shared x-layer pairs + the guests' records (state before this G2P)
+  | add what the neighbours sent | grid update | G2P + particle update of the core particles AND of the arrivals (from
+  the node values this rank holds, or — where a block is not active here — from the sender's partial sums) | guests dropped.
+
+TEST INFRASTRUCTURE ONLY (imports the oracle)."""
 import numpy as np
 import torch
 
 from oracle.orc import Oracle
-from wgsparkl_amd.sharded import associated_block_x
+from wgsparkl_amd.sharded import INT_MAX, INT_MIN, associated_block_x
 from wgsparkl_amd.solver import ParticleSet
 
 FIELDS = ("pos", "vel", "def_grad", "affine", "cdf_normal", "cdf_rigid_vel", "cdf_dist", "init_volume", "mass",
           "lambda_", "mu", "dp", "dp_state", "phase")
 
 
+def iface_masks(bx, lo, hi, has_lo, has_hi, ntag):
+    """kernels_shard.h iface_masks: (gather, from_nodes, send_lo, send_hi) bit masks over the x-layer pairs of layer bx."""
+    ALL = (1 << ntag) - 1
+    g = f = sl = sh = 0
+    if has_lo:
+        if bx == lo - 1: g |= ALL; sl |= ALL
+        if bx == lo: g |= ALL; sl |= 1; f |= ALL
+        if bx == lo + 1: g |= 1; f |= 1
+    if has_hi:
+        if bx == hi - 1: g |= ALL; f |= ALL
+        if bx == hi: g |= ALL; sh |= ALL; f |= 1
+        if bx == hi + 1: g |= 1; sh |= 1
+    return g, f, sl, sh
+
+
 class OracleShard:
     def __init__(self, scene, sub: ParticleSet, gids, block_lo, block_hi, has_lower, has_upper, dtype=np.float64):
         self.scene, self.dtype = scene, np.dtype(dtype)
         self.dim = sub.dim
+        assert not scene["colliders"], "the CPU checker covers the collider-free protocol"
         self.orc = Oracle(self.dim, dtype)
-        self.block_lo, self.block_hi, self.has_lower, self.has_upper = block_lo, block_hi, has_lower, has_upper
+        self.lo, self.hi = int(block_lo), int(block_hi)
+        self.has_lower, self.has_upper = has_lower, has_upper
+        if has_lower and has_upper:
+            assert self.hi - self.lo >= 3, "a slab with two neighbours must be at least 3 blocks wide"
         self.bw = 4 if self.dim == 3 else 8
+        self.ntag = self.bw // 2
+        t = np.arange(64)
+        self.node_lx = t % self.bw                      # x coordinate of a node inside its block
         self.gids = np.asarray(gids, np.int64)
-        self._make_state({k: np.asarray(getattr(sub, k), dtype) for k in FIELDS}, sub.cdf_affinity.copy())
+        self.st = self._make_state({k: np.asarray(getattr(sub, k), dtype) for k in FIELDS}, sub.cdf_affinity.copy())
+        self.guest = np.zeros(len(self.gids), bool)     # residents that left the core range in the last G2P
+        self.sent = 0
 
     def _make_state(self, arrs, aff):
         n = len(aff)
         ps = ParticleSet(dim=self.dim, cdf_affinity=aff.astype(np.uint32), init_radius=np.zeros(n, np.float32),
                          has_plasticity=np.ones(n, bool), has_phase=np.ones(n, bool), **arrs)
         sc = self.scene
-        self.st = self.orc.new_state(ps, sc["params"], sc["colliders"], sc["cell_width"], sc["grid_capacity"], sc.get("model", 0))
+        return self.orc.new_state(ps, sc["params"], sc["colliders"], sc["cell_width"], sc["grid_capacity"], sc.get("model", 0))
 
-    # ---- protocol
-    def bin_residents(self):
-        """(an optimisation hook of the GPU backend: nothing to pre-compute for the CPU oracle)"""
-
-    def step_begin(self):
-        st = self.st
-        st.sort(); st.grid_update_cdf(); st.g2p_cdf(); st.p2g()
-
-    def _layer_nodes(self):
-        t = np.arange(64)
-        lx = t % self.bw
-        return np.nonzero(lx < 2)[0]
-
-    def pack_halo(self, layer_bx):
+    # ---- phase A: sort .. P2G, messages
+    def begin(self):
+        """Returns (to_lower, to_upper): flat float64 tensors, None where there is no neighbour."""
         st, D = self.st, self.dim
+        st.sort(); st.grid_update_cdf(); st.g2p_cdf(); st.p2g()
         nb = st.n_blocks
         vid = st.g["block_vid"][:nb]
-        sel = np.nonzero(vid[:, 0] == layer_bx)[0]
-        nodes = self._layer_nodes()
         mv = st.g["node_mv"].reshape(-1, 64, D + 1)
-        rec = np.concatenate([vid[sel].astype(np.float64), mv[sel][:, nodes, :].reshape(len(sel), len(nodes) * (D + 1))], axis=1)
-        return torch.from_numpy(np.ascontiguousarray(rec.reshape(-1)))
-
-    def add_halo(self, recs):
-        st, D = self.st, self.dim
-        nodes = self._layer_nodes()
-        w = D + len(nodes) * (D + 1)
-        rec = recs.numpy().reshape(-1, w)
-        nb = st.n_blocks
-        index = {tuple(v): b for b, v in enumerate(st.g["block_vid"][:nb])}
-        mv = st.g["node_mv"].reshape(-1, 64, D + 1)
-        for r in rec:
-            b = index.get(tuple(int(x) for x in r[:D]))
-            if b is not None:
-                mv[b, nodes, :] += r[D:].reshape(len(nodes), D + 1)
-
-    def step_end(self):
-        st = self.st
-        st.grid_update(); st.g2p(); st.particle_update()
+        halo = ([], [])
+        for b in range(nb):
+            _, _, sl, sh = iface_masks(int(vid[b, 0]), self.lo, self.hi, self.has_lower, self.has_upper, self.ntag)
+            for f, send in ((0, sl), (1, sh)):
+                for tag in range(self.ntag):
+                    if not (send >> tag) & 1:
+                        continue
+                    nodes = np.nonzero(self.node_lx // 2 == tag)[0]
+                    vals = mv[b, nodes, :]
+                    regular = tag == 0 and int(vid[b, 0]) == (self.lo if f == 0 else self.hi)
+                    if regular or np.any(vals != 0):
+                        halo[f].append(np.concatenate([vid[b].astype(np.float64), [float(tag)], vals.reshape(-1)]))
+        # the guests' records: state BEFORE this substep's G2P
+        bx = associated_block_x(st.arr["pos"].astype(np.float32), self.scene["cell_width"], D)
+        assert np.array_equal(self.guest, (bx < self.lo) | (bx >= self.hi)), "the guest list must be the residents outside the core range"
+        out = []
+        self.sent = int(self.guest.sum())
+        for f, sel in ((0, bx < self.lo), (1, bx >= self.hi)):
+            if not (self.has_lower if f == 0 else self.has_upper):
+                assert not sel.any(), "a particle left the decomposition"
+                out.append(None)
+                continue
+            recs = self._records(np.nonzero(sel)[0])
+            h = np.stack(halo[f]) if halo[f] else np.zeros((0, 0))
+            msg = np.concatenate([[float(len(h)), float(len(recs))], h.reshape(-1), recs.reshape(-1)])
+            out.append(torch.from_numpy(np.ascontiguousarray(msg)))
+        return tuple(out)
 
     def _records(self, idx):
         a = self.st.arr
@@ -77,39 +103,141 @@ class OracleShard:
         cols += [a["cdf_affinity"][idx].reshape(len(idx), 1).astype(np.float64), self.gids[idx].reshape(len(idx), 1).astype(np.float64)]
         return np.concatenate(cols, axis=1)
 
-    def pack_migrants(self):
-        bx = associated_block_x(self.st.arr["pos"].astype(np.float32), self.scene["cell_width"], self.dim)
-        lo = np.nonzero(bx < self.block_lo)[0]
-        hi = np.nonzero(bx >= self.block_hi)[0]
-        out = (self._records(lo), self._records(hi))
-        keep = np.nonzero((bx >= self.block_lo) & (bx < self.block_hi))[0]
-        arrs = {k: self.st.arr[k][keep] for k in FIELDS}
-        aff = self.st.arr["cdf_affinity"][keep]
-        self.gids = self.gids[keep]
-        self._make_state(arrs, aff)
-        return tuple(torch.from_numpy(np.ascontiguousarray(o.reshape(-1))) for o in out)
-
-    def add_migrants(self, in_lower, in_upper):
-        for recs in (in_lower, in_upper):
-            self._add_migrants(recs)
-
-    def _add_migrants(self, recs):
-        if recs is None or recs.numel() == 0:
-            return
+    def _parse(self, msg):
+        D = self.dim
+        nodes_per = 64 // self.ntag
+        m = msg.numpy()
+        nh, nm = int(m[0]), int(m[1])
+        wh = D + 1 + nodes_per * (D + 1)
+        halo = m[2:2 + nh * wh].reshape(nh, wh)
         a = self.st.arr
         widths = [int(np.prod(a[k].shape[1:])) if a[k].ndim > 1 else 1 for k in FIELDS]
-        w = sum(widths) + 2
-        rec = recs.numpy().reshape(-1, w)
-        arrs, off = {}, 0
-        for k, wd in zip(FIELDS, widths):
-            new = rec[:, off:off + wd].reshape((len(rec),) + a[k].shape[1:])
-            arrs[k] = np.concatenate([a[k], new.astype(a[k].dtype)])
-            off += wd
-        aff = np.concatenate([a["cdf_affinity"], rec[:, off].astype(np.uint32)])
-        self.gids = np.concatenate([self.gids, rec[:, off + 1].astype(np.int64)])
-        self._make_state(arrs, aff)
+        wr = sum(widths) + 2
+        recs = m[2 + nh * wh:2 + nh * wh + nm * wr].reshape(nm, wr)
+        return halo, recs, widths
+
+    # ---- phase B: add, grid update, G2P of the core particles and the arrivals, guests dropped
+    def end(self, from_lower, from_upper):
+        st, D = self.st, self.dim
+        nb = st.n_blocks
+        vid = st.g["block_vid"][:nb]
+        index = {tuple(int(x) for x in v): b for b, v in enumerate(vid)}
+        mv = st.g["node_mv"].reshape(-1, 64, D + 1)
+        nodes_per = 64 // self.ntag
+        orphans = {}                                   # (block vid, pair) -> partial sums of a block not active here
+        arrivals = []
+        widths = None
+        for msg in (from_lower, from_upper):
+            if msg is None:
+                continue
+            halo, recs, widths = self._parse(msg)
+            for r in halo:
+                key, tag = tuple(int(x) for x in r[:D]), int(r[D])
+                vals = r[D + 1:].reshape(nodes_per, D + 1)
+                nodes = np.nonzero(self.node_lx // 2 == tag)[0]
+                b = index.get(key)
+                if b is not None:
+                    mv[b, nodes, :] += vals
+                else:
+                    orphans[(key, tag)] = vals
+            if len(recs):
+                arrivals.append(recs)
+        st.grid_update()
+        # arrivals: a tiny state of their own whose grid is filled with this rank's node velocities (or the sender's totals)
+        new_arr = None
+        if arrivals:
+            rec = np.concatenate(arrivals)
+            arrs, off = {}, 0
+            for k, wd in zip(FIELDS, widths):
+                shape = (len(rec),) + st.arr[k].shape[1:]
+                arrs[k] = rec[:, off:off + wd].reshape(shape).astype(self.dtype)
+                off += wd
+            aff = rec[:, off].astype(np.uint32)
+            gid = rec[:, off + 1].astype(np.int64)
+            tiny = self._make_state(arrs, aff)
+            tiny.sort()
+            tnb = tiny.n_blocks
+            tvid = tiny.g["block_vid"][:tnb]
+            tmv = tiny.g["node_mv"].reshape(-1, 64, D + 1)
+            prm = self.scene["params"]
+            g, dt, h = np.asarray(prm.gravity, np.float64), float(prm.dt), float(self.scene["cell_width"])
+            for tb in range(tnb):
+                key = tuple(int(x) for x in tvid[tb])
+                b = index.get(key)
+                if b is not None:
+                    tmv[tb] = mv[b]                    # velocities: the grid update ran on the totals
+                    continue
+                tmv[tb] = 0.0
+                for tag in range(self.ntag):
+                    vals = orphans.get((key, tag))
+                    if vals is None:
+                        continue
+                    nodes = np.nonzero(self.node_lx // 2 == tag)[0]
+                    mass = vals[:, D]
+                    with np.errstate(divide="ignore", invalid="ignore"):
+                        inv = np.where(mass > 0, 1.0 / mass, 0.0)
+                    vel = np.clip((vals[:, :D] + mass[:, None] * g[None, :] * dt) * inv[:, None], -h / dt, h / dt)
+                    tmv[tb, nodes, :D] = vel
+                    tmv[tb, nodes, D] = mass
+            tiny.g2p(); tiny.particle_update()
+            new_arr = (tiny, gid)
+        st.g2p(); st.particle_update()
+        keep = ~self.guest                              # the guests now live on the neighbour
+        arrs = {k: st.arr[k][keep] for k in FIELDS}
+        aff = st.arr["cdf_affinity"][keep]
+        gids = self.gids[keep]
+        if new_arr is not None:
+            tiny, gid = new_arr
+            arrs = {k: np.concatenate([arrs[k], tiny.arr[k]]) for k in FIELDS}
+            aff = np.concatenate([aff, tiny.arr["cdf_affinity"]])
+            gids = np.concatenate([gids, gid])
+        self.gids = gids
+        self.st = self._make_state(arrs, aff)
+        bx = associated_block_x(self.st.arr["pos"].astype(np.float32), self.scene["cell_width"], D)
+        self.guest = (bx < self.lo) | (bx >= self.hi)
+        assert ((bx >= self.lo - 1) & (bx <= self.hi)).all(), "a particle moved more than one block in a substep"
 
     def export(self):
         a = self.st.arr
         return dict(ids=self.gids.copy(), pos=a["pos"].copy(), vel=a["vel"].copy(), def_grad=a["def_grad"].copy(),
                     affine=a["affine"].copy())
+
+
+class DistExchange:
+    """Neighbour exchange over torch.distributed point-to-point ops (gloo on CPU): sizes, then payloads."""
+
+    def __init__(self, dist, rank: int, world: int):
+        self.dist, self.rank, self.world = dist, rank, world
+
+    def __call__(self, to_lower, to_upper):
+        dist = self.dist
+        lower = self.rank - 1 if self.rank > 0 else None
+        upper = self.rank + 1 if self.rank < self.world - 1 else None
+        sends = {lower: to_lower, upper: to_upper}
+        ops, rsize = [], {}
+        for peer in (lower, upper):
+            if peer is None:
+                continue
+            n_out = torch.tensor([int(sends[peer].numel())], dtype=torch.int64)
+            rsize[peer] = torch.zeros(1, dtype=torch.int64)
+            ops += [dist.P2POp(dist.isend, n_out, peer), dist.P2POp(dist.irecv, rsize[peer], peer)]
+        for w in (dist.batch_isend_irecv(ops) if ops else []):
+            w.wait()
+        ops, recv = [], {}
+        for peer in (lower, upper):
+            if peer is None:
+                continue
+            recv[peer] = torch.empty(int(rsize[peer].item()), dtype=torch.float64)
+            ops += [dist.P2POp(dist.isend, sends[peer].contiguous(), peer), dist.P2POp(dist.irecv, recv[peer], peer)]
+        for w in (dist.batch_isend_irecv(ops) if ops else []):
+            w.wait()
+        return recv.get(lower), recv.get(upper)
+
+
+def lockstep(shards, k):
+    """All ranks inside one process (no transport): what the gloo run must equal, and a quick CPU check of the protocol."""
+    n = len(shards)
+    for _ in range(k):
+        msgs = [s.begin() for s in shards]
+        for r, s in enumerate(shards):
+            s.end(msgs[r - 1][1] if r > 0 else None, msgs[r + 1][0] if r < n - 1 else None)

@@ -142,30 +142,41 @@ def test_c5_sixteen_million_fluid(hip_libs):
     assert np.abs(p).max() < 1e-4 * (got2.mass[:, None].astype(np.float64) * np.abs(got2.vel)).sum() + 1e-6
 
 
+def _slab_shards(pipe, make_slab, world, velocity, **caps):
+    """`world` NativeShards of a lockstep group, each generated by make_slab(world, rank) and given velocity(global ids)."""
+    from wgsparkl_amd.sharded import NativeShard, uniform_material_of
+    shards, total = [], 0
+    for rank in range(world):
+        sc = make_slab(world, rank)
+        ps = sc["particles"]
+        velocity(ps, sc["global_ids"].astype(np.float64))
+        total += ps.n
+        lo, hi = sc["partition"].block_range(rank)
+        shards.append(NativeShard(pipe, sc["params"], ps, sc["global_ids"], sc["colliders"], sc["cell_width"], sc["grid_capacity"], lo, hi,
+                                  rank > 0, rank < world - 1, particle_capacity=int(ps.n * 1.5) + 4096, model=sc["model"],
+                                  uniform_material=uniform_material_of(ps), **caps))
+    return shards, total
+
+
 def test_c5_strong_scaling_slabs_on_one_gpu(hip_libs):
     """The decomposition bench.py --config c5 --scaling strong uses, 8 x-slabs of the fluid block advanced in
-    lockstep on one GPU at a reduced y/z extent: nobody is lost, the slabs reproduce the single-domain run."""
+    lockstep on one GPU (wgs_sharded_step_lockstep: the per-phase code of wgs_sharded_step, device-to-device copies as the
+    transport) at a reduced y/z extent: nobody is lost, the slabs reproduce the single-domain run."""
     from helpers import pipeline
-    from wgsparkl_amd import MpmData
-    from wgsparkl_amd.sharded import GpuShard, lockstep_substep
+    from wgsparkl_amd.sharded import native_lockstep
     world, dims, k = 8, (256, 24, 24), 12
     pipe = pipeline(3)
     full = scenes.fluid_block(*dims)
     vel = lambda gid: np.stack([1.5 * np.sin(0.37 * gid), 0.3 * np.cos(0.11 * gid), 0.2 * np.sin(0.05 * gid)], 1).astype(np.float32)
     full["particles"].vel[:] = vel(np.arange(full["particles"].n, dtype=np.float64))
     ref = run_gpu(full, k).read_particles()
-    shards = []
-    for rank in range(world):
-        sc = scenes.fluid_block(*dims, world=world, rank=rank)
-        ps = sc["particles"]
-        ps.vel[:] = vel(sc["global_ids"].astype(np.float64))
-        lo, hi = sc["partition"].block_range(rank)
-        shards.append(GpuShard(pipe, sc["params"], ps, sc["global_ids"], sc["colliders"], sc["cell_width"],
-                               sc["grid_capacity"], lo, hi, rank > 0, rank < world - 1,
-                               particle_capacity=int(ps.n * 1.5) + 4096, model=sc["model"],
-                               halo_capacity_blocks=256, migrant_capacity=2048))
-    for _ in range(k):
-        lockstep_substep(shards)
+
+    def setv(ps, gid):
+        ps.vel[:] = vel(gid)
+    shards, total = _slab_shards(pipe, lambda w, r: scenes.fluid_block(*dims, world=w, rank=r), world, setv,
+                                 halo_capacity_records=512, migrant_capacity=2048)
+    assert total == full["particles"].n
+    native_lockstep(pipe, shards, k)
     ids, pos, velo = [], [], []
     for s in shards:
         s.sync()
@@ -178,29 +189,20 @@ def test_c5_strong_scaling_slabs_on_one_gpu(hip_libs):
 
 def test_bench_slabs_at_full_size_fit_their_exchange_buffers(hip_libs):
     """bench.py's N > 1 workload at its real size per rank (1M particles, two neighbouring slabs of the bar on one
-    GPU): the halo / migration buffers sized from the face area do not overflow and nobody is lost."""
+    GPU): the message buffers sized from the face area (bench.py's rule) do not overflow and nobody is lost."""
     from helpers import pipeline
-    from wgsparkl_amd.sharded import GpuShard, lockstep_finish, lockstep_pipelined_substep
+    from wgsparkl_amd.sharded import native_lockstep
     world, n_side, k = 2, 100, 20
     pipe = pipeline(3)
-    shards, total = [], 0
-    for rank in range(world):
-        sc = scenes.neo_hookean_bar(n_side=n_side, world=world, rank=rank)
-        ps = sc["particles"]
-        ps.vel[:, 0] = (2.0 * np.sin(0.37 * sc["global_ids"].astype(np.float64))).astype(np.float32)
-        total += ps.n
-        lo, hi = sc["partition"].block_range(rank)
-        shards.append(GpuShard(pipe, sc["params"], ps, sc["global_ids"], sc["colliders"], sc["cell_width"],
-                               sc["grid_capacity"], lo, hi, rank > 0, rank < world - 1,
-                               particle_capacity=int(ps.n * 1.25) + 4096, model=sc["model"],
-                               halo_capacity_blocks=(n_side // 8 + 3) ** 2 + 32, migrant_capacity=512))
+
+    def setv(ps, gid):
+        ps.vel[:, 0] = (6.0 + 2.0 * np.sin(0.37 * gid)).astype(np.float32)
+    shards, total = _slab_shards(pipe, lambda w, r: scenes.neo_hookean_bar(n_side=n_side, world=w, rank=r), world, setv,
+                                 halo_capacity_records=2 * ((n_side // 8 + 3) ** 2 + 32), migrant_capacity=max(512, n_side * n_side // 32))
     assert total == 2_000_000
-    pending = None
-    for _ in range(k):
-        pending = lockstep_pipelined_substep(shards, pending)
-    lockstep_finish(shards, pending)
+    native_lockstep(pipe, shards, k)
     for s in shards:
-        s.sync()                                       # raises on a halo / migration / capacity overflow
+        s.sync()                                       # raises on a message / capacity overflow
     n_now = [s.num_particles() for s in shards]
     assert sum(n_now) == total and n_now != [1_000_000, 1_000_000]
 

@@ -1,6 +1,6 @@
-"""-m "not gpu": the multi-GPU protocol (wgsparkl_amd/sharded.py) under torch.distributed with the gloo
-backend, world_size 2, with the CPU oracle as the per-rank solver: the decomposed run must reproduce the
-single-domain oracle run (fp64, so only the association of the interface sums differs)."""
+"""-m "not gpu": the multi-GPU substep protocol (wgsparkl_amd/csrc/kernels_shard.h) restated on the CPU oracle
+(tests/shard_oracle.py) under torch.distributed with the gloo backend, world_size 2 and 3: the decomposed run must
+reproduce the single-domain oracle run (fp64, so only the association of the interface sums differs)."""
 import os
 import subprocess
 import sys
@@ -23,21 +23,22 @@ def test_partition_helpers():
     assert counts.min() >= 200 and counts.sum() == 1000
 
 
-@pytest.mark.parametrize("dim,k,pipelined", [(3, 20, False), (2, 20, False), (3, 20, True)])
-def test_gloo_world2_matches_single_domain(oracle_libs, tmp_path, dim, k, pipelined):
+@pytest.mark.parametrize("dim,world,k", [(3, 2, 20), (2, 2, 20), (3, 3, 20)])
+def test_gloo_matches_single_domain(oracle_libs, tmp_path, dim, world, k):
+    """world_size 2 and 3 (an interior slab with two neighbours) over gloo: the one-exchange protocol — guests transferred
+    to the grid by their old owner, advanced by their new owner from the message — reproduces the single-domain run."""
     out = str(tmp_path / "shard")
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29611 + dim + (7 if pipelined else 0)), WORLD_SIZE="2",
-               OMP_NUM_THREADS="1", WGS_PIPELINED="1" if pipelined else "0")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29611 + dim + 10 * world), WORLD_SIZE=str(world), OMP_NUM_THREADS="1")
     procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "shard_gloo_worker.py"), str(dim), str(k), out],
                               env=dict(env, RANK=str(r)), stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
-             for r in range(2)]
-    logs = [p.communicate(timeout=300)[0].decode() for p in procs]
+             for r in range(world)]
+    logs = [p.communicate(timeout=600)[0].decode() for p in procs]
     assert all(p.returncode == 0 for p in procs), "\n".join(logs)
-    res = [np.load(f"{out}.rank{r}.npz") for r in range(2)]
+    res = [np.load(f"{out}.rank{r}.npz") for r in range(world)]
 
     sys.path.insert(0, HERE)
     from shard_gloo_worker import make_scene
-    sc = make_scene(dim)
+    sc = make_scene(dim, world)
     ps = sc["particles"]
     st = oracle_libs.Oracle(dim, np.float64).new_state(ps, sc["params"], sc["colliders"], sc["cell_width"],
                                                        sc["grid_capacity"], sc.get("model", 0))
@@ -54,10 +55,38 @@ def test_gloo_world2_matches_single_domain(oracle_libs, tmp_path, dim, k, pipeli
         assert err < 1e-9, (f, err)
 
 
-def test_fixed_exchange_routing_gloo_world3():
-    """FixedExchange (the transport bench.py uses over RCCL) routes lower/upper messages correctly; gloo, 3 ranks."""
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29631", WORLD_SIZE="3", OMP_NUM_THREADS="1")
-    procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "fixed_exchange_worker.py")], env=dict(env, RANK=str(r)),
-                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(3)]
-    logs = [p.communicate(timeout=120)[0].decode() for p in procs]
-    assert all(p.returncode == 0 for p in procs), "\n".join(logs)
+def test_protocol_lockstep_four_slabs_and_mask_table(oracle_libs):
+    """The same restated protocol with all ranks in one process (4 slabs: two interior ones), and the interface masks it
+    shares with kernels_shard.h spelt out for one slab."""
+    sys.path.insert(0, HERE)
+    from shard_gloo_worker import make_scene, partition_of
+    from shard_oracle import OracleShard, iface_masks, lockstep
+    from wgsparkl_amd.sharded import split_scene
+    # rank with core range [8, 12), both neighbours, 3D (2 x-layer pairs per block): what each layer is to it
+    m = {bx: iface_masks(bx, 8, 12, True, True, 2) for bx in range(6, 15)}
+    assert m[6] == (0, 0, 0, 0) and m[14] == (0, 0, 0, 0) and m[10] == (0, 0, 0, 0)
+    assert m[7] == (3, 0, 3, 0)          # layer lo - 1: only guests write it; everything they wrote goes down
+    assert m[8] == (3, 3, 1, 0)          # layer lo: first pair shared with the lower neighbour's core, all pairs may receive
+    assert m[9] == (1, 1, 0, 0)          # layer lo + 1: first pair may receive (the lower neighbour's guests)
+    assert m[11] == (3, 3, 0, 0)         # layer hi - 1: may receive (the upper neighbour's guests)
+    assert m[12] == (3, 1, 0, 3)         # layer hi: own core reaches the first pair, own guests all of it: all pairs go up
+    assert m[13] == (1, 0, 0, 1)         # layer hi + 1: own guests reach the first pair
+    world, k = 4, 12
+    sc = make_scene(3, world)
+    part = partition_of(sc, world)
+    assert part.min_interior_width() >= 3
+    shards = []
+    for r, (sub, gids) in enumerate(split_scene(sc["particles"], part, sc["cell_width"])):
+        lo, hi = part.block_range(r)
+        shards.append(OracleShard(sc, sub, gids, lo, hi, r > 0, r < world - 1))
+    n0 = [len(s.gids) for s in shards]
+    lockstep(shards, k)
+    st = oracle_libs.Oracle(3, np.float64).new_state(sc["particles"], sc["params"], sc["colliders"], sc["cell_width"], sc["grid_capacity"], sc.get("model", 0))
+    st.step(k)
+    outs = [s.export() for s in shards]
+    ids = np.concatenate([o["ids"] for o in outs])
+    assert np.array_equal(np.sort(ids), np.arange(sc["particles"].n)) and [len(o["ids"]) for o in outs] != n0
+    order = np.argsort(ids)
+    for f in ("pos", "vel", "def_grad", "affine"):
+        got, ref = np.concatenate([o[f] for o in outs])[order], st.arr[f]
+        assert np.sqrt(np.mean((got - ref) ** 2)) / max(np.sqrt(np.mean(ref * ref)), 1e-300) < 1e-9, f

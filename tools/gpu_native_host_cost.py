@@ -16,7 +16,7 @@ for self_nb in (False, True):
         bx = associated_block_x(ps.pos, sc["cell_width"], 3)
         lo, hi = int(bx.min()), int(bx.max()) + 2
     data = NativeShard(pipe, sc["params"], ps, sc["global_ids"], sc["colliders"], sc["cell_width"], sc["grid_capacity"], lo, hi, self_nb, self_nb,
-                       particle_capacity=int(ps.n * 1.25) + 4096, model=sc["model"], halo_capacity_blocks=(100 // 8 + 3) ** 2 + 32,
+                       particle_capacity=int(ps.n * 1.25) + 4096, model=sc["model"], halo_capacity_records=((100 // 8 + 3) ** 2) * 3 // 2 + 64,
                        migrant_capacity=512, comm=comm, uniform_material=uniform_material_of(ps))
     data.step(30); data.sync()
     for k in (100, 300, 100):

@@ -22,10 +22,7 @@ EXPORTS = (
     "wgs_read_grid", "wgs_read_blocks", "wgs_read_timings", "wgs_get_stats",
     # multi-GPU (x-slab decomposition; new design, no reference counterpart)
     "wgs_data_create_sharded", "wgs_shard_halo_record_bytes", "wgs_shard_particle_record_bytes",
-    "wgs_shard_buffer_header_bytes", "wgs_set_stream",
-    "wgs_shard_step_begin", "wgs_shard_bin_residents", "wgs_shard_register_buffers", "wgs_shard_pack_halos",
-    "wgs_shard_add_halos", "wgs_shard_pack_halo", "wgs_shard_add_halo", "wgs_shard_step_end",
-    "wgs_shard_pack_migrants", "wgs_shard_add_migrants", "wgs_shard_export",
+    "wgs_shard_buffer_header_bytes", "wgs_set_stream", "wgs_shard_export",
     # one call per frame on sharded data (RCCL inside the library) + build identification
     "wgs_comm_get_unique_id", "wgs_comm_create", "wgs_comm_destroy", "wgs_shard_attach", "wgs_sharded_step",
     "wgs_sharded_step_lockstep", "wgs_build_info", "wgs_debug_scan", "wgs_set_grid_growth", "wgs_set_uniform_material",
@@ -173,18 +170,8 @@ def load(dim: int):
                                             C.c_int32, C.c_int32, C.c_int32, C.POINTER(vp)]
     lib.wgs_shard_halo_record_bytes.restype = C.c_uint32
     lib.wgs_shard_particle_record_bytes.restype = C.c_uint32
-    lib.wgs_shard_step_begin.argtypes = [vp, vp]
-    lib.wgs_shard_bin_residents.argtypes = [vp, vp]
-    lib.wgs_shard_register_buffers.argtypes = [vp, vp, vp, vp, vp]
-    lib.wgs_shard_pack_halos.argtypes = [vp, vp, vp, C.c_uint32]
-    lib.wgs_shard_add_halos.argtypes = [vp, vp, vp, C.c_uint32]
-    lib.wgs_shard_step_end.argtypes = [vp, vp]
     lib.wgs_shard_buffer_header_bytes.restype = C.c_uint32
     lib.wgs_set_stream.argtypes = [vp, vp]
-    lib.wgs_shard_pack_halo.argtypes = [vp, C.c_int32, vp, C.c_uint32]
-    lib.wgs_shard_add_halo.argtypes = [vp, vp, C.c_uint32]
-    lib.wgs_shard_pack_migrants.argtypes = [vp, vp, vp, C.c_uint32]
-    lib.wgs_shard_add_migrants.argtypes = [vp, vp, vp, vp, vp, C.c_uint32]
     lib.wgs_shard_export.argtypes = [vp, vp, C.c_uint32, u32p]
     lib.wgs_build_info.restype = C.c_char_p
     lib.wgs_set_grid_growth.argtypes = [vp, C.c_int32]

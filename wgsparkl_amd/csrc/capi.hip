@@ -27,6 +27,7 @@
 #include "kernels_shard.h"
 #include "kernels_sort.h"
 #include "kernels_transfer.h"
+#include "kernels_arrivals.h"
 
 using namespace wgs;
 
@@ -77,14 +78,13 @@ struct wgs_comm {
     int lower = -1, upper = -1;   // peer ranks, -1 = none
     int device = 0;
 };
-struct ShardLink {                // device memory owned by the wgs_data: [count, -, -, -] + capacity records each
+struct ShardLink {                // device memory owned by the wgs_data: one message per face and direction (kernels_shard.h)
     bool attached = false;
     wgs_comm *comm = nullptr;     // null: lockstep transport (device-to-device copies inside one process)
     bool has_lower = false, has_upper = false;
     uint32_t halo_cap = 0, mig_cap = 0;
-    size_t halo_floats = 0, mig_floats = 0;
-    float *halo_out[2] = {nullptr, nullptr}, *halo_in[2] = {nullptr, nullptr};   // [lower, upper]
-    float *mig_out[2] = {nullptr, nullptr}, *mig_in[2] = {nullptr, nullptr};
+    size_t msg_floats = 0;
+    float *msg_out[2] = {nullptr, nullptr}, *msg_in[2] = {nullptr, nullptr};   // [lower, upper]
 };
 
 struct wgs_data {
@@ -96,13 +96,9 @@ struct wgs_data {
     bool plastic = false;
     bool cpic = false;
     bool prev_sorted = false;   // the current buffer is the sorted output of the previous substep (perm_cell, links valid)
-    bool tail_known = false;    // sharded: wgs_shard_add_migrants ran since the last substep (CTR_NPREV is current)
-    uint32_t tail_slots = 0;    // sharded: upper bound of the arrivals appended behind the residents
-    bool fused_halo = false;        // sharded: the caller uses wgs_shard_pack_halos / add_halos (registered with wgs_shard_register_buffers)
-    bool append_pending = false;    // sharded: wgs_shard_add_migrants recorded its buffers, the append has not run yet
-    MigIn mig{};                    // those buffers
-    bool needs_compact = false;     // sharded: the counters of the compacted buffer are still to be set
-    bool residents_binned = false;  // sharded: wgs_shard_bin_residents already ran k_rebin for the coming substep
+    uint32_t tail_slots = 0;    // sharded: upper bound of the arrivals k_g2p_arrivals wrote behind the residents in the last substep
+    bool needs_compact = false; // sharded: the last substep ran without its neighbours (wgs_step): the counters of its buffer are still to be set
+    bool in_sharded_step = false;  // the substep being enqueued belongs to wgs_sharded_step[_lockstep]: guests are dropped, arrivals advanced
     uint64_t substeps = 0;
     uint64_t device_bytes = 0;
     uint32_t sticky_errors = 0;
@@ -208,7 +204,7 @@ wgs_status alloc_grid(wgs_data *d) {
     GRID_ALLOC(&dev.cpic_list, (size_t)cap * 8);
     dev.visit_cap = dev.npad / 512u + 2u * cap + 16u;
     GRID_ALLOC(&dev.visit_list, (size_t)dev.visit_cap * 8);
-    if (dev.sharded) GRID_ALLOC(&dev.halo_list, (size_t)cap * 2);
+    if (dev.sharded) GRID_ALLOC(&dev.halo_list, (size_t)cap);
     if (d->two_way) GRID_ALLOC(&dev.imp_slab, cap * Dim<D>::TILE * (D == 3 ? 2 : 1));
     if (dev.mesh_min) {
         GRID_ALLOC(&dev.mesh_min, cap * NPB);
@@ -232,23 +228,30 @@ void release_alloc(wgs_data *d, void *p) {
 
 // SURVEY 8f4, second half — the reference's resize loop is a stub (src/grid/grid.rs:43-45,116-117: "TODO: resize the
 // hashmap and retry"). Here the block capacity doubles BEFORE the table fills: a new zeroed set of grid arrays replaces
-// the old one and the next substep rebuilds the table from the particles (the same full pass every 64th substep runs).
+// the old one and the next substep rebuilds the table from the particles (the same full pass a table rebuild runs).
 // Particle state is untouched, so nothing is lost; the stream is drained once (rare).
 wgs_status grow_grid(wgs_data *d, uint32_t new_cap) {
     Dev &dev = d->dev;
     HIP_TRY(hipStreamSynchronize(d->stream));
-    void *old[] = {dev.hkeys, dev.hvals, dev.block_key, dev.block_count, dev.block_stamp, dev.links_epoch, dev.block_acc, dev.active,
-                   dev.block_start, dev.nbr_plus, dev.nbr_minus, dev.nbr_known, dev.act_src, dev.cell_head, dev.chunk_a, dev.chunk_b, dev.group_a, dev.group_b,
-                   dev.cell_start, dev.cell_cursor, dev.nodes, dev.node_cdf, dev.slab, dev.block_cdf_flag, dev.block_cpic, dev.cpic_list, dev.visit_list, dev.halo_list,
-                   dev.imp_slab, dev.mesh_min, dev.mesh_aff};
-    for (void *p : old) release_alloc(d, p);
-    dev.imp_slab = nullptr;  // (alloc_grid re-creates what was in use: two_way / mesh_min say so)
-    const bool had_mesh = dev.mesh_min != nullptr;
+    // The new set is allocated BEFORE the old one is released: if the device cannot hold both, the old table stays in
+    // place, growth is switched off for this wgs_data and the run continues (an overflow is then reported as such).
+    const Dev old = dev;
+    const size_t first_new = d->allocs.size();
     dev.cap = new_cap;
     dev.hmask = new_cap * 2u - 1u;
-    if (!had_mesh) dev.mesh_min = nullptr;
-    wgs_status st = alloc_grid(d);
-    if (st != WGS_OK) return st;
+    const wgs_status st = alloc_grid(d);  // (re-creates the optional arrays that are in use: two_way / mesh_min / sharded say so)
+    if (st != WGS_OK) {
+        while (d->allocs.size() > first_new) release_alloc(d, d->allocs.back());
+        dev = old;
+        d->auto_grow = false;
+        hipGetLastError();  // (the failed hipMalloc is not this call's error)
+        return WGS_OK;
+    }
+    void *old_ptrs[] = {old.hkeys, old.hvals, old.block_key, old.block_count, old.block_stamp, old.links_epoch, old.block_acc, old.active,
+                        old.block_start, old.nbr_plus, old.nbr_minus, old.nbr_known, old.act_src, old.cell_head, old.chunk_a, old.chunk_b, old.group_a, old.group_b,
+                        old.cell_start, old.cell_cursor, old.nodes, old.node_cdf, old.slab, old.block_cdf_flag, old.block_cpic, old.cpic_list, old.visit_list, old.halo_list,
+                        old.imp_slab, old.mesh_min, old.mesh_aff};
+    for (void *p : old_ptrs) release_alloc(d, p);
     HIP_TRY(hipMemsetAsync(dev.hkeys, 0xff, sizeof(uint32_t) * ((size_t)dev.hmask + 1), d->stream));
     HIP_TRY(hipMemsetAsync(dev.hvals, 0xff, sizeof(uint32_t) * ((size_t)dev.hmask + 1), d->stream));
     HIP_TRY(hipMemsetAsync(dev.counters + CTR_NPHYS, 0, sizeof(uint32_t), d->stream));
@@ -383,12 +386,20 @@ template <int DIM> __device__ inline void fix_uniform(const Dev &d, Unpacked &u)
 }
 
 // general layout -> uniform-material layout: F[8] takes the place of the mass in XM.w
-__global__ void k_to_uniform(Dev d, int side) {
+// `check`: the caller ASSERTED the constants (wgs_set_uniform_material on sharded data): a particle that carries other
+// values would silently lose them, so every particle is compared bit for bit first and a mismatch is reported
+// (ERRBIT_MATERIAL -> the next wgs_sync).
+__global__ void k_to_uniform(Dev d, int side, int check) {
     if constexpr (D == 3) {
         float *buf = d.buf[side];
-        for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < d.n; j += gridDim.x * blockDim.x) {
+        const uint32_t n = num_slots(d);
+        for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < n; j += gridDim.x * blockDim.x) {
             float4 xm = ldq(buf, d.npad, Pl<3>::XM, j);
-            xm.w = ldq(buf, d.npad, Pl<3>::F2, j).x;
+            const float4 f2 = ldq(buf, d.npad, Pl<3>::F2, j);
+            if (check && (__float_as_uint(xm.w) != __float_as_uint(d.uni_mass) || __float_as_uint(f2.y) != __float_as_uint(d.uni_vol) ||
+                          __float_as_uint(f2.z) != __float_as_uint(d.uni_lambda) || __float_as_uint(f2.w) != __float_as_uint(d.uni_mu)))
+                atomicOr(&d.counters[CTR_ERRORS], ERRBIT_MATERIAL);
+            xm.w = f2.x;
             stq(buf, d.npad, Pl<3>::XM, j, xm);
         }
     }
@@ -556,7 +567,6 @@ __global__ void k_export_blocks(Dev d, uint32_t nblocks, wgs_block_record *out) 
     }
 }
 
-wgs_status flush_append(wgs_data *d);
 wgs_status allreduce_impulses(wgs_data *d);  // capi_sharded.inc
 
 // leaves a copy of the device counters in pinned host memory for the next call's maintain_grid (asynchronous)
@@ -572,10 +582,6 @@ wgs_status watch_counters(wgs_data *d) {
 }
 
 wgs_status fetch_counters(wgs_data *d) {
-    {
-        wgs_status fst = flush_append(d);  // sharded: a recorded but not yet executed migrant append
-        if (fst != WGS_OK) return fst;
-    }
     uint32_t host[CTR_COUNT];
     HIP_TRY(hipMemcpyAsync(host, d->dev.counters, sizeof(host), hipMemcpyDeviceToHost, d->stream));
     HIP_TRY(hipStreamSynchronize(d->stream));
@@ -596,9 +602,11 @@ wgs_status sticky_status(wgs_data *d) {
     if (d->sticky_errors & ERRBIT_OVERFLOW)
         return fail(WGS_ERR_GRID_OVERFLOW, "sparse grid overflow: more active blocks than grid_capacity");
     if (d->sticky_errors & ERRBIT_SHARD)
-        return fail(WGS_ERR_INVALID_ARGUMENT, "sharded run: a halo / migration buffer or the particle capacity overflowed");
+        return fail(WGS_ERR_INVALID_ARGUMENT, "sharded run: a message buffer or the particle capacity overflowed, a particle left the decomposition, or the ranks disagree on the uniform-material mode");
     if (d->sticky_errors & ERRBIT_KEYRANGE)
         return fail(WGS_ERR_KEY_RANGE, "a particle left the packed block-key range (grid.wgsl:88-95)");
+    if (d->sticky_errors & ERRBIT_MATERIAL)
+        return fail(WGS_ERR_INVALID_ARGUMENT, "wgs_set_uniform_material: a particle of this wgs_data carries other constants (mass, init_volume, lambda, mu)");
     return WGS_OK;
 }
 
@@ -626,19 +634,9 @@ void resolve_timings(wgs_data *d) {
     d->timings_pending = false;
 }
 
-// Sharded runs: run the pending append of the last migration round as a launch of its own.
-wgs_status flush_append(wgs_data *d) {
-    if (!d->append_pending) return WGS_OK;
-    d->append_pending = false;
-    hipLaunchKernelGGL(k_append_migrants<D>, dim3(std::max(1u, (d->tail_slots + 255u) / 256u)), dim3(256), 0, d->stream, d->dev,
-                       d->side, d->mig.in_lo, d->mig.in_hi, d->mig.out_lo, d->mig.out_hi, d->mig.cap);
-    HIP_TRY(hipGetLastError());
-    return WGS_OK;
-}
-
 // One substep = pipeline.rs:201-280 (MPM passes), enqueued on the data's stream.
-// part 0 = the whole substep (single GPU); sharded runs split it around the halo exchange:
-// part 1 = sort .. P2G + gather of the partial node sums, part 2 = grid update + fused G2P.
+// part 0 = the whole substep (single GPU, or a slab stepped without its neighbours); the sharded step splits it around
+// its one neighbour exchange: part 1 = sort .. P2G, part 2 = grid update + fused G2P (+ the arrivals' G2P) + bodies.
 template <bool TS> wgs_status enqueue_substep(wgs_data *d, int ts_slot, int part) {
     Dev &dev = d->dev;
     hipStream_t s = d->stream;
@@ -662,26 +660,17 @@ template <bool TS> wgs_status enqueue_substep(wgs_data *d, int ts_slot, int part
     // (perm_cell) and neighbour links are still valid, so the particles are re-binned RELATIVE to their old
     // block (k_rebin: no hash lookups except for the few particles that changed block). The full k_bin runs
     // on the first substep, on table-rebuild substeps and in sharded runs (particles arrive from neighbours).
-    const bool rehash = d->substeps % d->rehash_period == 0 || (d->force_rehash && part != 2 && part != 3);
-    if (rehash && part != 2 && part != 3) d->force_rehash = false;
+    const bool rehash = d->substeps % d->rehash_period == 0 || (d->force_rehash && part != 2);
+    if (rehash && part != 2) d->force_rehash = false;
     const bool fused_cdf = d->cpic && dev.n_rigid == 0 && !(dev.dbg & 1024u);  // (mesh cdfs are only complete after k_p2g_cdf)
     if (part != 2) dev.listed_in_perm = fused_cdf ? 1u : 0u;  // (part 2 of a sharded substep consumes what its part 1 wrote)
-    // (sharded data stepped with wgs_step: nobody arrived since the last substep, the residents are all there is)
-    const bool use_rebin = d->prev_sorted && !rehash && !(dev.dbg & 128u) && (!dev.sharded || d->tail_known || part == 3 || part == 0);
+    const bool use_rebin = d->prev_sorted && !rehash && !(dev.dbg & 128u);
+    // the fused G2P drops the guests only inside the sharded step (kernels_shard.h); wgs_step on a slab advances what it holds
+    dev.skip_guests = (d->in_sharded_step && dev.sharded) ? 1u : 0u;
     if (dev.sharded && d->needs_compact && part != 2) {
         hipLaunchKernelGGL(k_shard_compacted, dim3(1), dim3(64), 0, s, dev);
         d->needs_compact = false;
-    }
-    if (part == 3) {
-        // Sharded runs, optional: re-bin the residents while the particle migration is still in flight (it only
-        // needs the buffer the last G2P wrote). Part 1 then bins just the arrivals. Nothing to do on the substeps
-        // that rebuild the table or follow no sorted substep: part 1 runs the full pass then.
-        if (use_rebin && n > 0 && !d->residents_binned) {
-            hipLaunchKernelGGL(k_rebin<D>, dim3(pgrid), dim3(SORT_THREADS), 0, s, dev, side, epoch);
-            d->residents_binned = true;
-        }
-        HIP_TRY(hipGetLastError());
-        return WGS_OK;
+        d->tail_slots = 0;
     }
     if (part != 2) {
         if (TS) {  // two adjacent marks: their distance is what every interval below pays for its closing mark
@@ -700,25 +689,13 @@ template <bool TS> wgs_status enqueue_substep(wgs_data *d, int ts_slot, int part
             hipLaunchKernelGGL(k_rigid_transform<D>, dim3(grid_for(d, 1)), dim3(256), 0, s, dev);
         if (n > 0) {
             if (use_rebin) {
-                const bool tail = dev.sharded && d->tail_known && d->tail_slots > 0;  // particles arrived from the neighbours: append + bin
-                const dim3 tg((d->tail_slots + SORT_THREADS - 1) / SORT_THREADS);
-                if (!d->residents_binned && tail) {  // both in one launch (k_rebin_tail)
-                    const dim3 both((uint32_t)pgrid + tg.x);
-                    if (d->append_pending) hipLaunchKernelGGL((k_rebin_tail<D, 2>), both, dim3(SORT_THREADS), 0, s, dev, side, epoch, d->mig, (uint32_t)pgrid);
-                    else hipLaunchKernelGGL((k_rebin_tail<D, 1>), both, dim3(SORT_THREADS), 0, s, dev, side, epoch, MigIn{}, (uint32_t)pgrid);
-                    d->append_pending = false;
-                } else {
-                    if (!d->residents_binned) hipLaunchKernelGGL(k_rebin<D>, dim3(pgrid), dim3(SORT_THREADS), 0, s, dev, side, epoch);
-                    if (tail) {
-                        if (d->append_pending) hipLaunchKernelGGL((k_bin<D, 2>), tg, dim3(SORT_THREADS), 0, s, dev, side, epoch, d->mig);
-                        else hipLaunchKernelGGL((k_bin<D, 1>), tg, dim3(SORT_THREADS), 0, s, dev, side, epoch, MigIn{});
-                        d->append_pending = false;
-                    }
-                }
+                // sharded runs: the particles that arrived in the last substep lie behind the residents and have no previous
+                // cell: binned by the general form, in the same launch (k_rebin_tail)
+                const uint32_t tg = dev.sharded ? (d->tail_slots + SORT_THREADS - 1) / SORT_THREADS : 0u;
+                if (tg > 0u) hipLaunchKernelGGL((k_rebin_tail<D>), dim3((uint32_t)pgrid + tg), dim3(SORT_THREADS), 0, s, dev, side, epoch, (uint32_t)pgrid);
+                else hipLaunchKernelGGL(k_rebin<D>, dim3(pgrid), dim3(SORT_THREADS), 0, s, dev, side, epoch);
             } else {
-                wgs_status fst = flush_append(d);  // (the full pass reads the appended particles from the buffer)
-                if (fst != WGS_OK) return fst;
-                hipLaunchKernelGGL((k_bin<D, 0>), dim3(pgrid), dim3(SORT_THREADS), 0, s, dev, side, epoch, MigIn{});
+                hipLaunchKernelGGL((k_bin<D, 0>), dim3(pgrid), dim3(SORT_THREADS), 0, s, dev, side, epoch);
             }
             if (dev.n_rigid > 0) {  // blocks a mesh sample reaches must exist (sort.wgsl:38-86)
                 hipLaunchKernelGGL(k_rigid_mark<D>, dim3(grid_for(d, 1)), dim3(256), 0, s, dev, epoch);
@@ -777,9 +754,6 @@ template <bool TS> wgs_status enqueue_substep(wgs_data *d, int ts_slot, int part
             }
         }
         mark(4);
-        // sharded runs: the interface layers are gathered by wgs_shard_pack_halos (fused protocol); the per-face
-        // wgs_shard_pack_halo needs the gather-only pass
-        if (part == 1 && n > 0 && !d->fused_halo) hipLaunchKernelGGL((k_grid_update<D, 1>), dim3(grid_for(d, WGS_GU_WG_PER_CU)), dim3(256), 0, s, dev);
     }
     if (part != 1) {
         if (n > 0) {
@@ -787,10 +761,8 @@ template <bool TS> wgs_status enqueue_substep(wgs_data *d, int ts_slot, int part
             if (part == 0 && d->two_way)
                 hipLaunchKernelGGL((k_grid_update<D, 0, true>), dim3(grid_for(d, WGS_GU_WG_PER_CU)), dim3(256), 0, s, dev);
             else if (part == 0) hipLaunchKernelGGL((k_grid_update<D, 0>), dim3(grid_for(d, WGS_GU_WG_PER_CU)), dim3(256), 0, s, dev);
-            else if (d->fused_halo && d->two_way) hipLaunchKernelGGL((k_grid_update<D, 3, true>), dim3(grid_for(d, WGS_GU_WG_PER_CU)), dim3(256), 0, s, dev);
-            else if (d->fused_halo) hipLaunchKernelGGL((k_grid_update<D, 3>), dim3(grid_for(d, WGS_GU_WG_PER_CU)), dim3(256), 0, s, dev);
-            else if (d->two_way) return fail(WGS_ERR_UNSUPPORTED, "two-way coupling on sharded data needs the fused halo protocol (wgs_shard_register_buffers / wgs_shard_attach)");
-            else hipLaunchKernelGGL((k_grid_update<D, 2>), dim3(grid_for(d, WGS_GU_WG_PER_CU)), dim3(256), 0, s, dev);
+            else if (d->two_way) hipLaunchKernelGGL((k_grid_update<D, 3, true>), dim3(grid_for(d, WGS_GU_WG_PER_CU)), dim3(256), 0, s, dev);
+            else hipLaunchKernelGGL((k_grid_update<D, 3>), dim3(grid_for(d, WGS_GU_WG_PER_CU)), dim3(256), 0, s, dev);
         }
         mark(5);
         if (dev.nv > 0) {
@@ -850,6 +822,22 @@ template <bool TS> wgs_status enqueue_substep(wgs_data *d, int ts_slot, int part
 #undef WGS_LAUNCH_G2P
         }
         if (!(d->cpic && dev.nv > 0)) mark(6);  // (collider simulations: recorded between the two G2P launches)
+        // ---- sharded step: the particles that arrived with this substep's messages (kernels_arrivals.h); also the
+        // bookkeeping of the migration round, so it runs even when nobody can arrive
+        const bool arrivals = part == 2 && d->in_sharded_step && d->link && d->link->attached;
+        if (arrivals) {
+            const ShardLink &L = *d->link;
+            const uint32_t most = ((L.has_lower ? 1u : 0u) + (L.has_upper ? 1u : 0u)) * L.mig_cap;
+            const dim3 ag(std::max(1u, std::min((most + ARR_PER_WG - 1u) / ARR_PER_WG, 1024u)));
+            const int asel = (dev.model == WGS_MODEL_NEO_HOOKEAN ? 2 : 0) | (d->plastic ? 1 : 0);
+            switch (asel) {
+                case 0: hipLaunchKernelGGL((k_g2p_arrivals<D, 0, false>), ag, dim3(256), 0, s, dev, side, epoch); break;
+                case 1: hipLaunchKernelGGL((k_g2p_arrivals<D, 0, true>), ag, dim3(256), 0, s, dev, side, epoch); break;
+                case 2: hipLaunchKernelGGL((k_g2p_arrivals<D, 1, false>), ag, dim3(256), 0, s, dev, side, epoch); break;
+                default: hipLaunchKernelGGL((k_g2p_arrivals<D, 1, true>), ag, dim3(256), 0, s, dev, side, epoch); break;
+            }
+            d->tail_slots = most;
+        }
         mark(7);
         // ---- "integrate_bodies" (rigid_impulses.wgsl:95-136) + the world mass properties of the next substep
         // (pipeline.rs:204-205). Skipped while no body has a velocity or a mass: it would be the identity.
@@ -864,13 +852,10 @@ template <bool TS> wgs_status enqueue_substep(wgs_data *d, int ts_slot, int part
         d->side ^= 1;
         d->substeps++;
         d->prev_sorted = true;
-        d->tail_known = false;
-        d->tail_slots = 0;
-        d->residents_binned = false;
         dev.n = dev.nv;  // the buffer just written holds the valid particles only, in sorted order
-        // sharded: CTR_N / CTR_NPREV := CTR_NV before anything bins this buffer — done by the next
-        // wgs_shard_pack_migrants, or by k_shard_compacted at the head of the next substep (wgs_step on sharded data)
-        if (dev.sharded) d->needs_compact = true;
+        // sharded: the counters of the new buffer (CTR_N / CTR_NPREV / CTR_NV) are set by k_g2p_arrivals; a slab stepped
+        // without its neighbours (wgs_step) sets them at the head of its next substep (k_shard_compacted)
+        if (dev.sharded && !arrivals) d->needs_compact = true;
     }
     HIP_TRY(hipGetLastError());
     return WGS_OK;
@@ -1117,7 +1102,7 @@ static wgs_status create_impl(wgs_pipeline *pipeline, const wgs_sim_params *para
         dev.uni_vol = particles[0].dynamics.init_volume;
         dev.uni_lambda = particles[0].model.lambda;
         dev.uni_mu = particles[0].model.mu;
-        hipLaunchKernelGGL(k_to_uniform, dim3(grid_for(d, 4)), dim3(256), 0, d->stream, dev, 0);
+        hipLaunchKernelGGL(k_to_uniform, dim3(grid_for(d, 4)), dim3(256), 0, d->stream, dev, 0, 0);
     }
     if (hipStreamSynchronize(d->stream) != hipSuccess) return bail(fail(WGS_ERR_HIP, "initial upload failed"));
     *out = d;
@@ -1155,144 +1140,17 @@ wgs_status wgs_set_stream(wgs_data *d, void *hip_stream) {
     return WGS_OK;
 }
 
-wgs_status wgs_shard_step_begin(wgs_pipeline *pipeline, wgs_data *d) {
-    if (!pipeline || !d) return fail(WGS_ERR_INVALID_ARGUMENT, "NULL argument");
-    if (!d->dev.sharded) return fail(WGS_ERR_INVALID_ARGUMENT, "not a sharded wgs_data");
-    HIP_TRY(hipSetDevice(pipeline->device));
-    return enqueue_substep<false>(d, 0, 1);
-}
-
-wgs_status wgs_shard_bin_residents(wgs_pipeline *pipeline, wgs_data *d) {
-    if (!pipeline || !d) return fail(WGS_ERR_INVALID_ARGUMENT, "NULL argument");
-    if (!d->dev.sharded) return fail(WGS_ERR_INVALID_ARGUMENT, "not a sharded wgs_data");
-    HIP_TRY(hipSetDevice(pipeline->device));
-    return enqueue_substep<false>(d, 0, 3);
-}
-
-wgs_status wgs_shard_step_end(wgs_pipeline *pipeline, wgs_data *d) {
-    if (!pipeline || !d) return fail(WGS_ERR_INVALID_ARGUMENT, "NULL argument");
-    if (!d->dev.sharded) return fail(WGS_ERR_INVALID_ARGUMENT, "not a sharded wgs_data");
-    HIP_TRY(hipSetDevice(pipeline->device));
-    wgs_status st = enqueue_substep<false>(d, 0, 2);
-    return st;  // (CTR_N / CTR_NPREV := CTR_NV is pending: needs_compact, see enqueue_substep)
-}
-
-namespace {
-bool hdr_registered(const wgs_data *d, const void *p) {
-    for (int k = 0; k < 4; k++)
-        if (p && d->dev.hdr_clear[k] == p) return true;
-    return false;
-}
-}  // namespace
-
-wgs_status wgs_shard_register_buffers(wgs_data *d, void *halo_out_lo, void *halo_out_hi, void *mig_out_lo, void *mig_out_hi) {
-    if (!d) return fail(WGS_ERR_INVALID_ARGUMENT, "NULL argument");
-    if (!d->dev.sharded) return fail(WGS_ERR_INVALID_ARGUMENT, "not a sharded wgs_data");
-    void *p[4] = {halo_out_lo, halo_out_hi, mig_out_lo, mig_out_hi};
-    for (int k = 0; k < 4; k++) d->dev.hdr_clear[k] = static_cast<uint32_t *>(p[k]);
-    // registering also selects the fused halo protocol: wgs_shard_step_begin stops after P2G, wgs_shard_pack_halos
-    // gathers the interface layers itself (it must then be called every substep, even without neighbours), and
-    // wgs_shard_step_end runs the single-pass grid update
-    d->fused_halo = true;
-    return WGS_OK;
-}
-
-wgs_status wgs_shard_pack_halos(wgs_data *d, void *buf_lo, void *buf_hi, uint32_t capacity_records) {
-    if (!d) return fail(WGS_ERR_INVALID_ARGUMENT, "NULL argument");
-    if (!buf_lo && !buf_hi) return WGS_OK;  // no neighbour on either side: no interface layer
-    HIP_TRY(hipSetDevice(d->pipeline->device));
-    if ((buf_lo && !hdr_registered(d, buf_lo)) || (buf_hi && !hdr_registered(d, buf_hi)))
-        hipLaunchKernelGGL(k_clear_headers, dim3(1), dim3(64), 0, d->stream, static_cast<uint32_t *>(buf_lo), static_cast<uint32_t *>(buf_hi));
-    hipLaunchKernelGGL(k_pack_halos<D>, dim3(2u * std::max(64u, std::min(capacity_records, 2048u))), dim3(64), 0, d->stream, d->dev,
-                       static_cast<float4 *>(buf_lo), static_cast<float4 *>(buf_hi), capacity_records, d->fused_halo ? 1 : 0);
-    HIP_TRY(hipGetLastError());
-    return WGS_OK;
-}
-
-wgs_status wgs_shard_add_halos(wgs_data *d, const void *in_lo, const void *in_hi, uint32_t capacity_records) {
-    if (!d) return fail(WGS_ERR_INVALID_ARGUMENT, "NULL argument");
-    if (!in_lo && !in_hi) return WGS_OK;
-    HIP_TRY(hipSetDevice(d->pipeline->device));
-    const uint32_t epoch = (uint32_t)(d->substeps + 1);
-    const uint32_t g = capacity_records < 2048u ? (capacity_records ? capacity_records : 1u) : 2048u;
-    const void *a = in_lo ? in_lo : in_hi, *b = in_lo ? in_hi : nullptr;
-    hipLaunchKernelGGL(k_add_halo<D>, dim3(g, b ? 2 : 1), dim3(64), 0, d->stream, d->dev, static_cast<const float4 *>(a),
-                       static_cast<const float4 *>(b), capacity_records, epoch);
-    HIP_TRY(hipGetLastError());
-    return WGS_OK;
-}
-
-wgs_status wgs_shard_pack_halo(wgs_data *d, int32_t layer_bx, void *device_buf, uint32_t capacity_records) {
-    if (!d || !device_buf) return fail(WGS_ERR_INVALID_ARGUMENT, "NULL argument");
-    HIP_TRY(hipSetDevice(d->pipeline->device));
-    if (!hdr_registered(d, device_buf))
-        hipLaunchKernelGGL(k_clear_headers, dim3(1), dim3(64), 0, d->stream, static_cast<uint32_t *>(device_buf), (uint32_t *)nullptr);
-    hipLaunchKernelGGL(k_pack_halo<D>, dim3(grid_for(d, 4)), dim3(64), 0, d->stream, d->dev, layer_bx,
-                       static_cast<float4 *>(device_buf), capacity_records);
-    HIP_TRY(hipGetLastError());
-    return WGS_OK;
-}
-
-wgs_status wgs_shard_add_halo(wgs_data *d, const void *device_buf, uint32_t capacity_records) {
-    if (!d || !device_buf) return fail(WGS_ERR_INVALID_ARGUMENT, "NULL argument");
-    HIP_TRY(hipSetDevice(d->pipeline->device));
-    const uint32_t epoch = (uint32_t)(d->substeps + 1);
-    const uint32_t g = capacity_records < 2048u ? (capacity_records ? capacity_records : 1u) : 2048u;
-    hipLaunchKernelGGL(k_add_halo<D>, dim3(g), dim3(64), 0, d->stream, d->dev, static_cast<const float4 *>(device_buf),
-                       static_cast<const float4 *>(nullptr), capacity_records, epoch);
-    HIP_TRY(hipGetLastError());
-    return WGS_OK;
-}
-
-wgs_status wgs_shard_pack_migrants(wgs_data *d, void *dev_lo, void *dev_hi, uint32_t capacity_records) {
-    if (!d || !dev_lo || !dev_hi) return fail(WGS_ERR_INVALID_ARGUMENT, "NULL argument");
-    HIP_TRY(hipSetDevice(d->pipeline->device));
-    if (!hdr_registered(d, dev_lo) || !hdr_registered(d, dev_hi))
-        hipLaunchKernelGGL(k_clear_headers, dim3(1), dim3(64), 0, d->stream, static_cast<uint32_t *>(dev_lo), static_cast<uint32_t *>(dev_hi));
-    d->needs_compact = false;  // k_pack_migrants does the bookkeeping of the compacted buffer itself
-    hipLaunchKernelGGL(k_pack_migrants<D>, dim3(grid_for(d, 4)), dim3(256), 0, d->stream, d->dev, d->side, 0,
-                       static_cast<float *>(dev_lo), static_cast<float *>(dev_hi), capacity_records);
-    HIP_TRY(hipGetLastError());
-    return WGS_OK;
-}
-
-wgs_status wgs_shard_add_migrants(wgs_data *d, const void *in_lo, const void *in_hi, const void *out_lo, const void *out_hi,
-                                  uint32_t capacity_records) {
-    if (!d) return fail(WGS_ERR_INVALID_ARGUMENT, "NULL argument");
-    HIP_TRY(hipSetDevice(d->pipeline->device));
-    d->tail_known = true;
-    d->tail_slots = (in_lo ? capacity_records : 0u) + (in_hi ? capacity_records : 0u);
-    if (d->needs_compact) {  // no wgs_shard_pack_migrants since the last substep: do its bookkeeping here
-        hipLaunchKernelGGL(k_shard_compacted, dim3(1), dim3(64), 0, d->stream, d->dev);
-        d->needs_compact = false;
-    }
-    // The append itself rides in the next substep's tail binning launch (k_bin, tail = 2); anything that looks at the
-    // particles or the counters before that flushes it (flush_append).
-    d->mig = MigIn{static_cast<const float *>(in_lo), static_cast<const float *>(in_hi), static_cast<const float *>(out_lo),
-                   static_cast<const float *>(out_hi), capacity_records};
-    d->append_pending = true;
-    if (!in_lo && !in_hi && !out_lo && !out_hi) {  // no neighbour on either side: nobody left, nobody arrives
-        d->append_pending = false;
-        return WGS_OK;
-    }
-    if (d->tail_slots == 0) return flush_append(d);  // no inbound buffer: only the bookkeeping of the departures, now
-    return WGS_OK;
-}
-
 wgs_status wgs_shard_export(wgs_data *d, void *device_buf, uint32_t capacity_records, uint32_t *count) {
     if (!d || !device_buf || !count) return fail(WGS_ERR_INVALID_ARGUMENT, "NULL argument");
+    if (!d->dev.sharded) return fail(WGS_ERR_INVALID_ARGUMENT, "not a sharded wgs_data");
     HIP_TRY(hipSetDevice(d->pipeline->device));
     if (d->needs_compact) {
         hipLaunchKernelGGL(k_shard_compacted, dim3(1), dim3(64), 0, d->stream, d->dev);
         d->needs_compact = false;
-    }
-    {
-        wgs_status fst = flush_append(d);
-        if (fst != WGS_OK) return fst;
+        d->tail_slots = 0;
     }
     hipLaunchKernelGGL(k_clear_headers, dim3(1), dim3(64), 0, d->stream, static_cast<uint32_t *>(device_buf), (uint32_t *)nullptr);
-    hipLaunchKernelGGL(k_pack_migrants<D>, dim3(grid_for(d, 4)), dim3(256), 0, d->stream, d->dev, d->side, 1,
-                       static_cast<float *>(device_buf), static_cast<float *>(device_buf), capacity_records);
+    hipLaunchKernelGGL(k_export_records<D>, dim3(grid_for(d, 4)), dim3(256), 0, d->stream, d->dev, d->side, static_cast<float *>(device_buf), capacity_records);
     HIP_TRY(hipMemcpyAsync(count, device_buf, sizeof(uint32_t), hipMemcpyDeviceToHost, d->stream));
     HIP_TRY(hipStreamSynchronize(d->stream));
     if (*count > capacity_records) return fail(WGS_ERR_INVALID_ARGUMENT, "export buffer too small");
@@ -1324,7 +1182,7 @@ wgs_status wgs_set_uniform_material(wgs_data *d, float mass, float init_volume, 
     d->dev.uni_vol = init_volume;
     d->dev.uni_lambda = lambda;
     d->dev.uni_mu = mu;
-    if (d->dev.n) hipLaunchKernelGGL(k_to_uniform, dim3(grid_for(d, 4)), dim3(256), 0, d->stream, d->dev, d->side);
+    if (d->dev.n) hipLaunchKernelGGL(k_to_uniform, dim3(grid_for(d, 4)), dim3(256), 0, d->stream, d->dev, d->side, 1);
     HIP_TRY(hipGetLastError());
     return WGS_OK;
 }

@@ -1,215 +1,286 @@
 // kernels_shard.h — x-slab domain decomposition across GPUs (new design: the reference is
 // single-GPU). One process per GPU owns the particles whose associated
-// block has bx in [shard_lo, shard_hi). Because the stencil of a particle only reaches
-// nodes c .. c+2 of its associated cell c, a rank's particles write into, and read from, the
-// first two node layers (lx in {0,1}) of the block layer bx = shard_hi owned by the next
-// rank, and into nothing on the lower side. Per substep two small neighbour exchanges:
-//   1. after the P2G gather: partial (momentum, mass) sums of the interface node layers,
-//      both ways; each side adds what it received (a + b == b + a bitwise), so both ranks
-//      hold identical totals and run the grid update redundantly on those nodes;
-//   2. after the particle update: particles whose associated block left the rank's range
-//      (at most one block per substep because of the h/dt velocity clamps) move, full state.
-// Everything is stream-ordered: messages are fixed-capacity buffers whose first 16 bytes hold
-// the record count, particle counts live in device counters, so a substep needs no host
-// synchronisation (overflow of a buffer sets ERRBIT_SHARD, seen at the next wgs_sync).
+// block has bx in [shard_lo, shard_hi) — its CORE range. ONE neighbour exchange per substep:
+//
+//   A particle with associated cell c touches the nodes c .. c+2 only, so a rank's core particles reach the first
+//   two node layers of block layer shard_hi and nothing below shard_lo. A particle that LEAVES the core range in the
+//   fused G2P of substep n is not sent at once (that would be a second exchange, between the G2P and the next sort):
+//   it stays with its old owner as a GUEST for the sort and the P2G of substep n + 1, its record (state after
+//   substep n, which nothing changes before the next G2P) travels in the SAME message as the node sums of substep
+//   n + 1, and the new owner runs the G2P + particle update of substep n + 1 on it (k_g2p_arrivals) and keeps it.
+//   The old owner's fused G2P drops it. A guest sits at bx = shard_hi or shard_lo - 1 (a particle moves less than
+//   a cell per substep: grid_update.wgsl:60-62, particle_update.wgsl:70-72), so the old owner's P2G also writes
+//   block layer shard_hi completely and two node layers of shard_hi + 1 (and shard_lo - 1, shard_lo below).
+//
+//   Message to the UPPER neighbour: partial (momentum, mass) sums of block layer hi (all x-layer pairs) and of
+//   hi + 1 (first pair) + the records of the guests at bx = hi.  To the LOWER neighbour: layers lo - 1 (all pairs)
+//   and lo (first pair) + the guests at bx = lo - 1. A record = one x-layer PAIR of one block (key, pair index,
+//   2 * BW^(D-1) float4); pairs only guests can have touched are sent when they are non-zero. Both sides ADD what
+//   they receive (a + b == b + a bitwise: both hold identical totals of the nodes they share) and update redundantly.
+//   A received pair whose block is not active here (the first particles to enter an empty region) is kept by
+//   reference in a small table: the arrivals' G2P reads such nodes straight from the message — nobody here
+//   contributes to them, the neighbour's partial sum IS the total.
+//
+// Slabs with two neighbours must be at least 3 blocks wide (the layers the two messages touch must not overlap).
+// Everything is stream-ordered: messages are fixed-capacity buffers whose header holds the record counts,
+// particle counts live in device counters, so a substep needs no host synchronisation (overflow of a buffer
+// sets ERRBIT_SHARD, seen at the next wgs_sync).
 #pragma once
-#include "device_math.h"
+#include "kernels_cdf.h"
 
 namespace wgs {
 
-constexpr uint32_t PID_DEAD = 0xffffffffu;  // slot vacated by a migrated particle
-
 template <int D> struct HaloCfg {
     static constexpr int BW = Dim<D>::BW;
-    static constexpr int NODES = D == 3 ? 2 * BW * BW : 2 * BW;  // two x-layers of a block
-    static constexpr int REC_F4 = NODES + 1;                     // [key,0,0,0] + node partial sums
+    static constexpr int NODES = D == 3 ? 2 * BW * BW : 2 * BW;  // one x-layer pair of a block
+    static constexpr int NTAG = BW / 2;                          // pairs per block (3D: 2, 2D: 4)
+    static constexpr uint32_t ALL = (1u << NTAG) - 1u;
+    static constexpr int REC_F4 = NODES + 1;                     // [key, pair, -, -] + node partial sums
 };
 
-// local index of interface node q of a block: lx = q & 1, then y (, z)
-template <int D> __device__ inline uint32_t halo_node(int q) {
+// local index of node q of x-layer pair `tag` of a block: lx = 2 tag + (q & 1), then y (, z)
+template <int D> __device__ inline uint32_t halo_node(int tag, int q) {
     constexpr int BW = Dim<D>::BW, BS = Dim<D>::BSHIFT;
-    const int lx = q & 1, ly = (q >> 1) & (BW - 1), lz = D == 3 ? (q >> (1 + BS)) : 0;
+    const int lx = 2 * tag + (q & 1), ly = (q >> 1) & (BW - 1), lz = D == 3 ? (q >> (1 + BS)) : 0;
     return (uint32_t)(lx + (ly << BS) + (D == 3 ? (lz << (2 * BS)) : 0));
 }
-
-__global__ void k_clear_headers(uint32_t *a, uint32_t *b) {
-    if (threadIdx.x == 0) {
-        if (a) a[0] = 0;
-        if (b) b[0] = 0;
-    }
+// inverse: (pair, q) of a local node index
+template <int D> __device__ inline void halo_slot(uint32_t ln, int &tag, int &q) {
+    constexpr int BW = Dim<D>::BW, BS = Dim<D>::BSHIFT;
+    const int lx = ln & (BW - 1), ly = (ln >> BS) & (BW - 1), lz = D == 3 ? (int)(ln >> (2 * BS)) : 0;
+    tag = lx >> 1;
+    q = (lx & 1) + 2 * (ly + (D == 3 ? BW * lz : 0));
 }
 
-// Pack the partial sums of the interface layer `layer_bx` (active blocks only).
-// buf = [count, -, -, -] + cap records of REC_F4 float4.
-template <int D> __global__ __launch_bounds__(64) void k_pack_halo(Dev d, int layer_bx, float4 *buf, uint32_t cap) {
-    using H = HaloCfg<D>;
-    uint32_t *count = reinterpret_cast<uint32_t *>(buf);
-    float4 *out = buf + 1;
-    const uint32_t B = min(d.counters[CTR_NBLOCKS], d.cap);
-    const int lane = threadIdx.x;
-    for (uint32_t a = blockIdx.x; a < B; a += gridDim.x) {
-        const uint32_t b = d.active[a];
-        int bc[3] = {0, 0, 0};
-        unpack_key<D>(d.block_key[b], bc);
-        if (bc[0] != layer_bx) continue;  // wave-uniform
-        uint32_t slot = 0;
-        if (lane == 0) slot = atomicAdd(count, 1u);
-        slot = __shfl(slot, 0);
-        if (slot >= cap) {
-            if (lane == 0) atomicOr(&d.counters[CTR_ERRORS], ERRBIT_SHARD);
-            continue;
-        }
-        float4 *rec = out + (size_t)slot * H::REC_F4;
-        if (lane == 0) rec[0] = make_float4(__uint_as_float(d.block_key[b]), 0.f, 0.f, 0.f);
-        if (lane < H::NODES) rec[1 + lane] = d.nodes[(size_t)b * NPB + halo_node<D>(lane)];
+// What block layer bx is to this slab (bit t = x-layer pair t):
+//   gather     — the pack launch gathers these pairs' partial sums from the slabs into nodes[]
+//   from_nodes — the grid update takes these pairs from nodes[] (own partial + what the neighbours sent)
+//   send_lo/hi — pairs that travel to the lower / upper neighbour
+struct IfaceMasks {
+    uint32_t gather, from_nodes, send_lo, send_hi;
+};
+template <int D> __device__ inline IfaceMasks iface_masks(const Dev &d, int bx) {
+    constexpr uint32_t ALL = HaloCfg<D>::ALL;
+    IfaceMasks m = {0u, 0u, 0u, 0u};
+    if (d.shard_has_lo) {
+        const int lo = d.shard_lo;
+        if (bx == lo - 1) { m.gather |= ALL; m.send_lo |= ALL; }
+        if (bx == lo)     { m.gather |= ALL; m.send_lo |= 1u; m.from_nodes |= ALL; }
+        if (bx == lo + 1) { m.gather |= 1u; m.from_nodes |= 1u; }
     }
+    if (d.shard_has_hi) {
+        const int hi = d.shard_hi;
+        if (bx == hi - 1) { m.gather |= ALL; m.from_nodes |= ALL; }
+        if (bx == hi)     { m.gather |= ALL; m.send_hi |= ALL; m.from_nodes |= 1u; }
+        if (bx == hi + 1) { m.gather |= 1u; m.send_hi |= 1u; }
+    }
+    return m;
 }
 
-// Both interface layers in one launch (a launch costs ~4.5 us whatever it does): layer_lo -> buf_lo, layer_hi -> buf_hi;
-// a null buffer = no neighbour on that side.
-// `gather`: the node sums are not in nodes[] yet (no separate gather pass ran): compute them here from the slabs and
-// leave them in nodes[] for k_add_halo / the PHASE 3 grid update.
+// Full-state record of one particle: NQ quads + pid + cdf epoch.
+template <int D> constexpr int particle_record_floats() { return Pl<D>::NQ * 4 + 2; }
+
+// One message = header (4 words: halo records, particle records, flags, -) + halo_cap halo records + mig_cap particle records.
+constexpr uint32_t MSG_FLAG_UNIFORM = 1u;   // particle records are in the uniform-material layout (layout.h)
+template <int D> __host__ __device__ inline size_t msg_floats(uint32_t halo_cap, uint32_t mig_cap) {
+    return 4 + (size_t)halo_cap * HaloCfg<D>::REC_F4 * 4 + (size_t)mig_cap * particle_record_floats<D>();
+}
+template <int D> __device__ inline const float4 *msg_halo(const float *msg) { return reinterpret_cast<const float4 *>(msg) + 1; }
+template <int D> __device__ inline float4 *msg_halo(float *msg) { return reinterpret_cast<float4 *>(msg) + 1; }
+template <int D> __device__ inline const float *msg_particles(const float *msg, uint32_t halo_cap) {
+    return msg + 4 + (size_t)halo_cap * HaloCfg<D>::REC_F4 * 4;
+}
+template <int D> __device__ inline float *msg_particles(float *msg, uint32_t halo_cap) {
+    return msg + 4 + (size_t)halo_cap * HaloCfg<D>::REC_F4 * 4;
+}
+
 template <int D> __device__ inline float4 gather_slabs(const Dev &d, uint32_t b, uint32_t ln);  // kernels_transfer.h
-template <int D> __global__ __launch_bounds__(64) void k_pack_halos(Dev d, float4 *buf_lo, float4 *buf_hi, uint32_t cap, int gather) {
+
+// After P2G: (a) one wave per interface block (the sort listed them): the pairs the slab needs in nodes[] are gathered
+// from the slabs, and those that travel are appended to the outgoing messages; (b) the guests — the particles the last
+// G2P launch found outside the core range (Dev::leavers) — are copied into the message of the face they crossed. They
+// are NOT vacated here: this rank's fused G2P drops them (their block lies outside the core range).
+template <int D> __global__ __launch_bounds__(64) void k_pack_face(Dev d, int side, uint32_t nblk_wgs) {
     using H = HaloCfg<D>;
+    constexpr int BS = Dim<D>::BSHIFT, NQ = Pl<D>::NQ, RF = particle_record_floats<D>();
     const int lane = threadIdx.x;
-    // the active blocks of the two layers were listed by launch 2 of the sort (one wave per entry here: even workgroups
-    // walk layer_lo's list, odd ones layer_hi's) — scanning the whole active list for them took 11 us at 4000 blocks
-    const uint32_t sd = blockIdx.x & 1u;
-    const uint32_t nl = min(d.counters[CTR_NHALO + 32u * sd], d.cap);
-    for (uint32_t a = blockIdx.x >> 1; a < nl; a += gridDim.x >> 1) {
-        const uint32_t b = d.halo_list[(size_t)sd * d.cap + a];
-        float4 *buf = sd == 0u ? buf_lo : buf_hi;  // wave-uniform; null: no neighbour on that side (the sums are still gathered)
-        if (gather && lane < H::NODES) {
-            const uint32_t ln = halo_node<D>(lane);
-            d.nodes[(size_t)b * NPB + ln] = gather_slabs<D>(d, b, ln);  // (read back below by the same lane)
+    if (blockIdx.x == 0 && lane < 2 && d.msg.out[lane])   // layout of this rank's particle records (checked by the receiver)
+        reinterpret_cast<uint32_t *>(d.msg.out[lane])[2] = d.uniform ? MSG_FLAG_UNIFORM : 0u;
+    if (blockIdx.x < nblk_wgs) {
+        const uint32_t nl = min(d.counters[CTR_NHALO], d.cap);
+        for (uint32_t a = blockIdx.x; a < nl; a += nblk_wgs) {
+            const uint32_t b = d.halo_list[a];
+            int bc[3] = {0, 0, 0};
+            unpack_key<D>(d.block_key[b], bc);
+            const IfaceMasks m = iface_masks<D>(d, bc[0]);
+            int tag, q;
+            halo_slot<D>((uint32_t)lane, tag, q);   // lane = node of the block
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if ((m.gather >> tag) & 1u) {
+                v = gather_slabs<D>(d, b, (uint32_t)lane);
+                d.nodes[(size_t)b * NPB + lane] = v;
+            }
+            const bool nz = v.x != 0.f || v.y != 0.f || v.z != 0.f || v.w != 0.f;
+#pragma unroll
+            for (int f = 0; f < 2; f++) {
+                const uint32_t send = f == 0 ? m.send_lo : m.send_hi;
+                float *msg = d.msg.out[f];
+                if (send == 0u || !msg) continue;  // wave-uniform
+                for (int t = 0; t < H::NTAG; t++) {
+                    if (!((send >> t) & 1u)) continue;
+                    // the pair every core particle near the face writes travels always; pairs only guests reach, when non-zero
+                    const bool regular = t == 0 && bc[0] == (f == 0 ? d.shard_lo : d.shard_hi);
+                    const bool any = __ballot(tag == t && nz) != 0ull;
+                    if (!regular && !any) continue;
+                    uint32_t slot = 0;
+                    if (lane == 0) slot = atomicAdd(reinterpret_cast<uint32_t *>(msg), 1u);
+                    slot = __shfl(slot, 0);
+                    if (slot >= d.msg.halo_cap) {
+                        if (lane == 0) atomicOr(&d.counters[CTR_ERRORS], ERRBIT_SHARD);
+                        continue;
+                    }
+                    float4 *rec = msg_halo<D>(msg) + (size_t)slot * H::REC_F4;
+                    if (lane == 0) rec[0] = make_float4(__uint_as_float(d.block_key[b]), __uint_as_float((uint32_t)t), 0.f, 0.f);
+                    if (tag == t) rec[1 + q] = v;
+                }
+            }
         }
-        if (!buf) continue;
-        uint32_t slot = 0;
-        if (lane == 0) slot = atomicAdd(reinterpret_cast<uint32_t *>(buf), 1u);
-        slot = __shfl(slot, 0);
-        if (slot >= cap) {
-            if (lane == 0) atomicOr(&d.counters[CTR_ERRORS], ERRBIT_SHARD);
+        return;
+    }
+    // (b) guests
+    const float *buf = d.buf[side];
+    const uint32_t npad = d.npad;
+    const uint32_t n = num_slots(d);
+    const uint32_t nl = min(d.counters[CTR_NLEAVE], d.leavers_cap);
+    for (uint32_t t = (blockIdx.x - nblk_wgs) * 64u + (uint32_t)lane; t < nl; t += (gridDim.x - nblk_wgs) * 64u) {
+        const uint32_t i = d.leavers[t];
+        if (i >= n) continue;
+        const uint32_t pid = ldpid<D>(buf, npad, i);
+        if (pid == PID_DEAD) continue;
+        const float4 xm = ldq(buf, npad, Pl<D>::XM, i);
+        const int bx = assoc_cell(xm.x, d.h, d.inv_h, d.h_pow2 != 0u) >> BS;
+        const int face = bx < d.shard_lo ? 0 : (bx >= d.shard_hi ? 1 : -1);
+        if (face < 0) continue;
+        float *msg = d.msg.out[face];
+        if (!msg) {  // no neighbour on that side: the caller's decomposition does not cover the scene
+            atomicOr(&d.counters[CTR_ERRORS], ERRBIT_SHARD);
             continue;
         }
-        float4 *rec = buf + 1 + (size_t)slot * H::REC_F4;
-        if (lane == 0) rec[0] = make_float4(__uint_as_float(d.block_key[b]), 0.f, 0.f, 0.f);
-        if (lane < H::NODES) rec[1 + lane] = d.nodes[(size_t)b * NPB + halo_node<D>(lane)];
+        const uint32_t slot = atomicAdd(reinterpret_cast<uint32_t *>(msg) + 1, 1u);  // a handful of particles per substep
+        if (slot >= d.msg.mig_cap) {
+            atomicOr(&d.counters[CTR_ERRORS], ERRBIT_SHARD);  // the particle is lost to the neighbour: wrong physics, reported
+            continue;
+        }
+        float *rec = msg_particles<D>(msg, d.msg.halo_cap) + (size_t)slot * RF;
+#pragma unroll
+        for (int qd = 0; qd < NQ; qd++) {
+            const float4 v = ldq(buf, npad, qd, i);
+            rec[qd * 4 + 0] = v.x; rec[qd * 4 + 1] = v.y; rec[qd * 4 + 2] = v.z; rec[qd * 4 + 3] = v.w;
+        }
+        rec[NQ * 4] = __uint_as_float(pid);
+        rec[NQ * 4 + 1] = __uint_as_float(ldstamp<D>(buf, npad, i));
     }
 }
 
-// Add a neighbour's partial sums to the blocks this rank has active.
-// blockIdx.y selects the message (buf, or buf2 of the other neighbour when given): the two touch different block layers.
-template <int D> __global__ __launch_bounds__(64) void k_add_halo(Dev d, const float4 *buf, const float4 *buf2, uint32_t cap, uint32_t epoch) {
+// Received pairs whose block is not active on this rank, by (key, pair): entry = epoch << 32 | face << 31 | (record + 1).
+// Entries of earlier substeps are free (epochs only grow): nothing is ever cleared.
+constexpr uint32_t ORPHAN_SLOTS = 4096;
+__device__ inline uint32_t orphan_hash(uint32_t key, uint32_t tag) { return hash_key(key ^ (tag * 0x9e3779b9u)) & (ORPHAN_SLOTS - 1u); }
+__device__ inline void orphan_insert(const Dev &d, uint32_t key, uint32_t tag, uint32_t face, uint32_t rec, uint32_t epoch) {
+    const unsigned long long mine = ((unsigned long long)epoch << 32) | ((unsigned long long)face << 31) | (rec + 1u);
+    uint32_t h = orphan_hash(key, tag);
+    for (uint32_t probe = 0; probe < ORPHAN_SLOTS; probe++) {
+        unsigned long long cur = __hip_atomic_load(&d.orphans[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        while ((uint32_t)(cur >> 32) != epoch) {  // free: claim it
+            const unsigned long long old = atomicCAS(&d.orphans[h], cur, mine);
+            if (old == cur) return;
+            cur = old;
+        }
+        h = (h + 1u) & (ORPHAN_SLOTS - 1u);
+    }
+    atomicOr(&d.counters[CTR_ERRORS], ERRBIT_SHARD);
+}
+// the record of (key, pair) among this substep's orphans, or null
+template <int D> __device__ inline const float4 *orphan_find(const Dev &d, uint32_t key, uint32_t tag, uint32_t epoch) {
+    uint32_t h = orphan_hash(key, tag);
+    for (uint32_t probe = 0; probe < ORPHAN_SLOTS; probe++) {
+        const unsigned long long cur = d.orphans[h];
+        if ((uint32_t)(cur >> 32) != epoch) return nullptr;
+        const uint32_t face = (uint32_t)(cur >> 31) & 1u, rec = ((uint32_t)cur & 0x7fffffffu) - 1u;
+        const float4 *r = msg_halo<D>(d.msg.in[face]) + (size_t)rec * HaloCfg<D>::REC_F4;
+        const float4 hd = r[0];
+        if (__float_as_uint(hd.x) == key && __float_as_uint(hd.y) == tag) return r;
+        h = (h + 1u) & (ORPHAN_SLOTS - 1u);
+    }
+    return nullptr;
+}
+
+// Add the neighbours' partial sums to the blocks this rank has active; blockIdx.y = face (the two messages touch
+// different block layers: slabs are at least 3 blocks wide). One wave per record.
+template <int D> __global__ __launch_bounds__(64) void k_add_halo(Dev d, uint32_t epoch) {
     using H = HaloCfg<D>;
-    if (blockIdx.y == 1) buf = buf2;
-    if (!buf) return;
-    const uint32_t n_rec = min(reinterpret_cast<const uint32_t *>(buf)[0], cap);
-    const float4 *in = buf + 1;
+    const uint32_t face = blockIdx.y;
+    const float *msg = d.msg.in[face];
+    if (!msg) return;
+    const uint32_t *hdr = reinterpret_cast<const uint32_t *>(msg);
+    const uint32_t n_rec = min(hdr[0], d.msg.halo_cap);
+    if (blockIdx.x == 0 && threadIdx.x == 0 && hdr[1] != 0u && (hdr[2] & MSG_FLAG_UNIFORM) != (d.uniform ? MSG_FLAG_UNIFORM : 0u))
+        atomicOr(&d.counters[CTR_ERRORS], ERRBIT_SHARD);  // the neighbour's particle records are laid out differently (wgs_set_uniform_material on some ranks only)
+    const float4 *in = msg_halo<D>(msg);
     const int lane = threadIdx.x;
     for (uint32_t r = blockIdx.x; r < n_rec; r += gridDim.x) {
         const float4 *rec = in + (size_t)r * H::REC_F4;
-        const uint32_t key = __float_as_uint(rec[0].x);
+        const float4 hd = rec[0];
+        const uint32_t key = __float_as_uint(hd.x), tag = __float_as_uint(hd.y);
+        if (tag >= (uint32_t)H::NTAG) continue;  // (malformed: ignored)
         const uint32_t b = hmap_find(d, key, epoch);
-        if (b == NONE) continue;  // not active here: nobody on this rank reads those nodes
+        if (b == NONE) {  // not active here: only an arriving particle can read those nodes (k_g2p_arrivals)
+            if (lane == 0) orphan_insert(d, key, tag, face, r, epoch);
+            continue;
+        }
         if (lane < H::NODES) {
-            const size_t node = (size_t)b * NPB + halo_node<D>(lane);
+            const size_t node = (size_t)b * NPB + halo_node<D>((int)tag, lane);
             const float4 a = d.nodes[node], p = rec[1 + lane];
             d.nodes[node] = make_float4(a.x + p.x, a.y + p.y, a.z + p.z, a.w + p.w);
         }
     }
 }
 
-// Full-state record of one particle: NQ quads + pid. A particle buffer = 4 header floats
-// ([count, -, -, -]) + cap records.
-template <int D> constexpr int particle_record_floats() { return Pl<D>::NQ * 4 + 2; }  // quads, pid, cdf epoch
-
-// Particles whose associated block left [shard_lo, shard_hi): copy them to the outbox of the face
-// they crossed and vacate their slot. mode 1 = export every valid particle instead (read-back).
-template <int D> __global__ __launch_bounds__(256) void k_pack_migrants(Dev d, int side, int mode, float *buf_lo, float *buf_hi, uint32_t cap) {
-    constexpr int BS = Dim<D>::BSHIFT, NQ = Pl<D>::NQ, RF = particle_record_floats<D>();
-    float *buf = d.buf[side];
+// Read-back of a slab: full records of every live particle (guests included: they are this rank's until sent).
+template <int D> __global__ __launch_bounds__(256) void k_export_records(Dev d, int side, float *buf_out, uint32_t cap) {
+    constexpr int NQ = Pl<D>::NQ, RF = particle_record_floats<D>();
+    const float *buf = d.buf[side];
     const uint32_t npad = d.npad;
-    // right after a substep (mode 0) the buffer holds the valid particles only; a read-back (mode 1) may come
-    // after a migration round, when vacated slots and appended particles coexist
-    const uint32_t n = mode == 1 ? num_slots(d) : num_valid(d);
-    if (mode == 0 && blockIdx.x == 0 && threadIdx.x == 0) {
-        // after the fused G2P kernel this buffer holds exactly the valid particles, in sorted order (nothing in this
-        // launch reads CTR_N / CTR_NPREV)
-        d.counters[CTR_N] = n;
-        d.counters[CTR_NPREV] = n;  // residents of the next substep (arrivals are appended behind)
-    }
-    // mode 0: the fused G2P launch listed the slots of the particles that left the slab (Dev::leavers); mode 1 (read-back):
-    // every slot
-    const uint32_t nl = mode == 0 ? min(d.counters[CTR_NLEAVE], d.leavers_cap) : n;
-    for (uint32_t t = blockIdx.x * 256 + threadIdx.x; t < nl; t += gridDim.x * 256) {
-        const uint32_t i = mode == 0 ? d.leavers[t] : t;
-        if (i >= n) continue;
+    const uint32_t n = num_slots(d);
+    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
         const uint32_t pid = ldpid<D>(buf, npad, i);
         if (pid == PID_DEAD) continue;
-        int face = -1;
-        if (mode == 1) {
-            face = 0;
-        } else {
-            const float4 xm = ldq(buf, npad, Pl<D>::XM, i);
-            const int bx = assoc_cell(xm.x, d.h, d.inv_h, d.h_pow2 != 0u) >> BS;
-            if (bx < d.shard_lo) face = 0;
-            else if (bx >= d.shard_hi) face = 1;
-        }
-        if (face < 0) continue;
-        float *ob = face ? buf_hi : buf_lo;
-        const uint32_t slot = atomicAdd(reinterpret_cast<uint32_t *>(ob), 1u);  // a handful of particles per substep
-        if (slot < cap) {
-            float *rec = ob + 4 + (size_t)slot * RF;
+        const uint32_t slot = atomicAdd(reinterpret_cast<uint32_t *>(buf_out), 1u);
+        if (slot >= cap) continue;  // (the count says so)
+        float *rec = buf_out + 4 + (size_t)slot * RF;
 #pragma unroll
-            for (int q = 0; q < NQ; q++) {
-                const float4 v = ldq(buf, npad, q, i);
-                rec[q * 4 + 0] = v.x; rec[q * 4 + 1] = v.y; rec[q * 4 + 2] = v.z; rec[q * 4 + 3] = v.w;
-            }
-            rec[NQ * 4] = __uint_as_float(pid);
-            rec[NQ * 4 + 1] = __uint_as_float(ldstamp<D>(buf, npad, i));
-            if (mode == 0) stpid<D>(buf, npad, i, PID_DEAD);
-        } else {
-            atomicOr(&d.counters[CTR_ERRORS], ERRBIT_SHARD);  // the particle stays here: wrong physics, reported
+        for (int q = 0; q < NQ; q++) {
+            const float4 v = ldq(buf, npad, q, i);
+            rec[q * 4 + 0] = v.x; rec[q * 4 + 1] = v.y; rec[q * 4 + 2] = v.z; rec[q * 4 + 3] = v.w;
         }
+        rec[NQ * 4] = __uint_as_float(pid);
+        rec[NQ * 4 + 1] = __uint_as_float(ldstamp<D>(buf, npad, i));
     }
 }
 
-// Append the particles received from both neighbours after the current ones.
-template <int D> __global__ __launch_bounds__(256) void k_append_migrants(Dev d, int side, const float *in_lo, const float *in_hi, const float *out_lo,
-                                                                          const float *out_hi, uint32_t cap) {
-    constexpr int NQ = Pl<D>::NQ, RF = particle_record_floats<D>();
-    float *buf = d.buf[side];
-    const uint32_t n_lo = in_lo ? min(reinterpret_cast<const uint32_t *>(in_lo)[0], cap) : 0u;
-    const uint32_t n_hi = in_hi ? min(reinterpret_cast<const uint32_t *>(in_hi)[0], cap) : 0u;
-    const uint32_t first = d.counters[CTR_NPREV];  // the valid particles of the last substep occupy [0, NPREV)
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        // bookkeeping of the migration round (nothing in this launch reads these two): slots = residents + arrivals,
-        // valid = residents - departures + arrivals
-        auto cnt = [&](const float *b) { return b ? min(reinterpret_cast<const uint32_t *>(b)[0], cap) : 0u; };
-        const uint32_t arrivals = min(n_lo + n_hi, d.n - first);
-        d.counters[CTR_N] = first + arrivals;
-        d.counters[CTR_NV] = first - cnt(out_lo) - cnt(out_hi) + arrivals;
-    }
-    for (uint32_t r = blockIdx.x * 256 + threadIdx.x; r < n_lo + n_hi; r += gridDim.x * 256) {
-        const float *rec = r < n_lo ? in_lo + 4 + (size_t)r * RF : in_hi + 4 + (size_t)(r - n_lo) * RF;
-        const uint32_t i = first + r;
-        if (i >= d.n) {  // d.n = allocated capacity in sharded mode
-            atomicOr(&d.counters[CTR_ERRORS], ERRBIT_SHARD);
-            continue;
-        }
-#pragma unroll
-        for (int q = 0; q < NQ; q++) stq(buf, d.npad, q, i, make_float4(rec[q * 4], rec[q * 4 + 1], rec[q * 4 + 2], rec[q * 4 + 3]));
-        stpid<D>(buf, d.npad, i, __float_as_uint(rec[NQ * 4]));
-        ststamp<D>(buf, d.npad, i, __float_as_uint(rec[NQ * 4 + 1]));
+__global__ void k_clear_headers(uint32_t *a, uint32_t *b) {
+    if (threadIdx.x < 4) {
+        if (a) a[threadIdx.x] = 0;
+        if (b) b[threadIdx.x] = 0;
     }
 }
 
-// After the fused G2P kernel the other buffer holds exactly the valid particles, in sorted order.
+// Sharded data stepped WITHOUT its neighbours (wgs_step on a slab, or a slab that is not attached): the buffer the fused
+// G2P wrote holds exactly the valid particles, in sorted order.
 __global__ void k_shard_compacted(Dev d) {
     if (threadIdx.x == 0 && blockIdx.x == 0) {
         d.counters[CTR_N] = d.counters[CTR_NV];
-        d.counters[CTR_NPREV] = d.counters[CTR_NV];  // residents of the next substep (arrivals are appended behind)
+        d.counters[CTR_NPREV] = d.counters[CTR_NV];
     }
 }
 

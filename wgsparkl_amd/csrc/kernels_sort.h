@@ -26,7 +26,7 @@
 //     per chunk) when they need their block's first_particle, after all their independent work;
 //   * no per-particle rank, no per-cell counters, no sorting pass.
 #pragma once
-#include "kernels_cdf.h"
+#include "kernels_shard.h"
 
 namespace wgs {
 
@@ -60,49 +60,22 @@ __device__ inline void count_blocks(const Dev &d, int lane, uint32_t myid) {
 // sort.wgsl:26-36 touch_particle_blocks + sort.wgsl:89-99 update_block_particle_count, fused: the general form of
 // launch 1 (first substep, table-rebuild substeps, particles that arrived from a neighbouring rank). Every particle
 // it bins is a mover (it has no previous cell).
-// `tail`: sharded steady state — only the particles that arrived from the neighbours, slots [NPREV, N); the
-// residents go through k_rebin. `tail` = 2 also APPENDS them first: thread r copies record r of the two inbound
-// migration messages into slot NPREV + r and does the bookkeeping of the migration round (one launch instead of
-// append + bin).
-struct MigIn {
-    const float *in_lo, *in_hi, *out_lo, *out_hi;
-    uint32_t cap;
-};
+// `tail` = 1: sharded steady state — only the particles that arrived from the neighbours, slots [NPREV, N), which
+// k_g2p_arrivals wrote behind the residents; the residents go through k_rebin.
 // (body as a function of the workgroup index `bid`: k_bin runs it alone, k_rebin_tail behind the re-binning workgroups)
-template <int D, int TAIL> __device__ __forceinline__ void bin_body(const Dev &d, int side, uint32_t epoch, const MigIn &mig, uint32_t bid) {
-    constexpr int tail = TAIL;  // 0 = every slot, 1 = the arrivals (already appended), 2 = append + bin the arrivals
+template <int D, int TAIL> __device__ __forceinline__ void bin_body(const Dev &d, int side, uint32_t epoch, uint32_t bid) {
+    constexpr int tail = TAIL;  // 0 = every slot, 1 = the arrivals behind the residents
     constexpr int BS = Dim<D>::BSHIFT, BW = Dim<D>::BW, NN = Dim<D>::NNBR;
     __shared__ uint32_t s_keys[TOUCH_SET], s_ids[TOUCH_SET];
     const float *in = d.buf[side];
     const int tid = threadIdx.x, lane = tid & 63;
     if (tid < TOUCH_SET) s_keys[tid] = NONE;
     if (bid == 0u && tid < 16) d.counters[(tid < 8 ? (int)CTR_NCPIC : (int)CTR_NVISIT - 256) + 32 * tid] = 0;  // near-collider lists of this substep (k_regroup appends)
-    if (bid == 0u && tid >= 16 && tid < 18) d.counters[(int)CTR_NHALO + 32 * (tid - 16)] = 0;  // interface-layer lists (sharded runs)
+    if (bid == 0u && tid == 16) d.counters[CTR_NHALO] = 0;  // interface-block list (sharded runs)
     __syncthreads();
     const uint32_t first = tail ? d.counters[CTR_NPREV] : 0u;
     const uint32_t i = first + bid * SORT_THREADS + tid;
     uint32_t slots_end = num_slots(d);
-    if constexpr (TAIL == 2) {
-        constexpr int NQ = Pl<D>::NQ, RF = Pl<D>::NQ * 4 + 2;  // record = quads, pid, cdf epoch (kernels_shard.h)
-        auto cnt = [&](const float *b) { return b ? min(reinterpret_cast<const uint32_t *>(b)[0], mig.cap) : 0u; };
-        const uint32_t n_lo = cnt(mig.in_lo), n_hi = cnt(mig.in_hi);
-        const uint32_t arrivals = min(n_lo + n_hi, d.n - first);  // d.n = allocated capacity in sharded mode
-        if (n_lo + n_hi > arrivals && bid == 0u && tid == 0) atomicOr(&d.counters[CTR_ERRORS], ERRBIT_SHARD);
-        slots_end = first + arrivals;
-        if (bid == 0u && tid == 0) {  // nothing else in this launch reads these two
-            d.counters[CTR_N] = slots_end;
-            d.counters[CTR_NV] = first - cnt(mig.out_lo) - cnt(mig.out_hi) + arrivals;
-        }
-        const uint32_t r = i - first;
-        if (r < arrivals) {
-            const float *rec = r < n_lo ? mig.in_lo + 4 + (size_t)r * RF : mig.in_hi + 4 + (size_t)(r - n_lo) * RF;
-            float *buf = d.buf[side];
-#pragma unroll
-            for (int q = 0; q < NQ; q++) stq(buf, d.npad, q, i, make_float4(rec[q * 4], rec[q * 4 + 1], rec[q * 4 + 2], rec[q * 4 + 3]));
-            stpid<D>(buf, d.npad, i, __float_as_uint(rec[NQ * 4]));
-            ststamp<D>(buf, d.npad, i, __float_as_uint(rec[NQ * 4 + 1]));
-        }
-    }
     bool valid = i < slots_end;
     if (d.sharded && valid) valid = ldpid<D>(in, d.npad, i) != 0xffffffffu;  // slot vacated by a migrated particle
     int b[3] = {0, 0, 0};
@@ -179,8 +152,8 @@ template <int D, int TAIL> __device__ __forceinline__ void bin_body(const Dev &d
         if (cid != NONE) push_mover(d, cid, i);
     }
 }
-template <int D, int TAIL> __global__ __launch_bounds__(SORT_THREADS) void k_bin(Dev d, int side, uint32_t epoch, MigIn mig) {
-    bin_body<D, TAIL>(d, side, epoch, mig, blockIdx.x);
+template <int D, int TAIL> __global__ __launch_bounds__(SORT_THREADS) void k_bin(Dev d, int side, uint32_t epoch) {
+    bin_body<D, TAIL>(d, side, epoch, blockIdx.x);
 }
 
 // Steady-state launch 1 (sort.wgsl:26-36,89-99 for a buffer that is the sorted output of the previous
@@ -195,7 +168,7 @@ template <int D> __device__ __forceinline__ void rebin_body(const Dev &d, int si
     const int tid = threadIdx.x, lane = tid & 63;
     const uint32_t i = bid * SORT_THREADS + tid;
     if (bid == 0u && tid < 16) d.counters[(tid < 8 ? (int)CTR_NCPIC : (int)CTR_NVISIT - 256) + 32 * tid] = 0;  // near-collider lists of this substep (k_regroup appends)
-    if (bid == 0u && tid >= 16 && tid < 18) d.counters[(int)CTR_NHALO + 32 * (tid - 16)] = 0;  // interface-layer lists (sharded runs)
+    if (bid == 0u && tid == 16) d.counters[CTR_NHALO] = 0;  // interface-block list (sharded runs)
     // sharded runs: the residents only (arrivals have no previous cell: k_bin's tail pass), minus the slots
     // vacated by particles that migrated away
     const bool in_range = i < (d.sharded ? min(d.counters[CTR_NPREV], d.counters[CTR_N]) : num_slots(d));
@@ -259,12 +232,11 @@ template <int D> __global__ __launch_bounds__(SORT_THREADS) void k_rebin(Dev d, 
     rebin_body<D>(d, side, epoch, blockIdx.x);
 }
 // Sharded steady state: the residents re-binned (first `nrebin` workgroups) and the particles that arrived from the
-// neighbours appended + binned (the others) in ONE launch — a dependent launch costs ~4.5 us whatever it does, and the
-// two touch different slots (shared state only through atomics; CTR_N only grows in this launch and the re-binning
-// workgroups bound their range by min(CTR_NPREV, CTR_N)).
-template <int D, int TAIL> __global__ __launch_bounds__(SORT_THREADS) void k_rebin_tail(Dev d, int side, uint32_t epoch, MigIn mig, uint32_t nrebin) {
+// neighbours binned (the others) in ONE launch — a dependent launch costs ~4.5 us whatever it does, and the two touch
+// different slots (shared state only through atomics).
+template <int D> __global__ __launch_bounds__(SORT_THREADS) void k_rebin_tail(Dev d, int side, uint32_t epoch, uint32_t nrebin) {
     if (blockIdx.x < nrebin) rebin_body<D>(d, side, epoch, blockIdx.x);
-    else bin_body<D, TAIL>(d, side, epoch, mig, blockIdx.x - nrebin);
+    else bin_body<D, 1>(d, side, epoch, blockIdx.x - nrebin);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -380,7 +352,7 @@ __device__ __forceinline__ void scan_chunk(const Dev &d, uint32_t epoch, uint32_
     if (tid == 0) g_prof[WGS_PROF_ROWS - 1][0] = wall_clock64();
 #endif
     if (k == 0 && tid == 0) d.counters[CTR_NPHYS_SEEN + (epoch & 1u)] = d.counters[CTR_NPHYS];
-    if (k == 0 && tid < 4 && d.hdr_clear[tid]) d.hdr_clear[tid][0] = 0u;  // outgoing halo / migrant message counts of this substep
+    if (k == 0 && tid < 4 && d.msg.out[tid >> 1]) reinterpret_cast<uint32_t *>(d.msg.out[tid >> 1])[tid & 1] = 0u;  // record counts of this substep's outgoing messages
 }
 
 // Second level of the scan, by the wave that owns block `id`: loads of the group's 16 (stamp, count) pairs — issued
@@ -684,10 +656,8 @@ __device__ __forceinline__ void regroup_block(const Dev &d, int side, uint32_t e
         d.block_cdf_flag[id] = 0;      // (block_acc is cleared by the grid update: the waves of this group read it)
     }
     if (listed) append_visits(d, id, bstart, btotal, lane);
-    if (d.sharded && lane == 0 && (b[0] == d.shard_lo || b[0] == d.shard_hi)) {  // interface layers of the slab (k_pack_halos)
-        const uint32_t sd = b[0] == d.shard_lo ? 0u : 1u;
-        d.halo_list[(size_t)sd * d.cap + atomicAdd(&d.counters[CTR_NHALO + 32u * sd], 1u)] = id;
-    }
+    if (d.sharded && lane == 0 && iface_masks<D>(d, b[0]).gather != 0u)  // interface layers of the slab (k_pack_face)
+        d.halo_list[atomicAdd(&d.counters[CTR_NHALO], 1u)] = id;
     WGS_PROF(6)
     WGS_PROF_END()
 }

@@ -12,6 +12,7 @@
 // binding limit, p2g.wgsl:129-133).
 #pragma once
 #include "kernels_bodies.h"
+#include "kernels_shard.h"
 
 namespace wgs {
 
@@ -153,9 +154,7 @@ __global__ __launch_bounds__(P2GCfg<D>::NW * 64, WPE) void k_p2g_pair(Dev d, int
 // ------------------------------------------------------------ grid update
 // Gather of the slabs covering each node + solver/grid_update.wgsl:55-64.
 // PHASE 0: gather + update in one pass (single GPU). Sharded runs: PHASE 3 = the same single pass, except that the
-// interface node layers come from nodes[] (gathered and exchanged by k_pack_halos / k_add_halo). PHASE 1 = gather only
-// (partial momentum / mass sums into nodes[]) and PHASE 2 = update from nodes[] remain for callers that pack the two
-// faces separately (wgs_shard_pack_halo).
+// interface node layers come from nodes[] (gathered and exchanged by k_pack_face / k_add_halo, kernels_shard.h).
 
 // Partial (momentum, mass) sum of one node from the (at most 2^D) slabs that cover it, in the fixed order of the
 // grid update.
@@ -201,13 +200,13 @@ template <int D, int PHASE, bool TWOWAY = false> __global__ __launch_bounds__(25
         l[1] = (ln >> BS) & (BW - 1);
         l[2] = D == 3 ? (ln >> (2 * BS)) : 0;
         float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
-        // PHASE 3 (sharded runs): the two interface node layers of the blocks of layer shard_lo / shard_hi were
-        // gathered by k_pack_halos and completed with the neighbour's partial sums (k_add_halo): take them from nodes[]
+        // PHASE 3 (sharded runs): the x-layer pairs of the interface layers that a neighbour's particles reach were gathered
+        // by k_pack_face and completed with the neighbour's partial sums (k_add_halo): take them from nodes[]
         bool from_nodes = false;
         if constexpr (PHASE == 3) {
             int bc[3] = {0, 0, 0};
             unpack_key<D>(d.block_key[b], bc);
-            from_nodes = l[0] < 2 && (bc[0] == d.shard_lo || bc[0] == d.shard_hi);
+            from_nodes = ((iface_masks<D>(d, bc[0]).from_nodes >> (l[0] >> 1)) & 1u) != 0u;
         }
         float isum[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};  // node impulse (two-way coupling): linear, angular
         uint32_t srcs[NN];

@@ -23,6 +23,7 @@
 namespace wgs {
 
 constexpr uint32_t NONE = 0xffffffffu;
+constexpr uint32_t PID_DEAD = 0xffffffffu;  // sharded runs: slot of a particle that now lives on a neighbouring rank
 constexpr int NPB = 64;  // nodes (= cells) per block: 4^3 or 8^2, grid.wgsl:43
 
 template <int D> struct Dim;
@@ -107,17 +108,25 @@ struct NodeCdf {        // grid.wgsl:233-240
 // every wave of that launch reads the counters of the first line; sharing a line made those reads queue behind the atomics)
 enum { CTR_NBLOCKS = 0, CTR_ERRORS = 1, CTR_NPHYS = 2, CTR_N = 4, CTR_NV = 5,
        CTR_NPREV = 6,  // sharded runs: slots [0, NPREV) are the sorted output of the last substep, [NPREV, N) arrivals
-       CTR_NLEAVE = 7,  // sharded runs: particles the last fused G2P launch found outside the slab (Dev::leavers)
+       CTR_NLEAVE = 7,  // sharded runs: particles the last fused G2P launches found outside the core range (Dev::leavers): next substep's guests
+       CTR_TICKET = 10,  // sharded runs: workgroups of k_g2p_arrivals that are done (the last one does the bookkeeping)
        CTR_NPHYS_SEEN = 8,  // [8], [9]: the id counter as launch 2 of an even / odd substep saw it (kernels_sort.h regroup_block)
        CTR_NVISIT = 64,  // [64 + 32 k], k = 0..7: length of the visit list of XCD k (Dev::visit_list), one cache line each
        CTR_NCPIC = 320,  // [320 + 32 k], k = 0..7: length of list k of the near-collider blocks (Dev::cpic_list), one cache line each
-       CTR_NHALO = 576,  // [576], [608]: sharded runs, length of the lists of active blocks in block layer shard_lo / shard_hi (Dev::halo_list)
+       CTR_NHALO = 576,  // sharded runs: length of the list of active blocks in the interface layers (Dev::halo_list)
        CTR_COUNT = 640 };
-enum { ERRBIT_OVERFLOW = 1u, ERRBIT_KEYRANGE = 2u, ERRBIT_SHARD = 4u };
+enum { ERRBIT_OVERFLOW = 1u, ERRBIT_KEYRANGE = 2u, ERRBIT_SHARD = 4u, ERRBIT_MATERIAL = 8u };
 // Bit 31 of a perm_cell entry (block ids stay below 2^24): the particle's block is near a collider. Written by launch 2 of the
 // sort when it computes the block classes itself; the fused G2P then knows which body a particle belongs to from the sort
 // entry it loads anyway, instead of a dependent block_cpic lookup in the middle of every chunk.
 constexpr uint32_t CELL_LISTED = 0x80000000u;
+
+// Message buffers of a slab (kernels_shard.h): [0] lower, [1] upper neighbour; null = no neighbour on that side.
+struct ShardMsg {
+    float *out[2];
+    const float *in[2];
+    uint32_t halo_cap, mig_cap;  // records per message
+};
 
 // Everything a kernel needs, passed by value.
 struct Dev {
@@ -127,7 +136,12 @@ struct Dev {
     uint32_t n;          // particle slots in the current buffer (valid + vacated)
     uint32_t nv;         // valid particles = sorted slots (== n unless sharded and particles migrated)
     uint32_t sharded;    // 1: x-slab decomposition (kernels_shard.h)
-    int shard_lo, shard_hi;  // owned block range along x
+    int shard_lo, shard_hi;  // core block range along x
+    uint32_t shard_has_lo, shard_has_hi;  // a neighbour below / above (wgs_shard_attach)
+    uint32_t skip_guests;    // the fused G2P drops the particles whose block lies outside the core range: their new owner
+                             // advances them (set by the sharded step; wgs_step on a slab advances everything it holds)
+    ShardMsg msg;            // message buffers of the slab
+    unsigned long long *orphans;  // received node pairs whose block is not active here (kernels_shard.h)
     uint32_t npad;       // plane stride (floats)
     float *buf[2];       // ping-pong particle buffers
     uint32_t *perm;      // sorted slot -> index in the current buffer
@@ -167,7 +181,7 @@ struct Dev {
     uint2 *visit_list;        // 8 x visit_cap: (listed block, chunk of 64 sorted particles that holds some of its particles); list k, at
                               // [k * visit_cap, + counters[CTR_NVISIT + 32 k]), is the one the CPIC body of the fused G2P advances on
                               // XCD k (g2p_body.inc); device_math.h append_visits deals the chunks to the lists
-    uint32_t *halo_list;      // sharded runs, 2 x cap: the active blocks of the two interface layers (what k_pack_halos gathers and packs)
+    uint32_t *halo_list;      // sharded runs, cap: the active blocks of the interface layers (what k_pack_face gathers and packs)
     uint32_t visit_cap;       // per list (an eighth of the chunks + 2 per block would do; a block is visited once per chunk it spans)
     uint32_t listed_in_perm;  // this substep's perm_cell entries carry CELL_LISTED (launch 2 of the sort computed the block classes)
     uint32_t g2p_npass;       // chunks per wave of the fused G2P of this substep (defines the eighths; set by the host per substep)
@@ -179,9 +193,8 @@ struct Dev {
     int32_t *impulses;       // 16 * 8: fixed-point (x 1e5) linear[D] + angular impulses accumulated by P2G
     float4 *imp_slab;        // cap*TILE*IMPQ per-block partial node impulses (two-way coupling only), or null
     uint32_t *leavers;       // sharded: output slots of the particles that left [shard_lo, shard_hi) in the last substep (filled by the
-                             // fused G2P, consumed by k_pack_migrants: no pass over all particles to find a handful)
+                             // fused G2P and k_g2p_arrivals, consumed by the next substep's k_pack_face: its guests)
     uint32_t leavers_cap;
-    uint32_t *hdr_clear[4];  // sharded: headers of the registered outgoing message buffers, zeroed by the scan of k_regroup
     // rigid particles of mesh colliders (kernels_rigid.h); n_rigid == 0 when there is none
     uint32_t n_rigid, n_rvtx;
     float *rp_local, *rp_world;          // n_rigid * D: sample points, body frame / world

@@ -37,7 +37,7 @@ def compare_with_single_domain(pipe, dist, comm, world, rank, slab, full_scene, 
     face_blocks = (int((ys.max() - ys.min()) / slab["cell_width"]) // 4 + 4) * (int((zs.max() - zs.min()) / slab["cell_width"]) // 4 + 4)
     shard = NativeShard(pipe, slab["params"], ps, slab["global_ids"], slab["colliders"], slab["cell_width"], slab["grid_capacity"], lo, hi,
                         rank > 0, rank < world - 1, particle_capacity=int(ps.n * 1.5) + 4096, model=slab["model"],
-                        halo_capacity_blocks=2 * face_blocks + 64, migrant_capacity=max(1024, ps.n // 8), comm=comm,
+                        halo_capacity_records=3 * face_blocks + 64, migrant_capacity=max(1024, ps.n // 8), comm=comm,
                         uniform_material=slab.get("uniform_material"))
     n0 = shard.num_particles()
     per = max(1, substeps // max(1, calls))
