@@ -20,18 +20,18 @@ FIELDS = ("pos", "vel", "def_grad", "affine", "cdf_normal", "cdf_rigid_vel", "cd
 
 
 def iface_masks(bx, lo, hi, has_lo, has_hi, ntag):
-    """kernels_shard.h iface_masks: (gather, from_nodes, send_lo, send_hi) bit masks over the x-layer pairs of layer bx."""
+    """kernels_shard.h iface_masks: (recv, send_lo, send_hi) bit masks over the x-layer pairs of block layer bx."""
     ALL = (1 << ntag) - 1
-    g = f = sl = sh = 0
+    rc = sl = sh = 0
     if has_lo:
-        if bx == lo - 1: g |= ALL; sl |= ALL
-        if bx == lo: g |= ALL; sl |= 1; f |= ALL
-        if bx == lo + 1: g |= 1; f |= 1
+        if bx == lo - 1: sl |= ALL
+        if bx == lo: sl |= 1; rc |= ALL
+        if bx == lo + 1: rc |= 1
     if has_hi:
-        if bx == hi - 1: g |= ALL; f |= ALL
-        if bx == hi: g |= ALL; sh |= ALL; f |= 1
-        if bx == hi + 1: g |= 1; sh |= 1
-    return g, f, sl, sh
+        if bx == hi - 1: rc |= ALL
+        if bx == hi: sh |= ALL; rc |= 1
+        if bx == hi + 1: sh |= 1
+    return rc, sl, sh
 
 
 class OracleShard:
@@ -70,7 +70,7 @@ class OracleShard:
         mv = st.g["node_mv"].reshape(-1, 64, D + 1)
         halo = ([], [])
         for b in range(nb):
-            _, _, sl, sh = iface_masks(int(vid[b, 0]), self.lo, self.hi, self.has_lower, self.has_upper, self.ntag)
+            _, sl, sh = iface_masks(int(vid[b, 0]), self.lo, self.hi, self.has_lower, self.has_upper, self.ntag)
             for f, send in ((0, sl), (1, sh)):
                 for tag in range(self.ntag):
                     if not (send >> tag) & 1:
@@ -137,6 +137,8 @@ class OracleShard:
                 nodes = np.nonzero(self.node_lx // 2 == tag)[0]
                 b = index.get(key)
                 if b is not None:
+                    rc, _, _ = iface_masks(key[0], self.lo, self.hi, self.has_lower, self.has_upper, self.ntag)
+                    assert (rc >> tag) & 1, "a neighbour sent a pair this slab's grid update would not add"
                     mv[b, nodes, :] += vals
                 else:
                     orphans[(key, tag)] = vals

@@ -63,14 +63,14 @@ def test_protocol_lockstep_four_slabs_and_mask_table(oracle_libs):
     from shard_oracle import OracleShard, iface_masks, lockstep
     from wgsparkl_amd.sharded import split_scene
     # rank with core range [8, 12), both neighbours, 3D (2 x-layer pairs per block): what each layer is to it
-    m = {bx: iface_masks(bx, 8, 12, True, True, 2) for bx in range(6, 15)}
-    assert m[6] == (0, 0, 0, 0) and m[14] == (0, 0, 0, 0) and m[10] == (0, 0, 0, 0)
-    assert m[7] == (3, 0, 3, 0)          # layer lo - 1: only guests write it; everything they wrote goes down
-    assert m[8] == (3, 3, 1, 0)          # layer lo: first pair shared with the lower neighbour's core, all pairs may receive
-    assert m[9] == (1, 1, 0, 0)          # layer lo + 1: first pair may receive (the lower neighbour's guests)
-    assert m[11] == (3, 3, 0, 0)         # layer hi - 1: may receive (the upper neighbour's guests)
-    assert m[12] == (3, 1, 0, 3)         # layer hi: own core reaches the first pair, own guests all of it: all pairs go up
-    assert m[13] == (1, 0, 0, 1)         # layer hi + 1: own guests reach the first pair
+    m = {bx: iface_masks(bx, 8, 12, True, True, 2) for bx in range(6, 15)}      # (recv, send_lo, send_hi)
+    assert m[6] == (0, 0, 0) and m[14] == (0, 0, 0) and m[10] == (0, 0, 0)
+    assert m[7] == (0, 3, 0)          # layer lo - 1: only guests write it; everything they wrote goes down
+    assert m[8] == (3, 1, 0)          # layer lo: first pair shared with the lower neighbour's core; all pairs may receive
+    assert m[9] == (1, 0, 0)          # layer lo + 1: first pair may receive (the lower neighbour's guests)
+    assert m[11] == (3, 0, 0)         # layer hi - 1: may receive (the upper neighbour's guests)
+    assert m[12] == (1, 0, 3)         # layer hi: own core reaches the first pair, own guests all of it: all pairs go up
+    assert m[13] == (0, 0, 1)         # layer hi + 1: own guests reach the first pair
     world, k = 4, 12
     sc = make_scene(3, world)
     part = partition_of(sc, world)

@@ -24,6 +24,9 @@ __global__ __launch_bounds__(256) void k_g2p_arrivals(Dev d, int side, uint32_t 
 #pragma unroll
     for (int f = 0; f < 2; f++) n_in[f] = in_msg[f] ? min(reinterpret_cast<const uint32_t *>(in_msg[f])[1], d.msg.mig_cap) : 0u;
     const uint32_t n_arr_all = n_in[0] + n_in[1];
+    if (blockIdx.x == 0 && tid < 2 && in_msg[tid] && n_in[tid] != 0u &&
+        (reinterpret_cast<const uint32_t *>(in_msg[tid])[2] & MSG_FLAG_UNIFORM) != (d.uniform ? MSG_FLAG_UNIFORM : 0u))
+        atomicOr(&d.counters[CTR_ERRORS], ERRBIT_SHARD);  // the neighbour's particle records are laid out differently (wgs_set_uniform_material on some ranks only)
     // sorted residents of this substep: the arrivals go behind them (read by every workgroup before the last one to
     // finish rewrites the counters)
     const uint32_t s0 = d.counters[CTR_NV];
@@ -43,6 +46,11 @@ __global__ __launch_bounds__(256) void k_g2p_arrivals(Dev d, int side, uint32_t 
         {
             const int a = tid >> 5, n = tid & 31;
             const uint32_t r = base + (uint32_t)a;
+            uint32_t key = NONE, b = NONE;
+            int tag = 0, q = 0;
+            bool need = false;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            NodeCdf nc = {0.f, 0u, NONE, 0u};
             if (r < n_arr && n < NS) {
                 const float *rec = record_of(r);
                 const int s[3] = {n % 3, (n / 3) % 3, D == 3 ? n / 9 : 0};
@@ -57,37 +65,60 @@ __global__ __launch_bounds__(256) void k_g2p_arrivals(Dev d, int side, uint32_t 
                     shift += BS;
                     pt[k] = (float)c * h;
                 }
-                const uint32_t key = pack_key<D>(bcoord);
-                const uint32_t b = block_in_key_range<D>(bcoord) ? hmap_find(d, key, epoch) : NONE;
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                NodeCdf nc = {0.f, 0u, NONE, 0u};
+                key = pack_key<D>(bcoord);
+                b = block_in_key_range<D>(bcoord) ? hmap_find(d, key, epoch) : NONE;
+                halo_slot<D>(ln, tag, q);
                 if (b != NONE) {  // active here: the grid update left its velocity (all contributions of both ranks)
                     v = d.nodes[(size_t)b * NPB + ln];
                     if (cpic) nc = d.node_cdf[(size_t)b * NPB + ln];
                 } else {
-                    // not active here: nobody on this rank contributes; what the old owner sent is the node's total
-                    // (grid_update.wgsl:55-64 applied to it here). No record: the node is empty.
-                    int tag, q;
-                    halo_slot<D>(ln, tag, q);
-                    const float4 *orec = orphan_find<D>(d, key, (uint32_t)tag, epoch);
-                    if (orec) {
-                        const float4 p = orec[1 + q];
-                        const float mass = D == 3 ? p.w : p.z;
-                        const float inv_mass = mass > 0.f ? 1.0f / mass : 0.f;
-                        const float mom[3] = {p.x, p.y, p.z};
-                        const float lim = h / dt;
-                        float vel[3] = {0.f, 0.f, 0.f};
-#pragma unroll
-                        for (int k = 0; k < D; k++) {
-                            const float t = (mom[k] + mass * d.sp->gravity[k] * dt) * inv_mass;
-                            vel[k] = fminf(fmaxf(t, -lim), lim);
-                        }
-                        v = D == 3 ? make_float4(vel[0], vel[1], vel[2], mass) : make_float4(vel[0], vel[1], mass, 0.f);
-                    }
+                    need = true;
                     // (mesh colliders: the mesh part of a node cdf exists for active blocks only; an arrival that enters an
                     // empty region next to a mesh sees the analytic shapes there for this one substep)
                     if (cpic) nc = node_cdf_eval<D>(d, pt);
                 }
+            }
+            // Nodes of blocks that are NOT active here: nobody on this rank contributes to them, so what the old owner sent is
+            // the node's total (grid_update.wgsl:55-64 applied to it here); no record = the node is empty. The 32 lanes of an
+            // arrival scan the headers of its message together (rare: the first particles to enter an empty region).
+            {
+                const int face = r < n_in[0] ? 0 : 1;
+                const float *msg = r < n_arr ? in_msg[face] : nullptr;
+                const uint32_t n_rec = msg ? min(reinterpret_cast<const uint32_t *>(msg)[0], d.msg.halo_cap) : 0u;
+                const float4 *recs = msg ? msg_halo<D>(msg) : nullptr;
+                const int sub = tid & 31;
+                const unsigned long long needs = __ballot(need);
+                const bool grp = ((needs >> (tid & 32)) & 0xffffffffull) != 0ull;   // some lane of my 32-lane group needs a record
+                uint32_t found = NONE;
+                for (uint32_t rb = 0; __ballot(grp && rb < n_rec) != 0ull; rb += 32u) {
+                    const uint32_t rr = rb + (uint32_t)sub;
+                    uint32_t hk = NONE, ht = NONE;
+                    if (grp && rr < n_rec) {
+                        const float4 hd = recs[(size_t)rr * HaloCfg<D>::REC_F4];
+                        hk = __float_as_uint(hd.x);
+                        ht = __float_as_uint(hd.y);
+                    }
+                    for (int sft = 0; sft < 32; sft++) {
+                        const uint32_t k2 = (uint32_t)__shfl((int)hk, sft, 32), t2 = (uint32_t)__shfl((int)ht, sft, 32);
+                        if (need && k2 == key && t2 == (uint32_t)tag && rb + (uint32_t)sft < n_rec) found = rb + (uint32_t)sft;
+                    }
+                }
+                if (need && found != NONE) {
+                    const float4 p = recs[(size_t)found * HaloCfg<D>::REC_F4 + 1 + q];
+                    const float mass = D == 3 ? p.w : p.z;
+                    const float inv_mass = mass > 0.f ? 1.0f / mass : 0.f;
+                    const float mom[3] = {p.x, p.y, p.z};
+                    const float lim = h / dt;
+                    float vel[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int k = 0; k < D; k++) {
+                        const float t = (mom[k] + mass * d.sp->gravity[k] * dt) * inv_mass;
+                        vel[k] = fminf(fmaxf(t, -lim), lim);
+                    }
+                    v = D == 3 ? make_float4(vel[0], vel[1], vel[2], mass) : make_float4(vel[0], vel[1], mass, 0.f);
+                }
+            }
+            if (r < n_arr && n < NS) {
                 s_nv[a][n] = v;
                 s_nc[a][n] = make_uint2(nc.affinities, nc.closest_id);
             }

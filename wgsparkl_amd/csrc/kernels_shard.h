@@ -17,9 +17,11 @@
 //   and lo (first pair) + the guests at bx = lo - 1. A record = one x-layer PAIR of one block (key, pair index,
 //   2 * BW^(D-1) float4); pairs only guests can have touched are sent when they are non-zero. Both sides ADD what
 //   they receive (a + b == b + a bitwise: both hold identical totals of the nodes they share) and update redundantly.
-//   A received pair whose block is not active here (the first particles to enter an empty region) is kept by
-//   reference in a small table: the arrivals' G2P reads such nodes straight from the message — nobody here
-//   contributes to them, the neighbour's partial sum IS the total.
+//   Nothing is added by a launch of its own: the grid update looks its interface blocks up in the inbound message (a wave
+//   scans the ~300 record headers of a message in a handful of coalesced loads) and adds the neighbour's pair to its own
+//   gather. A received pair whose block is not active here (the first particles to enter an empty region) can only
+//   matter to an arriving particle: its G2P reads such nodes straight from the message — nobody here contributes to
+//   them, the neighbour's partial sum IS the total.
 //
 // Slabs with two neighbours must be at least 3 blocks wide (the layers the two messages touch must not overlap).
 // Everything is stream-ordered: messages are fixed-capacity buffers whose header holds the record counts,
@@ -53,29 +55,31 @@ template <int D> __device__ inline void halo_slot(uint32_t ln, int &tag, int &q)
 }
 
 // What block layer bx is to this slab (bit t = x-layer pair t):
-//   gather     — the pack launch gathers these pairs' partial sums from the slabs into nodes[]
-//   from_nodes — the grid update takes these pairs from nodes[] (own partial + what the neighbours sent)
-//   send_lo/hi — pairs that travel to the lower / upper neighbour
+//   recv       — pairs a neighbour's particles can reach: the grid update adds what the neighbour sent to its own gather
+//   send_lo/hi — pairs that travel to the lower / upper neighbour (k_pack_face gathers them from the slabs)
 struct IfaceMasks {
-    uint32_t gather, from_nodes, send_lo, send_hi;
+    uint32_t recv, send_lo, send_hi;
 };
 template <int D> __device__ inline IfaceMasks iface_masks(const Dev &d, int bx) {
     constexpr uint32_t ALL = HaloCfg<D>::ALL;
-    IfaceMasks m = {0u, 0u, 0u, 0u};
+    IfaceMasks m = {0u, 0u, 0u};
     if (d.shard_has_lo) {
         const int lo = d.shard_lo;
-        if (bx == lo - 1) { m.gather |= ALL; m.send_lo |= ALL; }
-        if (bx == lo)     { m.gather |= ALL; m.send_lo |= 1u; m.from_nodes |= ALL; }
-        if (bx == lo + 1) { m.gather |= 1u; m.from_nodes |= 1u; }
+        if (bx == lo - 1) m.send_lo |= ALL;
+        if (bx == lo)     { m.send_lo |= 1u; m.recv |= ALL; }
+        if (bx == lo + 1) m.recv |= 1u;
     }
     if (d.shard_has_hi) {
         const int hi = d.shard_hi;
-        if (bx == hi - 1) { m.gather |= ALL; m.from_nodes |= ALL; }
-        if (bx == hi)     { m.gather |= ALL; m.send_hi |= ALL; m.from_nodes |= 1u; }
-        if (bx == hi + 1) { m.gather |= 1u; m.send_hi |= 1u; }
+        if (bx == hi - 1) m.recv |= ALL;
+        if (bx == hi)     { m.send_hi |= ALL; m.recv |= 1u; }
+        if (bx == hi + 1) m.send_hi |= 1u;
     }
     return m;
 }
+// the inbound message that can hold pairs of layer bx (layers lo, lo + 1 come from below, hi - 1, hi from above: a slab
+// with two neighbours is at least 3 blocks wide)
+__device__ inline int iface_recv_face(const Dev &d, int bx) { return (d.shard_has_hi && bx >= d.shard_hi - 1) ? 1 : 0; }
 
 // Full-state record of one particle: NQ quads + pid + cdf epoch.
 template <int D> constexpr int particle_record_floats() { return Pl<D>::NQ * 4 + 2; }
@@ -96,15 +100,15 @@ template <int D> __device__ inline float *msg_particles(float *msg, uint32_t hal
 
 template <int D> __device__ inline float4 gather_slabs(const Dev &d, uint32_t b, uint32_t ln);  // kernels_transfer.h
 
-// After P2G: (a) one wave per interface block (the sort listed them): the pairs the slab needs in nodes[] are gathered
-// from the slabs, and those that travel are appended to the outgoing messages; (b) the guests — the particles the last
+// After P2G: (a) one wave per block of the layers that travel (the sort listed them): their pairs are gathered from the
+// slabs and appended to the outgoing messages; (b) the guests — the particles the last
 // G2P launch found outside the core range (Dev::leavers) — are copied into the message of the face they crossed. They
 // are NOT vacated here: this rank's fused G2P drops them (their block lies outside the core range).
 template <int D> __global__ __launch_bounds__(64) void k_pack_face(Dev d, int side, uint32_t nblk_wgs) {
     using H = HaloCfg<D>;
     constexpr int BS = Dim<D>::BSHIFT, NQ = Pl<D>::NQ, RF = particle_record_floats<D>();
     const int lane = threadIdx.x;
-    if (blockIdx.x == 0 && lane < 2 && d.msg.out[lane])   // layout of this rank's particle records (checked by the receiver)
+    if (blockIdx.x == 0 && lane < 2 && d.msg.out[lane])   // layout of this rank's particle records (checked by the receiver, k_g2p_arrivals)
         reinterpret_cast<uint32_t *>(d.msg.out[lane])[2] = d.uniform ? MSG_FLAG_UNIFORM : 0u;
     if (blockIdx.x < nblk_wgs) {
         const uint32_t nl = min(d.counters[CTR_NHALO], d.cap);
@@ -116,10 +120,7 @@ template <int D> __global__ __launch_bounds__(64) void k_pack_face(Dev d, int si
             int tag, q;
             halo_slot<D>((uint32_t)lane, tag, q);   // lane = node of the block
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if ((m.gather >> tag) & 1u) {
-                v = gather_slabs<D>(d, b, (uint32_t)lane);
-                d.nodes[(size_t)b * NPB + lane] = v;
-            }
+            if (((m.send_lo | m.send_hi) >> tag) & 1u) v = gather_slabs<D>(d, b, (uint32_t)lane);
             const bool nz = v.x != 0.f || v.y != 0.f || v.z != 0.f || v.w != 0.f;
 #pragma unroll
             for (int f = 0; f < 2; f++) {
@@ -182,66 +183,29 @@ template <int D> __global__ __launch_bounds__(64) void k_pack_face(Dev d, int si
     }
 }
 
-// Received pairs whose block is not active on this rank, by (key, pair): entry = epoch << 32 | face << 31 | (record + 1).
-// Entries of earlier substeps are free (epochs only grow): nothing is ever cleared.
-constexpr uint32_t ORPHAN_SLOTS = 4096;
-__device__ inline uint32_t orphan_hash(uint32_t key, uint32_t tag) { return hash_key(key ^ (tag * 0x9e3779b9u)) & (ORPHAN_SLOTS - 1u); }
-__device__ inline void orphan_insert(const Dev &d, uint32_t key, uint32_t tag, uint32_t face, uint32_t rec, uint32_t epoch) {
-    const unsigned long long mine = ((unsigned long long)epoch << 32) | ((unsigned long long)face << 31) | (rec + 1u);
-    uint32_t h = orphan_hash(key, tag);
-    for (uint32_t probe = 0; probe < ORPHAN_SLOTS; probe++) {
-        unsigned long long cur = __hip_atomic_load(&d.orphans[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        while ((uint32_t)(cur >> 32) != epoch) {  // free: claim it
-            const unsigned long long old = atomicCAS(&d.orphans[h], cur, mine);
-            if (old == cur) return;
-            cur = old;
-        }
-        h = (h + 1u) & (ORPHAN_SLOTS - 1u);
-    }
-    atomicOr(&d.counters[CTR_ERRORS], ERRBIT_SHARD);
-}
-// the record of (key, pair) among this substep's orphans, or null
-template <int D> __device__ inline const float4 *orphan_find(const Dev &d, uint32_t key, uint32_t tag, uint32_t epoch) {
-    uint32_t h = orphan_hash(key, tag);
-    for (uint32_t probe = 0; probe < ORPHAN_SLOTS; probe++) {
-        const unsigned long long cur = d.orphans[h];
-        if ((uint32_t)(cur >> 32) != epoch) return nullptr;
-        const uint32_t face = (uint32_t)(cur >> 31) & 1u, rec = ((uint32_t)cur & 0x7fffffffu) - 1u;
-        const float4 *r = msg_halo<D>(d.msg.in[face]) + (size_t)rec * HaloCfg<D>::REC_F4;
-        const float4 hd = r[0];
-        if (__float_as_uint(hd.x) == key && __float_as_uint(hd.y) == tag) return r;
-        h = (h + 1u) & (ORPHAN_SLOTS - 1u);
-    }
-    return nullptr;
-}
-
-// Add the neighbours' partial sums to the blocks this rank has active; blockIdx.y = face (the two messages touch
-// different block layers: slabs are at least 3 blocks wide). One wave per record.
-template <int D> __global__ __launch_bounds__(64) void k_add_halo(Dev d, uint32_t epoch) {
+// The record of (key, pair) in an inbound message, looked up by a whole wave (all 64 lanes call it with the same
+// arguments): record index or NONE. `found[t]` receives the record of every pair t of the block at once.
+template <int D> __device__ inline void find_records(const Dev &d, int face, uint32_t key, int lane, uint32_t *found) {
     using H = HaloCfg<D>;
-    const uint32_t face = blockIdx.y;
+#pragma unroll
+    for (int t = 0; t < H::NTAG; t++) found[t] = NONE;
     const float *msg = d.msg.in[face];
     if (!msg) return;
-    const uint32_t *hdr = reinterpret_cast<const uint32_t *>(msg);
-    const uint32_t n_rec = min(hdr[0], d.msg.halo_cap);
-    if (blockIdx.x == 0 && threadIdx.x == 0 && hdr[1] != 0u && (hdr[2] & MSG_FLAG_UNIFORM) != (d.uniform ? MSG_FLAG_UNIFORM : 0u))
-        atomicOr(&d.counters[CTR_ERRORS], ERRBIT_SHARD);  // the neighbour's particle records are laid out differently (wgs_set_uniform_material on some ranks only)
-    const float4 *in = msg_halo<D>(msg);
-    const int lane = threadIdx.x;
-    for (uint32_t r = blockIdx.x; r < n_rec; r += gridDim.x) {
-        const float4 *rec = in + (size_t)r * H::REC_F4;
-        const float4 hd = rec[0];
-        const uint32_t key = __float_as_uint(hd.x), tag = __float_as_uint(hd.y);
-        if (tag >= (uint32_t)H::NTAG) continue;  // (malformed: ignored)
-        const uint32_t b = hmap_find(d, key, epoch);
-        if (b == NONE) {  // not active here: only an arriving particle can read those nodes (k_g2p_arrivals)
-            if (lane == 0) orphan_insert(d, key, tag, face, r, epoch);
-            continue;
+    const uint32_t n_rec = min(reinterpret_cast<const uint32_t *>(msg)[0], d.msg.halo_cap);
+    const float4 *recs = msg_halo<D>(msg);
+    for (uint32_t base = 0; base < n_rec; base += 64u) {
+        const uint32_t r = base + (uint32_t)lane;
+        bool hit = false;
+        uint32_t tg = 0u;
+        if (r < n_rec) {
+            const float4 hd = recs[(size_t)r * H::REC_F4];
+            hit = __float_as_uint(hd.x) == key;
+            tg = __float_as_uint(hd.y);
         }
-        if (lane < H::NODES) {
-            const size_t node = (size_t)b * NPB + halo_node<D>((int)tag, lane);
-            const float4 a = d.nodes[node], p = rec[1 + lane];
-            d.nodes[node] = make_float4(a.x + p.x, a.y + p.y, a.z + p.z, a.w + p.w);
+#pragma unroll
+        for (int t = 0; t < H::NTAG; t++) {
+            const unsigned long long m = __ballot(hit && tg == (uint32_t)t);
+            if (m != 0ull) found[t] = base + (uint32_t)(__ffsll((long long)m) - 1);
         }
     }
 }

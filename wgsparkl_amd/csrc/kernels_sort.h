@@ -656,8 +656,10 @@ __device__ __forceinline__ void regroup_block(const Dev &d, int side, uint32_t e
         d.block_cdf_flag[id] = 0;      // (block_acc is cleared by the grid update: the waves of this group read it)
     }
     if (listed) append_visits(d, id, bstart, btotal, lane);
-    if (d.sharded && lane == 0 && iface_masks<D>(d, b[0]).gather != 0u)  // interface layers of the slab (k_pack_face)
-        d.halo_list[atomicAdd(&d.counters[CTR_NHALO], 1u)] = id;
+    if (d.sharded && lane == 0) {  // block layers that travel to a neighbour (k_pack_face)
+        const IfaceMasks im = iface_masks<D>(d, b[0]);
+        if ((im.send_lo | im.send_hi) != 0u) d.halo_list[atomicAdd(&d.counters[CTR_NHALO], 1u)] = id;
+    }
     WGS_PROF(6)
     WGS_PROF_END()
 }

@@ -153,8 +153,8 @@ __global__ __launch_bounds__(P2GCfg<D>::NW * 64, WPE) void k_p2g_pair(Dev d, int
 
 // ------------------------------------------------------------ grid update
 // Gather of the slabs covering each node + solver/grid_update.wgsl:55-64.
-// PHASE 0: gather + update in one pass (single GPU). Sharded runs: PHASE 3 = the same single pass, except that the
-// interface node layers come from nodes[] (gathered and exchanged by k_pack_face / k_add_halo, kernels_shard.h).
+// PHASE 0: gather + update in one pass (single GPU). Sharded runs: PHASE 3 = the same single pass, which also adds the
+// neighbours' partial sums of the interface layers, straight from the inbound messages (kernels_shard.h).
 
 // Partial (momentum, mass) sum of one node from the (at most 2^D) slabs that cover it, in the fixed order of the
 // grid update.
@@ -200,13 +200,26 @@ template <int D, int PHASE, bool TWOWAY = false> __global__ __launch_bounds__(25
         l[1] = (ln >> BS) & (BW - 1);
         l[2] = D == 3 ? (ln >> (2 * BS)) : 0;
         float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
-        // PHASE 3 (sharded runs): the x-layer pairs of the interface layers that a neighbour's particles reach were gathered
-        // by k_pack_face and completed with the neighbour's partial sums (k_add_halo): take them from nodes[]
-        bool from_nodes = false;
+        // PHASE 3 (sharded runs): pairs of the interface layers that a neighbour's particles reach get the neighbour's partial
+        // sum added to this rank's own gather (a + b == b + a bitwise: both ranks hold the same total). The wave — one block —
+        // finds the block's records in the inbound message itself (kernels_shard.h find_records)
+        float4 recv = make_float4(0.f, 0.f, 0.f, 0.f);
         if constexpr (PHASE == 3) {
             int bc[3] = {0, 0, 0};
             unpack_key<D>(d.block_key[b], bc);
-            from_nodes = ((iface_masks<D>(d, bc[0]).from_nodes >> (l[0] >> 1)) & 1u) != 0u;
+            const uint32_t rmask = iface_masks<D>(d, bc[0]).recv;  // wave-uniform
+            if (rmask != 0u) {
+                uint32_t found[HaloCfg<D>::NTAG];
+                const int face = iface_recv_face(d, bc[0]);
+                find_records<D>(d, face, d.block_key[b], (int)(threadIdx.x & 63u), found);
+                int tag, q;
+                halo_slot<D>(ln, tag, q);
+                uint32_t mine = NONE;
+#pragma unroll
+                for (int tt = 0; tt < HaloCfg<D>::NTAG; tt++)
+                    if (tt == tag) mine = found[tt];
+                if (((rmask >> tag) & 1u) && mine != NONE) recv = msg_halo<D>(d.msg.in[face])[(size_t)mine * HaloCfg<D>::REC_F4 + 1 + q];
+            }
         }
         float isum[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};  // node impulse (two-way coupling): linear, angular
         uint32_t srcs[NN];
@@ -222,7 +235,7 @@ template <int D, int PHASE, bool TWOWAY = false> __global__ __launch_bounds__(25
             int ti = tt[0] + TW * tt[1] + (D == 3 ? TW * TW * tt[2] : 0);
             srcs[o] = src;
             tis[o] = ti;
-            if (PHASE != 2 && !(PHASE == 3 && from_nodes)) {
+            if (PHASE != 2) {
                 float4 p = d.slab[(size_t)src * TILE + ti];
                 sum.x += p.x; sum.y += p.y; sum.z += p.z; sum.w += p.w;
             }
@@ -259,7 +272,7 @@ template <int D, int PHASE, bool TWOWAY = false> __global__ __launch_bounds__(25
         }
         if constexpr (PHASE == 2) sum = d.nodes[node];
         if constexpr (PHASE == 3) {
-            if (from_nodes) sum = d.nodes[node];
+            sum.x += recv.x; sum.y += recv.y; sum.z += recv.z; sum.w += recv.w;
         }
         float mass = D == 3 ? sum.w : sum.z;
         float inv_mass = mass > 0.f ? 1.0f / mass : 0.f;

@@ -141,7 +141,6 @@ struct Dev {
     uint32_t skip_guests;    // the fused G2P drops the particles whose block lies outside the core range: their new owner
                              // advances them (set by the sharded step; wgs_step on a slab advances everything it holds)
     ShardMsg msg;            // message buffers of the slab
-    unsigned long long *orphans;  // received node pairs whose block is not active here (kernels_shard.h)
     uint32_t npad;       // plane stride (floats)
     float *buf[2];       // ping-pong particle buffers
     uint32_t *perm;      // sorted slot -> index in the current buffer
