@@ -652,6 +652,7 @@ template <bool TS> wgs_status enqueue_substep(wgs_data *d, int ts_slot, int part
         }
     };
     const uint32_t epoch = (uint32_t)(d->substeps + 1);
+    dev.ctr_set = (uint32_t)(d->substeps & 1u);  // sharded runs: the set of particle counters this substep reads (layout.h)
     // chunks of 64 sorted particles per wave of the fused G2P (kernels_transfer.h); the sort files the visit list by it
     // (2D: the body keeps no state of the chunk after the next one — at most two chunks per wave)
     dev.g2p_npass = (D == 3 && dev.nv >= G2P_MANY_PASS_MIN_PARTICLES) ? (uint32_t)G2P_MANY_PASSES
@@ -765,6 +766,11 @@ template <bool TS> wgs_status enqueue_substep(wgs_data *d, int ts_slot, int part
             else hipLaunchKernelGGL((k_grid_update<D, 3>), dim3(grid_for(d, WGS_GU_WG_PER_CU)), dim3(256), 0, s, dev);
         }
         mark(5);
+        // sharded step: the particles that arrived with this substep's messages are advanced too (kernels_arrivals.h), by a
+        // launch of their own behind the fused G2P. (As extra workgroups INSIDE that launch — first or last in its grid — they
+        // made it 7-10 us longer at a 1 M slab for the 5 us launch they saved: measured twice in round 3, not kept.)
+        const bool arrivals = part == 2 && d->in_sharded_step && d->link && d->link->attached;
+        const uint32_t arr_most = arrivals ? ((d->link->has_lower ? 1u : 0u) + (d->link->has_upper ? 1u : 0u)) * d->link->mig_cap : 0u;
         if (dev.nv > 0) {
             // ---- "g2p" + "particles_update", fused
             // one single-wave workgroup per `npass` chunks of 64 sorted particles; multiple of 8: XCD-aware mapping
@@ -822,13 +828,9 @@ template <bool TS> wgs_status enqueue_substep(wgs_data *d, int ts_slot, int part
 #undef WGS_LAUNCH_G2P
         }
         if (!(d->cpic && dev.nv > 0)) mark(6);  // (collider simulations: recorded between the two G2P launches)
-        // ---- sharded step: the particles that arrived with this substep's messages (kernels_arrivals.h); also the
-        // bookkeeping of the migration round, so it runs even when nobody can arrive
-        const bool arrivals = part == 2 && d->in_sharded_step && d->link && d->link->attached;
+        // (the arrivals' body also does the bookkeeping of the migration round, so it runs even when nobody can arrive)
         if (arrivals) {
-            const ShardLink &L = *d->link;
-            const uint32_t most = ((L.has_lower ? 1u : 0u) + (L.has_upper ? 1u : 0u)) * L.mig_cap;
-            const dim3 ag(std::max(1u, std::min((most + ARR_PER_WG - 1u) / ARR_PER_WG, 1024u)));
+            const dim3 ag(std::max(1u, std::min((arr_most + ARR_PER_WG - 1u) / ARR_PER_WG, 1024u)));
             const int asel = (dev.model == WGS_MODEL_NEO_HOOKEAN ? 2 : 0) | (d->plastic ? 1 : 0);
             switch (asel) {
                 case 0: hipLaunchKernelGGL((k_g2p_arrivals<D, 0, false>), ag, dim3(256), 0, s, dev, side, epoch); break;
@@ -836,8 +838,8 @@ template <bool TS> wgs_status enqueue_substep(wgs_data *d, int ts_slot, int part
                 case 2: hipLaunchKernelGGL((k_g2p_arrivals<D, 1, false>), ag, dim3(256), 0, s, dev, side, epoch); break;
                 default: hipLaunchKernelGGL((k_g2p_arrivals<D, 1, true>), ag, dim3(256), 0, s, dev, side, epoch); break;
             }
-            d->tail_slots = most;
         }
+        if (arrivals) d->tail_slots = arr_most;
         mark(7);
         // ---- "integrate_bodies" (rigid_impulses.wgsl:95-136) + the world mass properties of the next substep
         // (pipeline.rs:204-205). Skipped while no body has a velocity or a mass: it would be the identity.
@@ -1081,6 +1083,7 @@ static wgs_status create_impl(wgs_pipeline *pipeline, const wgs_sim_params *para
         // counts live on the device; the host-side n / nv become the launch bound (allocated capacity)
         uint32_t cnt[2] = {n, n};
         H2D(dev.counters + CTR_N, cnt, sizeof(cnt));
+        H2D(dev.counters + CTR_N + CTR_SET, cnt, sizeof(cnt));   // (both sets: layout.h ctr_cur / ctr_next)
         dev.n = dev.nv = (uint32_t)particle_capacity;
     }
     d->host_colliders.resize(WGS_MAX_COLLIDERS);
@@ -1144,6 +1147,7 @@ wgs_status wgs_shard_export(wgs_data *d, void *device_buf, uint32_t capacity_rec
     if (!d || !device_buf || !count) return fail(WGS_ERR_INVALID_ARGUMENT, "NULL argument");
     if (!d->dev.sharded) return fail(WGS_ERR_INVALID_ARGUMENT, "not a sharded wgs_data");
     HIP_TRY(hipSetDevice(d->pipeline->device));
+    d->dev.ctr_set = (uint32_t)(d->substeps & 1u);
     if (d->needs_compact) {
         hipLaunchKernelGGL(k_shard_compacted, dim3(1), dim3(64), 0, d->stream, d->dev);
         d->needs_compact = false;
@@ -1679,7 +1683,8 @@ wgs_status wgs_get_stats(wgs_data *d, wgs_stats *out) {
     if (st != WGS_OK) return st;
     out->num_particles = d->dev.n;
     if (d->dev.sharded) {
-        HIP_TRY(hipMemcpyAsync(&out->num_particles, d->dev.counters + CTR_NV, sizeof(uint32_t), hipMemcpyDeviceToHost, d->stream));
+        HIP_TRY(hipMemcpyAsync(&out->num_particles, d->dev.counters + CTR_NV + CTR_SET * (d->needs_compact ? ((d->substeps & 1) ^ 1) : (d->substeps & 1)),
+                               sizeof(uint32_t), hipMemcpyDeviceToHost, d->stream));
         HIP_TRY(hipStreamSynchronize(d->stream));
     }
     out->num_active_blocks = d->last_nblocks;

@@ -243,8 +243,10 @@ __global__ void k_clear_headers(uint32_t *a, uint32_t *b) {
 // G2P wrote holds exactly the valid particles, in sorted order.
 __global__ void k_shard_compacted(Dev d) {
     if (threadIdx.x == 0 && blockIdx.x == 0) {
-        d.counters[CTR_N] = d.counters[CTR_NV];
-        d.counters[CTR_NPREV] = d.counters[CTR_NV];
+        const uint32_t nv = ctr_next(d, CTR_NV);   // (launched at the head of the NEXT substep: the last one read the other set)
+        ctr_cur(d, CTR_NV) = nv;
+        ctr_cur(d, CTR_N) = nv;
+        ctr_cur(d, CTR_NPREV) = nv;
     }
 }
 

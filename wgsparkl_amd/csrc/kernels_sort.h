@@ -73,7 +73,7 @@ template <int D, int TAIL> __device__ __forceinline__ void bin_body(const Dev &d
     if (bid == 0u && tid < 16) d.counters[(tid < 8 ? (int)CTR_NCPIC : (int)CTR_NVISIT - 256) + 32 * tid] = 0;  // near-collider lists of this substep (k_regroup appends)
     if (bid == 0u && tid == 16) d.counters[CTR_NHALO] = 0;  // interface-block list (sharded runs)
     __syncthreads();
-    const uint32_t first = tail ? d.counters[CTR_NPREV] : 0u;
+    const uint32_t first = tail ? ctr_cur(d, CTR_NPREV) : 0u;
     const uint32_t i = first + bid * SORT_THREADS + tid;
     uint32_t slots_end = num_slots(d);
     bool valid = i < slots_end;
@@ -171,7 +171,7 @@ template <int D> __device__ __forceinline__ void rebin_body(const Dev &d, int si
     if (bid == 0u && tid == 16) d.counters[CTR_NHALO] = 0;  // interface-block list (sharded runs)
     // sharded runs: the residents only (arrivals have no previous cell: k_bin's tail pass), minus the slots
     // vacated by particles that migrated away
-    const bool in_range = i < (d.sharded ? min(d.counters[CTR_NPREV], d.counters[CTR_N]) : num_slots(d));
+    const bool in_range = i < (d.sharded ? min(ctr_cur(d, CTR_NPREV), ctr_cur(d, CTR_N)) : num_slots(d));
     bool valid = in_range;
     if (d.sharded && valid) valid = ldpid<D>(in, d.npad, i) != 0xffffffffu;
     uint32_t myid = NONE, local = 0, old = NONE;

@@ -138,6 +138,7 @@ struct Dev {
     uint32_t sharded;    // 1: x-slab decomposition (kernels_shard.h)
     int shard_lo, shard_hi;  // core block range along x
     uint32_t shard_has_lo, shard_has_hi;  // a neighbour below / above (wgs_shard_attach)
+    uint32_t ctr_set;        // which set of the particle counters this substep reads (substep number & 1; below)
     uint32_t skip_guests;    // the fused G2P drops the particles whose block lies outside the core range: their new owner
                              // advances them (set by the sharded step; wgs_step on a slab advances everything it holds)
     ShardMsg msg;            // message buffers of the slab
@@ -218,8 +219,15 @@ struct Dev {
                          // result-changing ablations only exist in builds with -DWGS_ABLATE (never the shipped library)
 };
 
-__device__ inline uint32_t num_slots(const Dev &d) { return d.sharded ? d.counters[CTR_N] : d.n; }
-__device__ inline uint32_t num_valid(const Dev &d) { return d.sharded ? d.counters[CTR_NV] : d.nv; }
+// Sharded runs keep TWO sets of the three particle counters (CTR_N, CTR_NV, CTR_NPREV; the second set CTR_SET slots
+// further): the kernels of substep n read set n & 1 (Dev::ctr_set), and the bookkeeping of the migration round — done by
+// the arrivals' workgroups INSIDE the fused G2P launch, while other waves of that launch still read the current counts —
+// writes the set of substep n + 1.
+constexpr uint32_t CTR_SET = 16;
+__device__ inline uint32_t &ctr_cur(const Dev &d, uint32_t which) { return d.counters[which + CTR_SET * d.ctr_set]; }
+__device__ inline uint32_t &ctr_next(const Dev &d, uint32_t which) { return d.counters[which + CTR_SET * (d.ctr_set ^ 1u)]; }
+__device__ inline uint32_t num_slots(const Dev &d) { return d.sharded ? ctr_cur(d, CTR_N) : d.n; }
+__device__ inline uint32_t num_valid(const Dev &d) { return d.sharded ? ctr_cur(d, CTR_NV) : d.nv; }
 // Chunks of 64 sorted particles per XCD eighth of the fused G2P: waves advance `npass` consecutive chunks, an XCD gets
 // `per_xcd` consecutive waves' worth (g2p_body.inc; the sort files the visit list by the same rule).
 __device__ inline uint32_t g2p_waves_per_xcd(const Dev &d, uint32_t npass) {
