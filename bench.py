@@ -17,7 +17,7 @@ anything is timed the decomposition validates itself against a single-domain run
 mismatch). --scaling weak (default): N
 copies of the config side by side along x (fixed work per GPU); strong: the named size cut into N slabs (north_star's
 16M target: --config c5 --scaling strong). Without flags, the line also carries `extra` legs: the same cube after it
-landed on the floor, c3, and c5 (strong over the N GPUs), each with its own G2P roofline figure.
+landed on the floor, c3, the reference's own sand3 scene (202 k particles) and c5 (strong over the N GPUs), each with its own G2P roofline figure.
 `python bench.py --gpus N` outside a launcher starts the N ranks itself (torch.distributed.run as a child process).
 """
 import argparse
@@ -373,6 +373,9 @@ def main():
                                       "the C2 cube after it landed: lowered onto the floor with a -3 cells/s impact, 200 substeps before the timed region")
             sc = scenes.config_scene("c3")
             extra["c3"] = slim(measure(env, sc, 1, 0, k, w, "k_g2p_pair<plastic>"), sc["name"])
+            # the size the reference itself ships (its scenes hold 75 k - 490 k particles): latency-bound here, five dependent launches
+            sc = scenes.reference_sand3()
+            extra["sand3_202k"] = slim(measure(env, sc, 1, 0, k, w, "k_g2p_pair<plastic>", settle=100), sc["name"] + ", 100 substeps before the timed region")
             del sc
         sc = scenes.config_scene("c5", world, rank if sharded_path else None, "strong")
         r = measure(env, sc, world, rank, k, w, KERNEL_ELASTIC)

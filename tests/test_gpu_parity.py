@@ -173,6 +173,24 @@ def test_c1_configs0_as_written(hip_libs, oracle_libs, landed):
         assert np.abs(got.def_grad - np.eye(2, dtype=np.float32).reshape(-1)).max() > 1e-3, "the block must deform"
 
 
+def test_reference_sand3_scene_as_shipped(hip_libs, oracle_libs):
+    """The reference's own shipping scene (crates/wgsparkl3d/examples/sand3.rs:28-113) at its full size — 202 500
+    Drucker-Prager particles, floor, four walls, the tilted kinematic cuboid spinning under the column — 6 substeps against
+    the fp64 oracle: blocks and node bits exact, fields to the collider-scene tolerances, the body pose too."""
+    sc = scenes.reference_sand3()
+    assert sc["particles"].n == 202_500
+    k = 6
+    data = run_gpu(sc, k)
+    st32 = run_oracle(sc, k, np.float32)
+    st64 = run_oracle(sc, k, np.float64)
+    check_blocks(data, st32)
+    got, same = compare_cpic(data, st32, st64, 3, CPIC_GRID_V_TOL, 1e-4, min_same=0.998, fields=("pos", "vel", "def_grad"))
+    assert (got.cdf_affinity != 0).sum() > 100, "the spinning cuboid must be felt"
+    pose = data.read_body_poses()[5]
+    want = st64.collider_states()[5]
+    assert np.allclose(pose["rotation"], want["rotation"], atol=1e-6) and np.allclose(pose["translation"], want["translation"], atol=1e-6)
+
+
 def test_empty_and_single(hip_libs, oracle_libs):
     sc = cloud_scene(n=1)
     data = run_gpu(sc, 2)

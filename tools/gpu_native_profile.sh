@@ -2,7 +2,7 @@
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 export HSA_ENABLE_IPC_MODE_LEGACY=0
 rm -rf gpurun_out/nprof; mkdir -p gpurun_out/nprof
-timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/nprof -- python3 tools/gpu_native_host_cost.py > gpurun_out/nprof/log 2>&1
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/nprof -- python3 tools/gpu_native_host_cost.py ${CFG:-c2} > gpurun_out/nprof/log 2>&1
 grep "substeps" gpurun_out/nprof/log
 f=$(find gpurun_out/nprof -name "*kernel_stats.csv" | head -1); python3 - "$f" <<'PY'
 import csv,sys

@@ -6,3 +6,4 @@ timeout 600 python bench.py --no-extra --no-cpu-baseline 2>/dev/null | python -c
 import json,sys
 d=json.loads(sys.stdin.read()); print('bench', d['value'], d['ms_per_step'], d['roofline']['frac'], d['pass_ms_per_step'])"
 bash tools/gpu_native_profile.sh 2>&1 | tail -22
+timeout 400 python tools/gpu_native_host_cost.py c5 2>&1 | grep substeps

@@ -96,7 +96,6 @@ struct wgs_data {
     bool plastic = false;
     bool cpic = false;
     bool prev_sorted = false;   // the current buffer is the sorted output of the previous substep (perm_cell, links valid)
-    uint32_t tail_slots = 0;    // sharded: upper bound of the arrivals k_g2p_arrivals wrote behind the residents in the last substep
     bool needs_compact = false; // sharded: the last substep ran without its neighbours (wgs_step): the counters of its buffer are still to be set
     bool in_sharded_step = false;  // the substep being enqueued belongs to wgs_sharded_step[_lockstep]: guests are dropped, arrivals advanced
     uint64_t substeps = 0;
@@ -204,7 +203,7 @@ wgs_status alloc_grid(wgs_data *d) {
     GRID_ALLOC(&dev.cpic_list, (size_t)cap * 8);
     dev.visit_cap = dev.npad / 512u + 2u * cap + 16u;
     GRID_ALLOC(&dev.visit_list, (size_t)dev.visit_cap * 8);
-    if (dev.sharded) GRID_ALLOC(&dev.halo_list, (size_t)cap);
+    if (dev.sharded) GRID_ALLOC(&dev.halo_list, (size_t)cap * HALO_ENT);
     if (d->two_way) GRID_ALLOC(&dev.imp_slab, cap * Dim<D>::TILE * (D == 3 ? 2 : 1));
     if (dev.mesh_min) {
         GRID_ALLOC(&dev.mesh_min, cap * NPB);
@@ -671,7 +670,6 @@ template <bool TS> wgs_status enqueue_substep(wgs_data *d, int ts_slot, int part
     if (dev.sharded && d->needs_compact && part != 2) {
         hipLaunchKernelGGL(k_shard_compacted, dim3(1), dim3(64), 0, s, dev);
         d->needs_compact = false;
-        d->tail_slots = 0;
     }
     if (part != 2) {
         if (TS) {  // two adjacent marks: their distance is what every interval below pays for its closing mark
@@ -689,15 +687,9 @@ template <bool TS> wgs_status enqueue_substep(wgs_data *d, int ts_slot, int part
         if (dev.n_rigid > 0)
             hipLaunchKernelGGL(k_rigid_transform<D>, dim3(grid_for(d, 1)), dim3(256), 0, s, dev);
         if (n > 0) {
-            if (use_rebin) {
-                // sharded runs: the particles that arrived in the last substep lie behind the residents and have no previous
-                // cell: binned by the general form, in the same launch (k_rebin_tail)
-                const uint32_t tg = dev.sharded ? (d->tail_slots + SORT_THREADS - 1) / SORT_THREADS : 0u;
-                if (tg > 0u) hipLaunchKernelGGL((k_rebin_tail<D>), dim3((uint32_t)pgrid + tg), dim3(SORT_THREADS), 0, s, dev, side, epoch, (uint32_t)pgrid);
-                else hipLaunchKernelGGL(k_rebin<D>, dim3(pgrid), dim3(SORT_THREADS), 0, s, dev, side, epoch);
-            } else {
-                hipLaunchKernelGGL((k_bin<D, 0>), dim3(pgrid), dim3(SORT_THREADS), 0, s, dev, side, epoch);
-            }
+            // (sharded runs: k_rebin also bins the particles that arrived in the last substep, behind the residents)
+            if (use_rebin) hipLaunchKernelGGL(k_rebin<D>, dim3(pgrid), dim3(SORT_THREADS), 0, s, dev, side, epoch);
+            else hipLaunchKernelGGL(k_bin<D>, dim3(pgrid), dim3(SORT_THREADS), 0, s, dev, side, epoch);
             if (dev.n_rigid > 0) {  // blocks a mesh sample reaches must exist (sort.wgsl:38-86)
                 hipLaunchKernelGGL(k_rigid_mark<D>, dim3(grid_for(d, 1)), dim3(256), 0, s, dev, epoch);
                 hipLaunchKernelGGL(k_rigid_touch<D>, dim3(grid_for(d, 1)), dim3(256), 0, s, dev, epoch);
@@ -760,10 +752,10 @@ template <bool TS> wgs_status enqueue_substep(wgs_data *d, int ts_slot, int part
         if (n > 0) {
             // ---- "grid_update"
             if (part == 0 && d->two_way)
-                hipLaunchKernelGGL((k_grid_update<D, 0, true>), dim3(grid_for(d, WGS_GU_WG_PER_CU)), dim3(256), 0, s, dev);
-            else if (part == 0) hipLaunchKernelGGL((k_grid_update<D, 0>), dim3(grid_for(d, WGS_GU_WG_PER_CU)), dim3(256), 0, s, dev);
-            else if (d->two_way) hipLaunchKernelGGL((k_grid_update<D, 3, true>), dim3(grid_for(d, WGS_GU_WG_PER_CU)), dim3(256), 0, s, dev);
-            else hipLaunchKernelGGL((k_grid_update<D, 3>), dim3(grid_for(d, WGS_GU_WG_PER_CU)), dim3(256), 0, s, dev);
+                hipLaunchKernelGGL((k_grid_update<D, 0, true>), dim3(grid_for(d, WGS_GU_WG_PER_CU)), dim3(256), 0, s, dev, epoch);
+            else if (part == 0) hipLaunchKernelGGL((k_grid_update<D, 0>), dim3(grid_for(d, WGS_GU_WG_PER_CU)), dim3(256), 0, s, dev, epoch);
+            else if (d->two_way) hipLaunchKernelGGL((k_grid_update<D, 3, true>), dim3(grid_for(d, WGS_GU_WG_PER_CU)), dim3(256), 0, s, dev, epoch);
+            else hipLaunchKernelGGL((k_grid_update<D, 3>), dim3(grid_for(d, WGS_GU_WG_PER_CU)), dim3(256), 0, s, dev, epoch);
         }
         mark(5);
         // sharded step: the particles that arrived with this substep's messages are advanced too (kernels_arrivals.h), by a
@@ -839,7 +831,6 @@ template <bool TS> wgs_status enqueue_substep(wgs_data *d, int ts_slot, int part
                 default: hipLaunchKernelGGL((k_g2p_arrivals<D, 1, true>), ag, dim3(256), 0, s, dev, side, epoch); break;
             }
         }
-        if (arrivals) d->tail_slots = arr_most;
         mark(7);
         // ---- "integrate_bodies" (rigid_impulses.wgsl:95-136) + the world mass properties of the next substep
         // (pipeline.rs:204-205). Skipped while no body has a velocity or a mass: it would be the identity.
@@ -1151,7 +1142,6 @@ wgs_status wgs_shard_export(wgs_data *d, void *device_buf, uint32_t capacity_rec
     if (d->needs_compact) {
         hipLaunchKernelGGL(k_shard_compacted, dim3(1), dim3(64), 0, d->stream, d->dev);
         d->needs_compact = false;
-        d->tail_slots = 0;
     }
     hipLaunchKernelGGL(k_clear_headers, dim3(1), dim3(64), 0, d->stream, static_cast<uint32_t *>(device_buf), (uint32_t *)nullptr);
     hipLaunchKernelGGL(k_export_records<D>, dim3(grid_for(d, 4)), dim3(256), 0, d->stream, d->dev, d->side, static_cast<float *>(device_buf), capacity_records);

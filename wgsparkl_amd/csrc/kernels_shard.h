@@ -84,7 +84,8 @@ __device__ inline int iface_recv_face(const Dev &d, int bx) { return (d.shard_ha
 // Full-state record of one particle: NQ quads + pid + cdf epoch.
 template <int D> constexpr int particle_record_floats() { return Pl<D>::NQ * 4 + 2; }
 
-// One message = header (4 words: halo records, particle records, flags, -) + halo_cap halo records + mig_cap particle records.
+// One message = header (4 words: -, particle records, flags, -) + halo_cap halo record slots (a hash table, below)
+// + mig_cap particle records.
 constexpr uint32_t MSG_FLAG_UNIFORM = 1u;   // particle records are in the uniform-material layout (layout.h)
 template <int D> __host__ __device__ inline size_t msg_floats(uint32_t halo_cap, uint32_t mig_cap) {
     return 4 + (size_t)halo_cap * HaloCfg<D>::REC_F4 * 4 + (size_t)mig_cap * particle_record_floats<D>();
@@ -104,23 +105,44 @@ template <int D> __device__ inline float4 gather_slabs(const Dev &d, uint32_t b,
 // slabs and appended to the outgoing messages; (b) the guests — the particles the last
 // G2P launch found outside the core range (Dev::leavers) — are copied into the message of the face they crossed. They
 // are NOT vacated here: this rank's fused G2P drops them (their block lies outside the core range).
-template <int D> __global__ __launch_bounds__(64) void k_pack_face(Dev d, int side, uint32_t nblk_wgs) {
+template <int D> __global__ __launch_bounds__(64) void k_pack_face(Dev d, int side, uint32_t epoch, uint32_t nblk_wgs) {
     using H = HaloCfg<D>;
-    constexpr int BS = Dim<D>::BSHIFT, NQ = Pl<D>::NQ, RF = particle_record_floats<D>();
+    constexpr int BW = Dim<D>::BW, BS = Dim<D>::BSHIFT, TW = Dim<D>::TW, TILE = Dim<D>::TILE, NN = Dim<D>::NNBR;
+    constexpr int NQ = Pl<D>::NQ, RF = particle_record_floats<D>();
     const int lane = threadIdx.x;
     if (blockIdx.x == 0 && lane < 2 && d.msg.out[lane])   // layout of this rank's particle records (checked by the receiver, k_g2p_arrivals)
         reinterpret_cast<uint32_t *>(d.msg.out[lane])[2] = d.uniform ? MSG_FLAG_UNIFORM : 0u;
     if (blockIdx.x < nblk_wgs) {
         const uint32_t nl = min(d.counters[CTR_NHALO], d.cap);
         for (uint32_t a = blockIdx.x; a < nl; a += nblk_wgs) {
-            const uint32_t b = d.halo_list[a];
+            // the sort left everything needed in the list entry: block id, key and the slabs its nodes are gathered from
+            // (its "-" neighbours that hold particles)
+            uint32_t ew = NONE;
+            if (lane < 10) ew = d.halo_list[(size_t)a * HALO_ENT + (uint32_t)lane];
+            const uint32_t bkey = __shfl(ew, 1);
+            const uint32_t src = __shfl(ew, 2 + (lane & 7));   // lanes 0 .. 7 (and their images): source slab o = lane & 7
             int bc[3] = {0, 0, 0};
-            unpack_key<D>(d.block_key[b], bc);
+            unpack_key<D>(bkey, bc);
             const IfaceMasks m = iface_masks<D>(d, bc[0]);
             int tag, q;
             halo_slot<D>((uint32_t)lane, tag, q);   // lane = node of the block
+            // all slab loads of the node issued together, summed in the fixed order of the grid update (gather_slabs)
+            const int l[3] = {lane & (BW - 1), (lane >> BS) & (BW - 1), D == 3 ? (lane >> (2 * BS)) : 0};
+            float4 part[NN];
+#pragma unroll
+            for (int o = 0; o < NN; o++) {
+                const int tt[3] = {l[0] + BW * (o & 1), l[1] + BW * ((o >> 1) & 1), l[2] + BW * ((o >> 2) & 1)};
+                const bool in_tile = tt[0] < TW && tt[1] < TW && (D == 2 || tt[2] < TW);
+                const uint32_t so = __shfl(src, o);
+                part[o] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (in_tile && so != NONE && (((m.send_lo | m.send_hi) >> tag) & 1u))
+                    part[o] = d.slab[(size_t)so * TILE + tt[0] + TW * tt[1] + (D == 3 ? TW * TW * tt[2] : 0)];
+            }
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (((m.send_lo | m.send_hi) >> tag) & 1u) v = gather_slabs<D>(d, b, (uint32_t)lane);
+#pragma unroll
+            for (int o = 0; o < NN; o++) {  // (a slab that is skipped adds nothing in gather_slabs either: + 0 changes no bit of a sum that started at + 0)
+                v.x += part[o].x; v.y += part[o].y; v.z += part[o].z; v.w += part[o].w;
+            }
             const bool nz = v.x != 0.f || v.y != 0.f || v.z != 0.f || v.w != 0.f;
 #pragma unroll
             for (int f = 0; f < 2; f++) {
@@ -133,15 +155,9 @@ template <int D> __global__ __launch_bounds__(64) void k_pack_face(Dev d, int si
                     const bool regular = t == 0 && bc[0] == (f == 0 ? d.shard_lo : d.shard_hi);
                     const bool any = __ballot(tag == t && nz) != 0ull;
                     if (!regular && !any) continue;
-                    uint32_t slot = 0;
-                    if (lane == 0) slot = atomicAdd(reinterpret_cast<uint32_t *>(msg), 1u);
-                    slot = __shfl(slot, 0);
-                    if (slot >= d.msg.halo_cap) {
-                        if (lane == 0) atomicOr(&d.counters[CTR_ERRORS], ERRBIT_SHARD);
-                        continue;
-                    }
+                    const uint32_t slot = rec_claim<D>(d, msg, bkey, (uint32_t)t, epoch, lane);   // (no record counter: a thousand adds on one address serialise)
+                    if (slot == NONE) continue;
                     float4 *rec = msg_halo<D>(msg) + (size_t)slot * H::REC_F4;
-                    if (lane == 0) rec[0] = make_float4(__uint_as_float(d.block_key[b]), __uint_as_float((uint32_t)t), 0.f, 0.f);
                     if (tag == t) rec[1 + q] = v;
                 }
             }
@@ -153,21 +169,36 @@ template <int D> __global__ __launch_bounds__(64) void k_pack_face(Dev d, int si
     const uint32_t npad = d.npad;
     const uint32_t n = num_slots(d);
     const uint32_t nl = min(d.counters[CTR_NLEAVE], d.leavers_cap);
-    for (uint32_t t = (blockIdx.x - nblk_wgs) * 64u + (uint32_t)lane; t < nl; t += (gridDim.x - nblk_wgs) * 64u) {
-        const uint32_t i = d.leavers[t];
-        if (i >= n) continue;
-        const uint32_t pid = ldpid<D>(buf, npad, i);
-        if (pid == PID_DEAD) continue;
-        const float4 xm = ldq(buf, npad, Pl<D>::XM, i);
-        const int bx = assoc_cell(xm.x, d.h, d.inv_h, d.h_pow2 != 0u) >> BS;
-        const int face = bx < d.shard_lo ? 0 : (bx >= d.shard_hi ? 1 : -1);
+    const uint32_t nl64 = (nl + 63u) & ~63u;   // (whole waves: the slots of a wave's guests are handed out with one atomic per face)
+    for (uint32_t t = (blockIdx.x - nblk_wgs) * 64u + (uint32_t)lane; t < nl64; t += (gridDim.x - nblk_wgs) * 64u) {
+        int face = -1;
+        uint32_t i = 0, pid = PID_DEAD;
+        if (t < nl) {
+            i = d.leavers[t];
+            if (i < n) pid = ldpid<D>(buf, npad, i);
+            if (pid != PID_DEAD) {
+                const float4 xm = ldq(buf, npad, Pl<D>::XM, i);
+                const int bx = assoc_cell(xm.x, d.h, d.inv_h, d.h_pow2 != 0u) >> BS;
+                face = bx < d.shard_lo ? 0 : (bx >= d.shard_hi ? 1 : -1);
+            }
+        }
+        uint32_t slot = NONE;
+#pragma unroll
+        for (int f = 0; f < 2; f++) {
+            const unsigned long long mine = __ballot(face == f);
+            if (mine == 0ull) continue;
+            float *msgf = d.msg.out[f];
+            uint32_t base = 0;
+            if (msgf && lane == __ffsll((long long)mine) - 1) base = atomicAdd(reinterpret_cast<uint32_t *>(msgf) + 1, (uint32_t)__popcll(mine));
+            base = __shfl(base, __ffsll((long long)mine) - 1);
+            if (face == f) slot = msgf ? base + (uint32_t)__popcll(mine & ((1ull << lane) - 1ull)) : NONE;
+        }
         if (face < 0) continue;
         float *msg = d.msg.out[face];
         if (!msg) {  // no neighbour on that side: the caller's decomposition does not cover the scene
             atomicOr(&d.counters[CTR_ERRORS], ERRBIT_SHARD);
             continue;
         }
-        const uint32_t slot = atomicAdd(reinterpret_cast<uint32_t *>(msg) + 1, 1u);  // a handful of particles per substep
         if (slot >= d.msg.mig_cap) {
             atomicOr(&d.counters[CTR_ERRORS], ERRBIT_SHARD);  // the particle is lost to the neighbour: wrong physics, reported
             continue;
@@ -183,31 +214,80 @@ template <int D> __global__ __launch_bounds__(64) void k_pack_face(Dev d, int si
     }
 }
 
-// The record of (key, pair) in an inbound message, looked up by a whole wave (all 64 lanes call it with the same
-// arguments): record index or NONE. `found[t]` receives the record of every pair t of the block at once.
-template <int D> __device__ inline void find_records(const Dev &d, int face, uint32_t key, int lane, uint32_t *found) {
-    using H = HaloCfg<D>;
-#pragma unroll
-    for (int t = 0; t < H::NTAG; t++) found[t] = NONE;
-    const float *msg = d.msg.in[face];
-    if (!msg) return;
-    const uint32_t n_rec = min(reinterpret_cast<const uint32_t *>(msg)[0], d.msg.halo_cap);
-    const float4 *recs = msg_halo<D>(msg);
-    for (uint32_t base = 0; base < n_rec; base += 64u) {
-        const uint32_t r = base + (uint32_t)lane;
-        bool hit = false;
-        uint32_t tg = 0u;
-        if (r < n_rec) {
-            const float4 hd = recs[(size_t)r * H::REC_F4];
-            hit = __float_as_uint(hd.x) == key;
-            tg = __float_as_uint(hd.y);
-        }
-#pragma unroll
-        for (int t = 0; t < H::NTAG; t++) {
-            const unsigned long long m = __ballot(hit && tg == (uint32_t)t);
-            if (m != 0ull) found[t] = base + (uint32_t)(__ffsll((long long)m) - 1);
+// The halo area of a message is an OPEN-ADDRESSING TABLE of records keyed by (block key, pair): the sender claims the slot
+// hash(key, pair) (linear probing, one 64-bit compare-and-swap on the record's header), the receiver finds a block's pair
+// in one or two probes instead of scanning a thousand headers. A header = (key, substep << 4 | pair): slots of earlier
+// substeps read as free (substep numbers only grow, and both ranks count the same substeps), so nothing is ever cleared.
+__device__ inline uint32_t rec_hash(uint32_t key, uint32_t tag, uint32_t cap) { return hash_key(key ^ (tag * 0x9e3779b9u)) % cap; }
+__device__ inline unsigned long long rec_header(uint32_t key, uint32_t tag, uint32_t epoch) {
+    return (unsigned long long)key | ((unsigned long long)((epoch << 4) | tag) << 32);
+}
+// sender, a whole wave (same arguments in all lanes): slot claimed for (key, pair) in `msg`, or NONE (table full:
+// reported). The 64 lanes look at 64 consecutive slots of the probe sequence at once — a few records of a face sit at the
+// end of probe chains 20 slots long, and walked one slot per round trip they alone made this launch twice as long —
+// and the first free one is claimed with one compare-and-swap.
+template <int D> __device__ inline uint32_t rec_claim(const Dev &d, float *msg, uint32_t key, uint32_t tag, uint32_t epoch, int lane) {
+    const uint32_t cap = d.msg.halo_cap;
+    const unsigned long long want = rec_header(key, tag, epoch);
+    const uint32_t h = rec_hash(key, tag, cap);
+    auto header = [&](uint32_t slot) { return reinterpret_cast<unsigned long long *>(msg_halo<D>(msg) + (size_t)slot * HaloCfg<D>::REC_F4); };
+    {   // steady state: this very record held its first slot one substep ago — one atomic, no look before
+        int ok = 0;
+        if (lane == 0) ok = atomicCAS(header(h), rec_header(key, tag, epoch - 1u), want) == rec_header(key, tag, epoch - 1u) ? 1 : 0;
+        if (__shfl(ok, 0)) return h;
+    }
+    for (uint32_t base = 0; base < cap; base += 64u) {
+        const uint32_t off = base + (uint32_t)lane;
+        const uint32_t slot = (h + off) % cap;
+        unsigned long long cur = want;  // (lanes past the end of the table: "taken")
+        if (off < cap) cur = __hip_atomic_load(header(slot), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        unsigned long long free = __ballot(off < cap && (uint32_t)(cur >> 36) != (epoch & 0x0fffffffu));
+        while (free != 0ull) {  // first free slot in probe order; lost to another wave: the next one
+            const int first = __ffsll((long long)free) - 1;
+            int ok = 0;
+            if (lane == first) ok = atomicCAS(header(slot), cur, want) == cur ? 1 : 0;
+            if (__shfl(ok, first)) return __shfl(slot, first);
+            free &= free - 1ull;
         }
     }
+    if (lane == 0) atomicOr(&d.counters[CTR_ERRORS], ERRBIT_SHARD);
+    return NONE;
+}
+// receiver, a whole wave (same arguments in all lanes): the slot of (key, pair) in the inbound message of `face`, or NONE
+template <int D> __device__ inline uint32_t rec_find_wave(const Dev &d, int face, uint32_t key, uint32_t tag, uint32_t epoch, int lane) {
+    const float *msg = d.msg.in[face];
+    if (!msg) return NONE;
+    const uint32_t cap = d.msg.halo_cap;
+    const unsigned long long want = rec_header(key, tag, epoch);
+    const uint32_t h = rec_hash(key, tag, cap);
+    for (uint32_t base = 0; base < cap; base += 64u) {
+        const uint32_t off = base + (uint32_t)lane;
+        const uint32_t slot = (h + off) % cap;
+        unsigned long long cur = 0ull;
+        if (off < cap) cur = *reinterpret_cast<const unsigned long long *>(msg_halo<D>(msg) + (size_t)slot * HaloCfg<D>::REC_F4);
+        const unsigned long long hit = __ballot(off < cap && cur == want);
+        const unsigned long long free = __ballot(off < cap && (uint32_t)(cur >> 36) != (epoch & 0x0fffffffu));
+        // a free slot ends the probe sequence: a record behind it is not this substep's
+        if (hit != 0ull && (free == 0ull || __ffsll((long long)hit) < __ffsll((long long)free))) return __shfl(slot, __ffsll((long long)hit) - 1);
+        if (free != 0ull) return NONE;
+    }
+    return NONE;
+}
+// receiver, one lane: the record of (key, pair) in the inbound message of `face`, or null
+template <int D> __device__ inline const float4 *rec_find(const Dev &d, int face, uint32_t key, uint32_t tag, uint32_t epoch) {
+    const float *msg = d.msg.in[face];
+    if (!msg) return nullptr;
+    const uint32_t cap = d.msg.halo_cap;
+    const unsigned long long want = rec_header(key, tag, epoch);
+    uint32_t slot = rec_hash(key, tag, cap);
+    for (uint32_t probe = 0; probe < cap; probe++) {
+        const float4 *rec = msg_halo<D>(msg) + (size_t)slot * HaloCfg<D>::REC_F4;
+        const unsigned long long cur = *reinterpret_cast<const unsigned long long *>(rec);
+        if (cur == want) return rec;
+        if ((uint32_t)(cur >> 36) != (epoch & 0x0fffffffu)) return nullptr;  // a free slot ends the probe sequence
+        slot = slot + 1u == cap ? 0u : slot + 1u;
+    }
+    return nullptr;
 }
 
 // Read-back of a slab: full records of every live particle (guests included: they are this rank's until sent).

@@ -58,13 +58,8 @@ __device__ inline void count_blocks(const Dev &d, int lane, uint32_t myid) {
 }
 
 // sort.wgsl:26-36 touch_particle_blocks + sort.wgsl:89-99 update_block_particle_count, fused: the general form of
-// launch 1 (first substep, table-rebuild substeps, particles that arrived from a neighbouring rank). Every particle
-// it bins is a mover (it has no previous cell).
-// `tail` = 1: sharded steady state — only the particles that arrived from the neighbours, slots [NPREV, N), which
-// k_g2p_arrivals wrote behind the residents; the residents go through k_rebin.
-// (body as a function of the workgroup index `bid`: k_bin runs it alone, k_rebin_tail behind the re-binning workgroups)
-template <int D, int TAIL> __device__ __forceinline__ void bin_body(const Dev &d, int side, uint32_t epoch, uint32_t bid) {
-    constexpr int tail = TAIL;  // 0 = every slot, 1 = the arrivals behind the residents
+// launch 1 (first substep, table-rebuild substeps). Every particle it bins is a mover (it has no previous cell).
+template <int D> __device__ __forceinline__ void bin_body(const Dev &d, int side, uint32_t epoch, uint32_t bid) {
     constexpr int BS = Dim<D>::BSHIFT, BW = Dim<D>::BW, NN = Dim<D>::NNBR;
     __shared__ uint32_t s_keys[TOUCH_SET], s_ids[TOUCH_SET];
     const float *in = d.buf[side];
@@ -73,8 +68,7 @@ template <int D, int TAIL> __device__ __forceinline__ void bin_body(const Dev &d
     if (bid == 0u && tid < 16) d.counters[(tid < 8 ? (int)CTR_NCPIC : (int)CTR_NVISIT - 256) + 32 * tid] = 0;  // near-collider lists of this substep (k_regroup appends)
     if (bid == 0u && tid == 16) d.counters[CTR_NHALO] = 0;  // interface-block list (sharded runs)
     __syncthreads();
-    const uint32_t first = tail ? ctr_cur(d, CTR_NPREV) : 0u;
-    const uint32_t i = first + bid * SORT_THREADS + tid;
+    const uint32_t i = bid * SORT_THREADS + tid;
     uint32_t slots_end = num_slots(d);
     bool valid = i < slots_end;
     if (d.sharded && valid) valid = ldpid<D>(in, d.npad, i) != 0xffffffffu;  // slot vacated by a migrated particle
@@ -152,8 +146,8 @@ template <int D, int TAIL> __device__ __forceinline__ void bin_body(const Dev &d
         if (cid != NONE) push_mover(d, cid, i);
     }
 }
-template <int D, int TAIL> __global__ __launch_bounds__(SORT_THREADS) void k_bin(Dev d, int side, uint32_t epoch) {
-    bin_body<D, TAIL>(d, side, epoch, blockIdx.x);
+template <int D> __global__ __launch_bounds__(SORT_THREADS) void k_bin(Dev d, int side, uint32_t epoch) {
+    bin_body<D>(d, side, epoch, blockIdx.x);
 }
 
 // Steady-state launch 1 (sort.wgsl:26-36,89-99 for a buffer that is the sorted output of the previous
@@ -169,14 +163,15 @@ template <int D> __device__ __forceinline__ void rebin_body(const Dev &d, int si
     const uint32_t i = bid * SORT_THREADS + tid;
     if (bid == 0u && tid < 16) d.counters[(tid < 8 ? (int)CTR_NCPIC : (int)CTR_NVISIT - 256) + 32 * tid] = 0;  // near-collider lists of this substep (k_regroup appends)
     if (bid == 0u && tid == 16) d.counters[CTR_NHALO] = 0;  // interface-block list (sharded runs)
-    // sharded runs: the residents only (arrivals have no previous cell: k_bin's tail pass), minus the slots
-    // vacated by particles that migrated away
-    const bool in_range = i < (d.sharded ? min(ctr_cur(d, CTR_NPREV), ctr_cur(d, CTR_N)) : num_slots(d));
+    // sharded runs: the residents minus the slots vacated by particles that now live on a neighbour, and behind them,
+    // in [NPREV, N), the particles that arrived in the last substep (kernels_arrivals.h): they have no previous cell and
+    // take the hash path below like a particle that changed block
+    const bool in_range = i < num_slots(d);
     bool valid = in_range;
     if (d.sharded && valid) valid = ldpid<D>(in, d.npad, i) != 0xffffffffu;
     uint32_t myid = NONE, local = 0, old = NONE;
     if (valid) {
-        old = d.perm_cell[i];  // NONE only after a grid overflow: take the hash path then
+        if (!d.sharded || i < ctr_cur(d, CTR_NPREV)) old = d.perm_cell[i];  // NONE only after a grid overflow: take the hash path then
         if (old != NONE) old &= ~CELL_LISTED;
         const uint32_t ob = old >> 6;
         const uint32_t okey = old != NONE ? d.block_key[ob] : 0u;
@@ -231,14 +226,6 @@ template <int D> __device__ __forceinline__ void rebin_body(const Dev &d, int si
 template <int D> __global__ __launch_bounds__(SORT_THREADS) void k_rebin(Dev d, int side, uint32_t epoch) {
     rebin_body<D>(d, side, epoch, blockIdx.x);
 }
-// Sharded steady state: the residents re-binned (first `nrebin` workgroups) and the particles that arrived from the
-// neighbours binned (the others) in ONE launch — a dependent launch costs ~4.5 us whatever it does, and the two touch
-// different slots (shared state only through atomics).
-template <int D> __global__ __launch_bounds__(SORT_THREADS) void k_rebin_tail(Dev d, int side, uint32_t epoch, uint32_t nrebin) {
-    if (blockIdx.x < nrebin) rebin_body<D>(d, side, epoch, blockIdx.x);
-    else bin_body<D, 1>(d, side, epoch, blockIdx.x - nrebin);
-}
-
 // ---------------------------------------------------------------------------------------------------------------
 // Launch 2. Chunked scan of the known blocks (physical ids): chunk k = ids [k * SCAN_CHUNK, (k + 1) * SCAN_CHUNK).
 //   active[a] = id of the a-th block stamped with the current epoch   (grid.wgsl:323-334's active_blocks list,
@@ -656,9 +643,19 @@ __device__ __forceinline__ void regroup_block(const Dev &d, int side, uint32_t e
         d.block_cdf_flag[id] = 0;      // (block_acc is cleared by the grid update: the waves of this group read it)
     }
     if (listed) append_visits(d, id, bstart, btotal, lane);
-    if (d.sharded && lane == 0) {  // block layers that travel to a neighbour (k_pack_face)
+    if (d.sharded) {  // block layers that travel to a neighbour: an entry k_pack_face can work from without another look-up —
+        // [id, key, the 2^D slabs the block's nodes are gathered from (its "-" neighbours that hold particles: lanes 8..15)]
         const IfaceMasks im = iface_masks<D>(d, b[0]);
-        if ((im.send_lo | im.send_hi) != 0u) d.halo_list[atomicAdd(&d.counters[CTR_NHALO], 1u)] = id;
+        if ((im.send_lo | im.send_hi) != 0u) {  // wave-uniform
+            uint32_t e = 0u;
+            if (lane == 0) e = atomicAdd(&d.counters[CTR_NHALO], 1u);
+            e = __shfl(e, 0);
+            if (e < d.cap) {
+                uint32_t *ent = d.halo_list + (size_t)e * HALO_ENT;
+                if (lane == 0) { ent[0] = id; ent[1] = bkey; }
+                if (lane >= 8 && lane < 16) ent[2 + (lane & 7)] = link_cnt > 0u ? res : NONE;
+            }
+        }
     }
     WGS_PROF(6)
     WGS_PROF_END()

@@ -175,7 +175,7 @@ template <int D> __device__ inline float4 gather_slabs(const Dev &d, uint32_t b,
     return sum;
 }
 
-template <int D, int PHASE, bool TWOWAY = false> __global__ __launch_bounds__(256) void k_grid_update(Dev d) {
+template <int D, int PHASE, bool TWOWAY = false> __global__ __launch_bounds__(256) void k_grid_update(Dev d, uint32_t epoch) {
     constexpr int BW = Dim<D>::BW, BS = Dim<D>::BSHIFT, TW = Dim<D>::TW, TILE = Dim<D>::TILE, NN = Dim<D>::NNBR;
     const uint32_t B = min(d.counters[CTR_NBLOCKS], d.cap);
     const uint32_t total = B * NPB;
@@ -201,24 +201,25 @@ template <int D, int PHASE, bool TWOWAY = false> __global__ __launch_bounds__(25
         l[2] = D == 3 ? (ln >> (2 * BS)) : 0;
         float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
         // PHASE 3 (sharded runs): pairs of the interface layers that a neighbour's particles reach get the neighbour's partial
-        // sum added to this rank's own gather (a + b == b + a bitwise: both ranks hold the same total). The wave — one block —
-        // finds the block's records in the inbound message itself (kernels_shard.h find_records)
+        // sum added to this rank's own gather (a + b == b + a bitwise: both ranks hold the same total), found in the inbound
+        // message's record table (kernels_shard.h rec_find)
         float4 recv = make_float4(0.f, 0.f, 0.f, 0.f);
         if constexpr (PHASE == 3) {
             int bc[3] = {0, 0, 0};
             unpack_key<D>(d.block_key[b], bc);
             const uint32_t rmask = iface_masks<D>(d, bc[0]).recv;  // wave-uniform
             if (rmask != 0u) {
-                uint32_t found[HaloCfg<D>::NTAG];
-                const int face = iface_recv_face(d, bc[0]);
-                find_records<D>(d, face, d.block_key[b], (int)(threadIdx.x & 63u), found);
                 int tag, q;
                 halo_slot<D>(ln, tag, q);
+                const int face = iface_recv_face(d, bc[0]);
                 uint32_t mine = NONE;
 #pragma unroll
-                for (int tt = 0; tt < HaloCfg<D>::NTAG; tt++)
-                    if (tt == tag) mine = found[tt];
-                if (((rmask >> tag) & 1u) && mine != NONE) recv = msg_halo<D>(d.msg.in[face])[(size_t)mine * HaloCfg<D>::REC_F4 + 1 + q];
+                for (int tt = 0; tt < HaloCfg<D>::NTAG; tt++) {
+                    if (!((rmask >> tt) & 1u)) continue;  // wave-uniform: the wave is one block
+                    const uint32_t slot = rec_find_wave<D>(d, face, d.block_key[b], (uint32_t)tt, epoch, (int)(threadIdx.x & 63u));
+                    if (tt == tag) mine = slot;
+                }
+                if (mine != NONE) recv = msg_halo<D>(d.msg.in[face])[(size_t)mine * HaloCfg<D>::REC_F4 + 1 + q];
             }
         }
         float isum[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};  // node impulse (two-way coupling): linear, angular

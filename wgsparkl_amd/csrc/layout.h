@@ -120,6 +120,7 @@ enum { ERRBIT_OVERFLOW = 1u, ERRBIT_KEYRANGE = 2u, ERRBIT_SHARD = 4u, ERRBIT_MAT
 // sort when it computes the block classes itself; the fused G2P then knows which body a particle belongs to from the sort
 // entry it loads anyway, instead of a dependent block_cpic lookup in the middle of every chunk.
 constexpr uint32_t CELL_LISTED = 0x80000000u;
+constexpr uint32_t HALO_ENT = 12;  // words per Dev::halo_list entry: block id, key, 8 source slabs, 2 spare
 
 // Message buffers of a slab (kernels_shard.h): [0] lower, [1] upper neighbour; null = no neighbour on that side.
 struct ShardMsg {
@@ -181,7 +182,7 @@ struct Dev {
     uint2 *visit_list;        // 8 x visit_cap: (listed block, chunk of 64 sorted particles that holds some of its particles); list k, at
                               // [k * visit_cap, + counters[CTR_NVISIT + 32 k]), is the one the CPIC body of the fused G2P advances on
                               // XCD k (g2p_body.inc); device_math.h append_visits deals the chunks to the lists
-    uint32_t *halo_list;      // sharded runs, cap: the active blocks of the interface layers (what k_pack_face gathers and packs)
+    uint32_t *halo_list;      // sharded runs, cap x HALO_ENT words: the active blocks of the layers that travel (what k_pack_face gathers and packs)
     uint32_t visit_cap;       // per list (an eighth of the chunks + 2 per block would do; a block is visited once per chunk it spans)
     uint32_t listed_in_perm;  // this substep's perm_cell entries carry CELL_LISTED (launch 2 of the sort computed the block classes)
     uint32_t g2p_npass;       // chunks per wave of the fused G2P of this substep (defines the eighths; set by the host per substep)

@@ -43,6 +43,27 @@ def reference_smoke_scene():
                 model=MODEL_COROTATED)
 
 
+def reference_sand3():
+    """The reference's shipping 3D scene as written (crates/wgsparkl3d/examples/sand3.rs:28-113): 45 x 100 x 45 = 202 500
+    Drucker-Prager sand particles (E = 2e9, nu = 0.2, phase None) at spacing h/2 above a floor cuboid, four wall cuboids
+    and one kinematic cuboid (tilted -0.5 rad about z, spinning at -1 rad/s about y); h = 1, dt = 1/1200, capacity 60 000."""
+    import math
+    h, nxz = 1.0, 45
+    i, j, k = np.meshgrid(np.arange(nxz), np.arange(100), np.arange(nxz), indexing="ij")
+    pos = (np.stack([i.ravel() + 0.5 - nxz / 2.0, j.ravel() + 0.5 + 10.0, k.ravel() + 0.5 - nxz / 2.0], 1) * (h / 2.0)).astype(F32)
+    ps = ParticleSet.uniform(pos, h / 4.0, 2700.0, ElasticCoefficients.from_young_modulus(2.0e9, 0.2),
+                             plasticity=DruckerPrager.new(2.0e9, 0.2), phase=None)
+    colliders = [Collider.cuboid((100.0, 4.0, 100.0), (0.0, -4.0, 0.0)),
+                 Collider.cuboid((35.0, 5.0, 0.5), (0.0, 5.0, -35.0)), Collider.cuboid((35.0, 5.0, 0.5), (0.0, 5.0, 35.0)),
+                 Collider.cuboid((0.5, 5.0, 35.0), (-35.0, 5.0, 0.0)), Collider.cuboid((0.5, 5.0, 35.0), (35.0, 5.0, 0.0)),
+                 Collider.cuboid((0.5, 2.0, 30.0), (0.0, 2.0, 0.0), rotation=(0.0, 0.0, math.sin(-0.25), math.cos(-0.25)),
+                                 angvel=(0.0, -1.0, 0.0))]
+    return dict(particles=ps, params=SimulationParams(gravity=(0.0, -9.81, 0.0), dt=(1.0 / 60.0) / 20.0), colliders=colliders,
+                cell_width=h, grid_capacity=60_000, model=MODEL_COROTATED,
+                name="the reference's sand3 example as shipped: 45x100x45 Drucker-Prager sand, floor + 4 walls + kinematic rotating cuboid",
+                bytes_per_particle=216.0)
+
+
 def elastic_block_2d(nx=100, ny=100, with_floor=True, jitter=0.05):
     """C1: wgsparkl2d elastic block, 10k particles, 64x64 grid (8x8 blocks), corotated."""
     h = 1.0
