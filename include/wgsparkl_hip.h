@@ -304,6 +304,12 @@ wgs_status wgs_set_uniform_material(wgs_data *data, float mass, float init_volum
  * substep rebuilds the table. enabled = 0 restores the fixed capacity; WGS_ERR_GRID_OVERFLOW remains for growth that
  * outruns the check (more than half a capacity of new blocks inside one call). */
 wgs_status wgs_set_grid_growth(wgs_data *data, int32_t enabled);
+/* Environment (read once per wgs_data_create; developer switches, none of them changes a result): WGS_DEBUG = bit mask of
+ * launch-SHAPE choices (two launches instead of one paired launch, the general binning pass on every substep, ...) and
+ * WGS_REHASH_PERIOD = substeps between unconditional rebuilds of the block table — used by the A/B tools and by the tests
+ * that assert those shapes are bit-identical; WGS_TRACE drains the stream at every pass boundary and says so on stderr.
+ * bench.py refuses to run with WGS_DEBUG / WGS_REHASH_PERIOD set. Switches that DO change results (ablations for timing
+ * experiments) exist only in builds with -DWGS_ABLATE, which wgs_build_info() names and bench.py refuses. */
 /* TEST HOOK (not part of the drop-in surface): runs the device-side exclusive scan that replaces WgPrefixSum
  * (src/grid/prefix_sum.rs:17-152, prefix_sum.wgsl:11-93) on caller data, so that the reference's own scan test
  * vectors (src/grid/prefix_sum.rs:183-229) can be put through the HIP code: out[i] = sum of values[0..i), *total

@@ -182,7 +182,7 @@ template <int D, int PHASE, bool TWOWAY = false> __global__ __launch_bounds__(25
     const float dt = d.sp->dt;
     const float lim = d.h / dt;
     float g[3] = {d.sp->gravity[0], d.sp->gravity[1], d.sp->gravity[2]};
-    if (d.sharded && PHASE != 1 && blockIdx.x == 0 && threadIdx.x == 0) d.counters[CTR_NLEAVE] = 0;  // list of the coming G2P launch
+    if (d.sharded && blockIdx.x == 0 && threadIdx.x == 0) d.counters[CTR_NLEAVE] = 0;  // list of the coming G2P launch
     // Two-way coupling: the node impulses are summed per body in LDS first (integers: any order gives the same sum) and
     // leave the workgroup as at most 16 x 6 global atomics. One atomic per node and component instead serialises at the
     // memory side: 40 k of them on a dozen addresses took 290 us in a scene whose cube rests on the floor.
@@ -236,14 +236,14 @@ template <int D, int PHASE, bool TWOWAY = false> __global__ __launch_bounds__(25
             int ti = tt[0] + TW * tt[1] + (D == 3 ? TW * TW * tt[2] : 0);
             srcs[o] = src;
             tis[o] = ti;
-            if (PHASE != 2) {
+            {
                 float4 p = d.slab[(size_t)src * TILE + ti];
                 sum.x += p.x; sum.y += p.y; sum.z += p.z; sum.w += p.w;
             }
             if constexpr (TWOWAY) {
                 // (sharded runs: also for the interface nodes — the impulses of a rank's OWN particles; the ranks'
                 // fixed-point sums are reduced before integrate_bodies)
-                if (PHASE != 2 && d.block_cpic[src] != 0u) {  // only the CPIC launch of P2G writes impulse partials
+                if (d.block_cpic[src] != 0u) {  // only the CPIC launch of P2G writes impulse partials
                     constexpr int IMPQ = D == 3 ? 2 : 1;
                     const float4 a = d.imp_slab[((size_t)src * TILE + ti) * IMPQ];
                     isum[0] += a.x; isum[1] += a.y; isum[2] += a.z;
@@ -267,11 +267,6 @@ template <int D, int PHASE, bool TWOWAY = false> __global__ __launch_bounds__(25
                 }
             }
         }
-        if constexpr (PHASE == 1) {
-            d.nodes[node] = sum;
-            continue;
-        }
-        if constexpr (PHASE == 2) sum = d.nodes[node];
         if constexpr (PHASE == 3) {
             sum.x += recv.x; sum.y += recv.y; sum.z += recv.z; sum.w += recv.w;
         }
@@ -348,7 +343,10 @@ __device__ unsigned long long g_g2p_prof[WGS_G2P_ROWS][8];
 // buffers fit the 256 MB Infinity Cache (the launch then runs at HBM-roofline speed for its real traffic and a longer
 // wave life only costs), 2 beyond — there the kernel is bound by latency x occupancy and twice the bytes in flight per
 // wave buy 12-15 % (4.1 M particles: 184 -> 161 us, 16 M: 761 -> 647 us; 1 M: 39.0 -> 41.7 us). Same results either way.
-constexpr uint32_t G2P_TWO_PASS_MIN_PARTICLES = 1500000;
+#ifndef WGS_G2P_TWO_PASS_MIN
+#define WGS_G2P_TWO_PASS_MIN 1500000
+#endif
+constexpr uint32_t G2P_TWO_PASS_MIN_PARTICLES = WGS_G2P_TWO_PASS_MIN;
 #ifndef WGS_G2P_LIST_PASSES
 #define WGS_G2P_LIST_PASSES 2
 #endif
