@@ -1131,6 +1131,48 @@ def test_native_lockstep_matches_single_domain(hip_libs, world, dim, monkeypatch
         assert ((bx >= lo - 1) & (bx <= hi)).all()
 
 
+@pytest.mark.parametrize("with_floor", [False, True])
+def test_particles_enter_an_empty_slab_and_leave_theirs_empty(hip_libs, with_floor):
+    """The edge of the one-exchange protocol: a cube flies from slab 0 into slab 1, which holds NO particle at the start —
+    the first arrivals find none of their blocks active on their new rank and read their nodes from the message (the old
+    owner's partial sums are then the totals; with the floor also the node cdfs, evaluated on the spot) — and keeps going
+    until slab 0 is empty. Both against the single-domain run."""
+    from helpers import pipeline
+    from wgsparkl_amd.sharded import NativeShard, SlabPartition, associated_block_x, native_lockstep, split_scene, uniform_material_of
+    sc = scenes.neo_hookean_cube(n_side=16, with_floor=with_floor)
+    ps = sc["particles"]
+    if with_floor:
+        ps.pos[:, 1] -= 5.6                                   # sliding just above the floor: CPIC state travels with the particles
+    ps.vel[:, 0] = 400.0                                      # a third of a cell per substep
+    k = 45                                                    # 15 cells: the whole cube (8 cells wide) crosses the cut
+    ref = run_gpu(sc, k).read_particles()
+    bx = associated_block_x(ps.pos, sc["cell_width"], 3)
+    part = SlabPartition([int(bx.min()), int(bx.max()) + 1, int(bx.max()) + 12])
+    pipe = pipeline(3)
+    shards = []
+    for r, (sub, gids) in enumerate(split_scene(ps, part, sc["cell_width"])):
+        lo, hi = part.block_range(r)
+        shards.append(NativeShard(pipe, sc["params"], sub, gids, sc["colliders"], sc["cell_width"], sc["grid_capacity"], lo, hi, r > 0, r < 1,
+                                  particle_capacity=ps.n, model=sc["model"], uniform_material=uniform_material_of(ps),
+                                  halo_capacity_records=256, migrant_capacity=2048))
+    assert [s.num_particles() for s in shards] == [ps.n, 0]
+    native_lockstep(pipe, shards, 20)
+    mid = [s.num_particles() for s in shards]
+    assert 0 < mid[0] < ps.n and sum(mid) == ps.n, mid         # on its way
+    native_lockstep(pipe, shards, k - 20)
+    for s in shards:
+        s.sync()
+    assert [s.num_particles() for s in shards] == [0, ps.n]
+    outs = [s.export() for s in shards]
+    ids = np.concatenate([o["ids"] for o in outs])
+    assert np.array_equal(np.sort(ids), np.arange(ps.n, dtype=np.uint32))
+    order = np.argsort(ids)
+    for f, tol in (("pos", 1e-5), ("vel", 1e-5), ("def_grad", 1e-5)):
+        err = rel_rms(np.concatenate([o[f] for o in outs])[order], getattr(ref, f))
+        report_margin(f"cube into an empty slab ({'floor' if with_floor else 'free'}) {f}", err, tol)
+        assert err < tol, (f, err)
+
+
 @pytest.mark.parametrize("name", ["mesh_floor3d", "polyline2d"])
 def test_mesh_colliders_on_sharded_data(hip_libs, name):
     """Mesh colliders (rigid-particle samples) on slabs: every slab holds every sample, the node cdfs of the

@@ -774,12 +774,17 @@ template <bool TS> wgs_status enqueue_substep(wgs_data *d, int ts_slot, int part
 #ifndef WGS_PLASTIC_WPE
 #define WGS_PLASTIC_WPE G2P_WAVES_PER_EU
 #endif
-#define WGS_LAUNCH_G2P(MODEL, PL, CM, NP)                                                                          \
-    hipLaunchKernelGGL((k_g2p_update<D, MODEL, PL, CM, NP>), (CM) == 2 ? dim3(8 * (grid_for(d, 1) * 3 / 2)) : dim3(g), \
+            // (the decomposition is a template parameter of the fused G2P: kernels_transfer.h; a slab always takes the paired /
+            // single-body launch shapes, the two-launch debug shape exists for single-domain data only)
+#define WGS_LAUNCH_G2P(MODEL, PL, CM, NP, SH)                                                                          \
+    hipLaunchKernelGGL((k_g2p_update<D, MODEL, PL, CM, NP, SH>), (CM) == 2 ? dim3(8 * (grid_for(d, 1) * 3 / 2)) : dim3(g), \
                        dim3(G2P_THREADS), 0, s, dev, side, epoch)
+#define WGS_LAUNCH_G2P_PAIR(MODEL, PL, WPE, NP, SH)                                                                        \
+    hipLaunchKernelGGL((k_g2p_pair<D, MODEL, PL, WPE, NP, SH>), dim3((uint32_t)g + 8u * nlist), dim3(G2P_THREADS), 0, s, \
+                       dev, side, epoch, (uint32_t)g, nlist)
 #define WGS_LAUNCH_G2P_NP(MODEL, PL, NP)    \
     do {                                    \
-        if (d->cpic && !(dev.dbg & 4096u)) {                                                               \
+        if (d->cpic && (shard || !(dev.dbg & 4096u))) {                                                    \
             /* both bodies in one launch (k_g2p_pair) */                                                          \
             /* list waves (8 x nlist; the waves of an XCD stride over the runs of its visit list): 2 x the runs of the */ \
             /* longest list as the host last saw it */                                                             \
@@ -787,19 +792,20 @@ template <bool TS> wgs_status enqueue_substep(wgs_data *d, int ts_slot, int part
             const uint32_t full = (uint32_t)grid_for(d, 1) * 3u / 2u;                                             \
             const uint32_t nlist = d->last_nvisit == UINT32_MAX ? full : std::min(full, std::max(8u, 2u * ((d->last_nvisit + std::min<uint32_t>(NP, WGS_G2P_LIST_PASSES) - 1u) / std::min<uint32_t>(NP, WGS_G2P_LIST_PASSES)))); \
             /* plastic scenes with a large share of listed blocks: the spill-free variant (kernels_transfer.h) */  \
-            if (PL && d->last_ncpic != UINT32_MAX && d->last_ncpic * 2u >= std::max(1u, d->last_nblocks) && !(dev.dbg & 16384u)) \
-                hipLaunchKernelGGL((k_g2p_pair<D, MODEL, PL, (PL) ? WGS_PLASTIC_WPE_DENSE : G2P_WAVES_PER_EU, NP>), dim3((uint32_t)g + 8u * nlist), \
-                                   dim3(G2P_THREADS), 0, s, dev, side, epoch, (uint32_t)g, nlist);                \
-            else                                                                                                  \
-                hipLaunchKernelGGL((k_g2p_pair<D, MODEL, PL, (PL) ? WGS_PLASTIC_WPE : G2P_WAVES_PER_EU, NP>), dim3((uint32_t)g + 8u * nlist), dim3(G2P_THREADS), 0, s, \
-                                   dev, side, epoch, (uint32_t)g, nlist);                                         \
+            const bool dense = PL && d->last_ncpic != UINT32_MAX && d->last_ncpic * 2u >= std::max(1u, d->last_nblocks) && !(dev.dbg & 16384u); \
+            if (dense && shard) WGS_LAUNCH_G2P_PAIR(MODEL, PL, (PL) ? WGS_PLASTIC_WPE_DENSE : G2P_WAVES_PER_EU, NP, true);      \
+            else if (dense) WGS_LAUNCH_G2P_PAIR(MODEL, PL, (PL) ? WGS_PLASTIC_WPE_DENSE : G2P_WAVES_PER_EU, NP, false);         \
+            else if (shard) WGS_LAUNCH_G2P_PAIR(MODEL, PL, (PL) ? WGS_PLASTIC_WPE : G2P_WAVES_PER_EU, NP, true);                 \
+            else WGS_LAUNCH_G2P_PAIR(MODEL, PL, (PL) ? WGS_PLASTIC_WPE : G2P_WAVES_PER_EU, NP, false);                           \
             mark(6);                                                                                              \
         } else if (d->cpic) {               \
-            WGS_LAUNCH_G2P(MODEL, PL, 1, NP);   \
+            WGS_LAUNCH_G2P(MODEL, PL, 1, NP, false);   \
             mark(6);                        \
-            WGS_LAUNCH_G2P(MODEL, PL, 2, 1);   \
+            WGS_LAUNCH_G2P(MODEL, PL, 2, 1, false);    \
+        } else if (shard) {                 \
+            WGS_LAUNCH_G2P(MODEL, PL, 0, NP, true);    \
         } else {                            \
-            WGS_LAUNCH_G2P(MODEL, PL, 0, NP);   \
+            WGS_LAUNCH_G2P(MODEL, PL, 0, NP, false);   \
         }                                   \
     } while (0)
 #define WGS_LAUNCH_G2P_MP(MODEL, PL)                    \
@@ -808,6 +814,7 @@ template <bool TS> wgs_status enqueue_substep(wgs_data *d, int ts_slot, int part
         else if (npass == 2u) WGS_LAUNCH_G2P_NP(MODEL, PL, 2); \
         else WGS_LAUNCH_G2P_NP(MODEL, PL, 1);           \
     } while (0)
+            const bool shard = dev.sharded != 0u;
             const int sel = (dev.model == WGS_MODEL_NEO_HOOKEAN ? 2 : 0) | (d->plastic ? 1 : 0);
             switch (sel) {
                 case 0: WGS_LAUNCH_G2P_MP(0, false); break;
@@ -817,6 +824,7 @@ template <bool TS> wgs_status enqueue_substep(wgs_data *d, int ts_slot, int part
             }
 #undef WGS_LAUNCH_G2P_MP
 #undef WGS_LAUNCH_G2P_NP
+#undef WGS_LAUNCH_G2P_PAIR
 #undef WGS_LAUNCH_G2P
         }
         if (!(d->cpic && dev.nv > 0)) mark(6);  // (collider simulations: recorded between the two G2P launches)

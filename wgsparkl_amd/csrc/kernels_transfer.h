@@ -358,7 +358,7 @@ constexpr uint32_t G2P_TWO_PASS_MIN_PARTICLES = WGS_G2P_TWO_PASS_MIN;
 #endif
 constexpr int G2P_MANY_PASSES = WGS_G2P_MANY_PASSES;
 constexpr uint32_t G2P_MANY_PASS_MIN_PARTICLES = WGS_G2P_MANY_PASS_MIN;
-template <int D, int MODEL, bool PLASTIC, int CMODE, int NPASS = 1>
+template <int D, int MODEL, bool PLASTIC, int CMODE, int NPASS = 1, bool SHARD = false>
 __global__ __launch_bounds__(G2P_THREADS, G2P_WAVES_PER_EU) void k_g2p_update(Dev d, int side, uint32_t epoch) {
     constexpr uint32_t npass = NPASS;  // (a template parameter: as a kernel argument the second pass's registers spilled in the one-pass launch)
     __shared__ float4 s_node[Dim<D>::TILE];
@@ -385,7 +385,7 @@ __global__ __launch_bounds__(G2P_THREADS, G2P_WAVES_PER_EU) void k_g2p_update(De
 // (With the list half as it was in the middle of round 2 — chunk lanes on XCDs, 27-term stencil for every particle —
 // a third of the blocks listed was already enough: 4 M sand between walls 16 % faster; since the visit lists and the
 // per-particle choice of the stencil that scene is 4.5 % faster with 3: 362-371 -> 346-351 us.)
-template <int D, int MODEL, bool PLASTIC, int WPE = G2P_WAVES_PER_EU, int NPASS = 1>
+template <int D, int MODEL, bool PLASTIC, int WPE = G2P_WAVES_PER_EU, int NPASS = 1, bool SHARD = false>
 __global__ __launch_bounds__(G2P_THREADS, WPE) void k_g2p_pair(Dev d, int side, uint32_t epoch, uint32_t nmain, uint32_t nlist) {
     constexpr uint32_t npass = NPASS;
     __shared__ float4 s_node[Dim<D>::TILE];
