@@ -702,8 +702,11 @@ template <bool TS> wgs_status enqueue_substep(wgs_data *d, int ts_slot, int part
                 // one resident round: 4 workgroups per CU (127 VGPRs, 36 KB of LDS), the scan workgroups among them
                 const uint32_t nreg = std::max(1u, std::min((dev.cap + 3u) / 4u, WGS_REGROUP_ROUNDS * ((uint32_t)grid_for(d, 4) - std::min(nscan, (uint32_t)grid_for(d, 2)))));
                 const dim3 g(nscan + nreg);
-                if (fused_cdf) hipLaunchKernelGGL((k_regroup<D, true>), g, dim3(SORT_THREADS), 0, s, dev, side, epoch, nscan, use_rebin ? 1 : 0);
-                else hipLaunchKernelGGL((k_regroup<D, false>), g, dim3(SORT_THREADS), 0, s, dev, side, epoch, nscan, use_rebin ? 1 : 0);
+                const int have_old = use_rebin ? 1 : 0;
+                if (fused_cdf && dev.sharded) hipLaunchKernelGGL((k_regroup<D, true, true>), g, dim3(SORT_THREADS), 0, s, dev, side, epoch, nscan, have_old);
+                else if (fused_cdf) hipLaunchKernelGGL((k_regroup<D, true, false>), g, dim3(SORT_THREADS), 0, s, dev, side, epoch, nscan, have_old);
+                else if (dev.sharded) hipLaunchKernelGGL((k_regroup<D, false, true>), g, dim3(SORT_THREADS), 0, s, dev, side, epoch, nscan, have_old);
+                else hipLaunchKernelGGL((k_regroup<D, false, false>), g, dim3(SORT_THREADS), 0, s, dev, side, epoch, nscan, have_old);
             }
         } else {
             HIP_TRY(hipMemsetAsync(dev.counters + CTR_NBLOCKS, 0, sizeof(uint32_t), s));

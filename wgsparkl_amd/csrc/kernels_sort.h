@@ -270,6 +270,7 @@ __device__ inline void publish_tagged(unsigned long long *word, uint32_t epoch, 
     __hip_atomic_store(word, ((unsigned long long)epoch << 32) | value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+template <bool SHARD = false>
 __device__ __forceinline__ void scan_chunk(const Dev &d, uint32_t epoch, uint32_t k, uint32_t nchunks, unsigned long long *s_wave, unsigned long long *s_bcast) {
     const uint32_t nphys = min(d.counters[CTR_NPHYS], d.cap);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -339,7 +340,9 @@ __device__ __forceinline__ void scan_chunk(const Dev &d, uint32_t epoch, uint32_
     if (tid == 0) g_prof[WGS_PROF_ROWS - 1][0] = wall_clock64();
 #endif
     if (k == 0 && tid == 0) d.counters[CTR_NPHYS_SEEN + (epoch & 1u)] = d.counters[CTR_NPHYS];
-    if (k == 0 && tid < 4 && d.msg.out[tid >> 1]) reinterpret_cast<uint32_t *>(d.msg.out[tid >> 1])[tid & 1] = 0u;  // record counts of this substep's outgoing messages
+    if constexpr (SHARD) {
+        if (k == 0 && tid < 4 && d.msg.out[tid >> 1]) reinterpret_cast<uint32_t *>(d.msg.out[tid >> 1])[tid & 1] = 0u;  // record counts of this substep's outgoing messages
+    }
 }
 
 // Second level of the scan, by the wave that owns block `id`: loads of the group's 16 (stamp, count) pairs — issued
@@ -379,7 +382,7 @@ __device__ inline void block_prefix(const Dev &d, uint32_t epoch, uint32_t id, i
 // `have_old`: the buffer is the sorted output of the previous substep (cell_start / cell_cursor of a block whose
 // links are one epoch old describe its previous runs: that is where the stayers are); otherwise every particle is
 // on a list.
-template <int D, bool CDF>
+template <int D, bool CDF, bool SHARD>
 __device__ __forceinline__ void regroup_block(const Dev &d, int side, uint32_t epoch, uint32_t id, uint32_t nphys, bool have_old, bool no_new_blocks,
                                               uint32_t *s_in, uint32_t *s_out, uint32_t *s_pid) {
     constexpr int NN = Dim<D>::NNBR;
@@ -643,7 +646,7 @@ __device__ __forceinline__ void regroup_block(const Dev &d, int side, uint32_t e
         d.block_cdf_flag[id] = 0;      // (block_acc is cleared by the grid update: the waves of this group read it)
     }
     if (listed) append_visits(d, id, bstart, btotal, lane);
-    if (d.sharded) {  // block layers that travel to a neighbour: an entry k_pack_face can work from without another look-up —
+    if constexpr (SHARD) {  // block layers that travel to a neighbour: an entry k_pack_face can work from without another look-up —
         // [id, key, the 2^D slabs the block's nodes are gathered from (its "-" neighbours that hold particles: lanes 8..15)]
         const IfaceMasks im = iface_masks<D>(d, b[0]);
         if ((im.send_lo | im.send_hi) != 0u) {  // wave-uniform
@@ -667,13 +670,14 @@ __device__ __forceinline__ void regroup_block(const Dev &d, int side, uint32_t e
 #ifndef WGS_REGROUP_WPE
 #define WGS_REGROUP_WPE 4
 #endif
-template <int D, bool CDF> __global__ __launch_bounds__(SORT_THREADS, WGS_REGROUP_WPE) void k_regroup(Dev d, int side, uint32_t epoch, uint32_t nscan, int have_old) {
+// SHARD: the data is one slab of a decomposition (a template parameter: the single-domain kernel carries no register for it)
+template <int D, bool CDF, bool SHARD = false> __global__ __launch_bounds__(SORT_THREADS, WGS_REGROUP_WPE) void k_regroup(Dev d, int side, uint32_t epoch, uint32_t nscan, int have_old) {
     __shared__ unsigned long long s_wave[SORT_THREADS / 64];
     __shared__ unsigned long long s_bcast;
     __shared__ uint32_t s_in[SORT_THREADS / 64][RUNCAP], s_out[SORT_THREADS / 64][RUNCAP], s_pid[SORT_THREADS / 64][RUNCAP];
     if (blockIdx.x < nscan) {
         __builtin_amdgcn_s_setprio(3);  // every regrouping wave ends up waiting for these few workgroups
-        scan_chunk(d, epoch, blockIdx.x, nscan, s_wave, &s_bcast);
+        scan_chunk<SHARD>(d, epoch, blockIdx.x, nscan, s_wave, &s_bcast);
         return;
     }
     const uint32_t nphys = min(d.counters[CTR_NPHYS], d.cap);
@@ -684,7 +688,7 @@ template <int D, bool CDF> __global__ __launch_bounds__(SORT_THREADS, WGS_REGROU
     // still not in it (rim of the active region: the lookups with the longest probe sequences, every substep)
     const bool no_new_blocks = d.counters[CTR_NPHYS] == d.counters[CTR_NPHYS_SEEN + ((epoch - 1u) & 1u)];
     for (uint32_t id = wave; id < nphys; id += nwaves)
-        regroup_block<D, CDF>(d, side, epoch, id, nphys, have_old != 0, no_new_blocks, s_in[w], s_out[w], s_pid[w]);
+        regroup_block<D, CDF, SHARD>(d, side, epoch, id, nphys, have_old != 0, no_new_blocks, s_in[w], s_out[w], s_pid[w]);
 }
 
 // Test hook (wgs_debug_scan): the scan workgroups, and workgroups that finish it per block exactly like the
