@@ -136,7 +136,7 @@ template <int D> __global__ __launch_bounds__(64) void k_pack_face(Dev d, int si
                 const uint32_t so = __shfl(src, o);
                 part[o] = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (in_tile && so != NONE && (((m.send_lo | m.send_hi) >> tag) & 1u))
-                    part[o] = d.slab[(size_t)so * TILE + tt[0] + TW * tt[1] + (D == 3 ? TW * TW * tt[2] : 0)];
+                    part[o] = d.slab[(size_t)so * TILE + slab_pos<D>(o, l)];
             }
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll

@@ -169,7 +169,7 @@ template <int D> __device__ inline float4 gather_slabs(const Dev &d, uint32_t b,
         if (!in_tile) continue;
         const uint32_t src = d.nbr_minus[b * 8u + o];
         if (src == NONE || d.block_count[src] == 0) continue;
-        const float4 p = d.slab[(size_t)src * TILE + tt[0] + TW * tt[1] + (D == 3 ? TW * TW * tt[2] : 0)];
+        const float4 p = d.slab[(size_t)src * TILE + slab_pos<D>(o, l)];
         sum.x += p.x; sum.y += p.y; sum.z += p.z; sum.w += p.w;
     }
     return sum;
@@ -233,7 +233,7 @@ template <int D, int PHASE, bool TWOWAY = false> __global__ __launch_bounds__(25
             if (!in_tile) continue;
             const uint32_t src = d.act_src[(t >> 6) * 8u + o];  // (k_regroup: "-" neighbour with particles, else NONE)
             if (src == NONE) continue;
-            int ti = tt[0] + TW * tt[1] + (D == 3 ? TW * TW * tt[2] : 0);
+            int ti = (int)slab_pos<D>(o, l);   // (position in the source slab: region o, layout.h)
             srcs[o] = src;
             tis[o] = ti;
             {

@@ -236,6 +236,55 @@ __device__ inline uint32_t g2p_waves_per_xcd(const Dev &d, uint32_t npass) {
     return ((num_valid(d) + span - 1u) / span + 7u) >> 3;
 }
 
+// Layout of a block's tile slab (Dev::slab, Dev::imp_slab): NOT in tile order but grouped by the block the nodes belong to —
+// region o (o in {0,1}^D, bit k = the node lies in the "+1" neighbour along axis k) holds the nodes of the tile that are
+// nodes of block b + o, in that block's own (x fastest) order restricted to the two layers the tile reaches where o_k = 1.
+// The grid update gathers and rewrites, for every destination block, exactly one region of each source slab: with this
+// layout those are contiguous runs of 128 B .. 1 KB instead of 64-byte rows strided through a (BW+2)^D box — the launch
+// moves a tile 3.4x its block, so how it touches it is most of its time. P2G stores and the fused G2P loads whole slabs
+// (contiguous either way) and translate positions with slab_tile_of.
+template <int D> __host__ __device__ constexpr int slab_region_base(int o) {
+    // sizes: prod_k (o_k ? 2 : BW); 3D: 64 32 32 16 32 16 16 8, 2D: 64 16 16 4
+    int base = 0;
+    for (int r = 0; r < o; r++) {
+        int sz = 1;
+        for (int k = 0; k < D; k++) sz *= ((r >> k) & 1) ? 2 : Dim<D>::BW;
+        base += sz;
+    }
+    return base;
+}
+// position in the slab of the node with local coordinates l (in its own block b + o) of region o
+template <int D> __device__ inline uint32_t slab_pos(int o, const int *l) {
+    constexpr int BW = Dim<D>::BW;
+    const int ex = (o & 1) ? 2 : BW, ey = (o & 2) ? 2 : BW;
+    int base = 0;
+#pragma unroll
+    for (int r = 0; r < (1 << D); r++)
+        if (r == o) base = slab_region_base<D>(r);
+    return (uint32_t)(base + l[0] + ex * (l[1] + (D == 3 ? ey * l[2] : 0)));
+}
+// tile index (x + TW y (+ TW^2 z)) of slab position p
+template <int D> __host__ __device__ constexpr uint32_t slab_tile_of(uint32_t p) {
+    constexpr int BW = Dim<D>::BW, TW = Dim<D>::TW;
+    int o = 0;
+    for (int r = 1; r < (1 << D); r++)
+        if (p >= (uint32_t)slab_region_base<D>(r)) o = r;
+    const uint32_t q = p - (uint32_t)slab_region_base<D>(o);
+    const uint32_t sx = (o & 1) ? 1u : (uint32_t)Dim<D>::BSHIFT, sy = (o & 2) ? 1u : (uint32_t)Dim<D>::BSHIFT;   // log2 of the region's extents
+    const uint32_t lx = q & ((1u << sx) - 1u), ly = (q >> sx) & ((1u << sy) - 1u), lz = D == 3 ? q >> (sx + sy) : 0u;
+    const uint32_t tx = lx + ((o & 1) ? BW : 0), ty = ly + ((o & 2) ? BW : 0), tz = lz + ((o & 4) ? BW : 0);
+    return tx + TW * ty + (D == 3 ? TW * TW * tz : 0u);
+}
+// ... as a table in constant memory: the kernels that walk a whole slab (P2G's store, the fused G2P's tile staging) fetch
+// their entries with the slab loads themselves instead of spending ~30 integer instructions per node on the arithmetic
+template <int D> struct SlabTileMap {
+    uint8_t t[Dim<D>::TILE];
+    constexpr SlabTileMap() : t{} {
+        for (int p = 0; p < Dim<D>::TILE; p++) t[p] = (uint8_t)slab_tile_of<D>((uint32_t)p);
+    }
+};
+__constant__ SlabTileMap<WGS_DIM> g_slab_tile_map = SlabTileMap<WGS_DIM>();
+
 // Quad access = (one uniform 64-bit buffer base in SGPRs) + (32-bit per-lane byte offset):
 // `global_load_dwordx4 v[..], v_off, s[base:base+1]`. Valid while one ping-pong buffer is
 // < 4 GiB (checked in wgs_data_create).
