@@ -131,6 +131,7 @@ struct wgs_data {
     bool watch_pending = false, force_rehash = false, auto_grow = true;
     uint32_t grid_grown = 0;            // times the block capacity was doubled
     uint32_t watch_skips = 0;
+    uint32_t cdf_generation = 1;        // bumped whenever cached node cdfs / block classes become invalid (kernels_sort.h regroup_block)
     uint32_t rehash_period = REHASH_PERIOD;  // substeps between unconditional table rebuilds (developer override: WGS_REHASH_PERIOD)
     ShardLink *link = nullptr;          // wgs_shard_attach
     int reduce_impulses = 0;            // sharded two-way coupling: 1 = ncclAllReduce of the body impulses before
@@ -198,7 +199,7 @@ wgs_status alloc_grid(wgs_data *d) {
     GRID_ALLOC(&dev.nodes, cap * NPB);
     GRID_ALLOC(&dev.node_cdf, cap * NPB);
     GRID_ALLOC(&dev.slab, cap * Dim<D>::TILE);
-    GRID_ALLOC(&dev.block_cdf_flag, cap);
+    GRID_ALLOC(&dev.block_cdf_gen, cap);
     GRID_ALLOC(&dev.block_cpic, cap);
     GRID_ALLOC(&dev.cpic_list, (size_t)cap * 8);
     dev.visit_cap = dev.npad / 512u + 2u * cap + 16u;
@@ -248,13 +249,14 @@ wgs_status grow_grid(wgs_data *d, uint32_t new_cap) {
     }
     void *old_ptrs[] = {old.hkeys, old.hvals, old.block_key, old.block_count, old.block_stamp, old.links_epoch, old.block_acc, old.active,
                         old.block_start, old.nbr_plus, old.nbr_minus, old.nbr_known, old.act_src, old.cell_head, old.chunk_a, old.chunk_b, old.group_a, old.group_b,
-                        old.cell_start, old.cell_cursor, old.nodes, old.node_cdf, old.slab, old.block_cdf_flag, old.block_cpic, old.cpic_list, old.visit_list, old.halo_list,
+                        old.cell_start, old.cell_cursor, old.nodes, old.node_cdf, old.slab, old.block_cdf_gen, old.block_cpic, old.cpic_list, old.visit_list, old.halo_list,
                         old.imp_slab, old.mesh_min, old.mesh_aff};
     for (void *p : old_ptrs) release_alloc(d, p);
     HIP_TRY(hipMemsetAsync(dev.hkeys, 0xff, sizeof(uint32_t) * ((size_t)dev.hmask + 1), d->stream));
     HIP_TRY(hipMemsetAsync(dev.hvals, 0xff, sizeof(uint32_t) * ((size_t)dev.hmask + 1), d->stream));
     HIP_TRY(hipMemsetAsync(dev.counters + CTR_NPHYS, 0, sizeof(uint32_t), d->stream));
     d->prev_sorted = false;      // block ids start over: the next substep bins every particle through the hash map
+    d->cdf_generation++;
     d->last_ncpic = UINT32_MAX;
     d->last_nvisit = UINT32_MAX;
     d->grid_grown++;
@@ -661,7 +663,12 @@ template <bool TS> wgs_status enqueue_substep(wgs_data *d, int ts_slot, int part
     // block (k_rebin: no hash lookups except for the few particles that changed block). The full k_bin runs
     // on the first substep, on table-rebuild substeps and in sharded runs (particles arrive from neighbours).
     const bool rehash = d->substeps % d->rehash_period == 0 || (d->force_rehash && part != 2);
-    if (rehash && part != 2) d->force_rehash = false;
+    if (rehash && part != 2) {
+        d->force_rehash = false;
+        d->cdf_generation++;   // block ids are handed out anew
+    }
+    // node cdfs / block classes are reused from one substep to the next while no collider can move
+    dev.cdf_gen = (d->cpic && !d->bodies_move) ? d->cdf_generation : 0u;
     const bool fused_cdf = d->cpic && dev.n_rigid == 0 && !(dev.dbg & 1024u);  // (mesh cdfs are only complete after k_p2g_cdf)
     if (part != 2) dev.listed_in_perm = fused_cdf ? 1u : 0u;  // (part 2 of a sharded substep consumes what its part 1 wrote)
     const bool use_rebin = d->prev_sorted && !rehash && !(dev.dbg & 128u);
@@ -1276,6 +1283,7 @@ wgs_status wgs_set_collider_poses(wgs_data *d, const wgs_pose *poses, const floa
         c.scale = poses[i].scale;
         if (coms) for (int k = 0; k < 3; k++) c.com[k] = coms[i * 3 + k];
     }
+    d->cdf_generation++;   // cached node cdfs / block classes are those of the old poses
     static_assert(offsetof(ColliderDev, scale) + sizeof(float) - offsetof(ColliderDev, rot) == 32, "rot|trans|scale contiguous");
     wgs_status st = upload_collider_field(d, offsetof(ColliderDev, rot), 32, n);
     if (st != WGS_OK) return st;

@@ -397,6 +397,11 @@ __device__ __forceinline__ void regroup_block(const Dev &d, int side, uint32_t e
     uint32_t cs_old = d.cell_start[idx], ce_old = d.cell_cursor[idx];
     const uint32_t head = d.cell_head[idx];
     const uint32_t bkey = d.block_key[id];
+    uint32_t cdf_seen = 0u, cdf_class = 0u;
+    if constexpr (CDF) {
+        cdf_seen = d.block_cdf_gen[id];
+        cdf_class = d.block_cpic[id];
+    }
     uint32_t link = NONE;
     if (lane < 16) link = d.nbr_known[id * 16u + lane];
     const GroupLoads grp = block_prefix_loads(d, id, lane);
@@ -499,7 +504,17 @@ __device__ __forceinline__ void regroup_block(const Dev &d, int side, uint32_t e
     bool listed = false;  // near a collider and holding particles: on the lists of the CPIC bodies of P2G / G2P
     WGS_PROF(2)
     // ---- node cdf tile + block class (independent of the scan: placed before the wait for it)
-    if (CDF WGS_ABLATE_AND(!(d.dbg & (1u << 21)))) {
+    // Colliders that do not move (Dev::cdf_gen != 0): a block keeps its physical id, i.e. its place in space, so the node cdfs
+    // and the class computed for it one substep ago still hold — nothing below needs to run again for a block that holds
+    // particles (then all its "+" neighbours are active, which is what the class depends on besides position) and was
+    // computed under the current generation (bumped by every table rebuild, growth and pose upload).
+    const bool cdf_cached = CDF && d.cdf_gen != 0u && btotal > 0u && cdf_seen == d.cdf_gen;
+    if (cdf_cached) {
+        const bool any = cdf_class != 0u;
+        if (lane == 0 && any) d.cpic_list[(size_t)(id & 7u) * d.cap + atomicAdd(&d.counters[CTR_NCPIC + 32u * (id & 7u)], 1u)] = id;
+        listed = any;
+        pc_flag = any ? CELL_LISTED : 0u;
+    } else if (CDF WGS_ABLATE_AND(!(d.dbg & (1u << 21)))) {
         constexpr int BW = Dim<D>::BW, BS = Dim<D>::BSHIFT, TW = Dim<D>::TW, TILE = Dim<D>::TILE;
         uint32_t mine = 0u;
         // Quick reject, wave-uniform: a collider whose boundary is farther from the tile's centre than the tile's
@@ -545,6 +560,7 @@ __device__ __forceinline__ void regroup_block(const Dev &d, int side, uint32_t e
         const bool any = __ballot(mine != 0u) != 0ull;
         if (lane == 0) {
             d.block_cpic[id] = any ? 1u : 0u;
+            if (d.cdf_gen != 0u && btotal > 0u) d.block_cdf_gen[id] = d.cdf_gen;
             if (any && btotal > 0u) d.cpic_list[(size_t)(id & 7u) * d.cap + atomicAdd(&d.counters[CTR_NCPIC + 32u * (id & 7u)], 1u)] = id;
         }
         listed = any && btotal > 0u;
@@ -643,7 +659,7 @@ __device__ __forceinline__ void regroup_block(const Dev &d, int side, uint32_t e
         d.block_start[id] = bstart;    // first_particle
         d.block_count[id] = btotal;    // snapshot used by P2G / grid update / G2P
         d.links_epoch[id] = epoch;     // the neighbour links and cell runs written above are those of this substep
-        d.block_cdf_flag[id] = 0;      // (block_acc is cleared by the grid update: the waves of this group read it)
+        // (block_acc is cleared by the grid update: the waves of this group read it)
     }
     if (listed) append_visits(d, id, bstart, btotal, lane);
     if constexpr (SHARD) {  // block layers that travel to a neighbour: an entry k_pack_face can work from without another look-up —

@@ -175,7 +175,7 @@ struct Dev {
     float4 *nodes;         // cap*64: velocity|momentum xyz, mass (2D: vx, vy, mass, 0)
     NodeCdf *node_cdf;     // cap*64
     float4 *slab;          // cap*TILE: per-block tile (block + its "+1" rim): momentum after P2G, velocity after the grid update
-    uint32_t *block_cdf_flag; // cap: block has a node with non-zero affinity
+    uint32_t *block_cdf_gen;  // cap: generation (Dev::cdf_gen) under which block_cpic / node_cdf of the block were last computed
     uint32_t *block_cpic;     // cap: some node of the block's (BW+2)^D tile has non-zero affinity
     uint32_t *cpic_list;      // 8 x cap: particle-bearing blocks with block_cpic set; list k = (block id & 7) at [k * cap, + counters[CTR_NCPIC + 32 k]):
                               // eight lists because thousands of returning atomics on ONE counter serialise in the fabric
@@ -184,6 +184,8 @@ struct Dev {
                               // XCD k (g2p_body.inc); device_math.h append_visits deals the chunks to the lists
     uint32_t *halo_list;      // sharded runs, cap x HALO_ENT words: the active blocks of the layers that travel (what k_pack_face gathers and packs)
     uint32_t visit_cap;       // per list (an eighth of the chunks + 2 per block would do; a block is visited once per chunk it spans)
+    uint32_t cdf_gen;         // != 0: no collider moves — node cdfs and block classes computed under this generation stay valid
+                              // (a block keeps its id and therefore its place); 0: recompute every substep
     uint32_t listed_in_perm;  // this substep's perm_cell entries carry CELL_LISTED (launch 2 of the sort computed the block classes)
     uint32_t g2p_npass;       // chunks per wave of the fused G2P of this substep (defines the eighths; set by the host per substep)
     uint32_t *counters;    // CTR_COUNT
