@@ -185,6 +185,8 @@ wgs_status alloc_grid(wgs_data *d) {
     GRID_ALLOC(&dev.block_acc, cap);
     GRID_ALLOC(&dev.active, cap);
     GRID_ALLOC(&dev.block_start, cap);
+    GRID_ALLOC(&dev.act_info, cap);
+    GRID_ALLOC(&dev.act_cells, cap * NPB);
     GRID_ALLOC(&dev.nbr_plus, cap * 8);
     GRID_ALLOC(&dev.nbr_minus, cap * 8);
     GRID_ALLOC(&dev.nbr_known, cap * 16);
@@ -248,7 +250,7 @@ wgs_status grow_grid(wgs_data *d, uint32_t new_cap) {
         return WGS_OK;
     }
     void *old_ptrs[] = {old.hkeys, old.hvals, old.block_key, old.block_count, old.block_stamp, old.links_epoch, old.block_acc, old.active,
-                        old.block_start, old.nbr_plus, old.nbr_minus, old.nbr_known, old.act_src, old.cell_head, old.chunk_a, old.chunk_b, old.group_a, old.group_b,
+                        old.block_start, old.act_info, old.act_cells, old.nbr_plus, old.nbr_minus, old.nbr_known, old.act_src, old.cell_head, old.chunk_a, old.chunk_b, old.group_a, old.group_b,
                         old.cell_start, old.cell_cursor, old.nodes, old.node_cdf, old.slab, old.block_cdf_gen, old.block_cpic, old.cpic_list, old.visit_list, old.halo_list,
                         old.imp_slab, old.mesh_min, old.mesh_aff};
     for (void *p : old_ptrs) release_alloc(d, p);

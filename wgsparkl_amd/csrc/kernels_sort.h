@@ -647,6 +647,7 @@ __device__ __forceinline__ void regroup_block(const Dev &d, int side, uint32_t e
     // ---- new runs, reset of what this substep consumed
     d.cell_start[idx] = bstart + lstart;
     d.cell_cursor[idx] = bstart + lstart + total;
+    d.act_cells[(size_t)aidx * NPB + lane] = make_uint2(bstart + lstart, bstart + lstart + total);   // (the same, where P2G finds it without the block id)
     if (head != 0u) d.cell_head[idx] = 0u;
     if (d.n_rigid != 0u) {             // mesh-collider cdf accumulators of this substep (k_p2g_cdf)
         d.mesh_min[idx] = ~0ull;
@@ -656,6 +657,7 @@ __device__ __forceinline__ void regroup_block(const Dev &d, int side, uint32_t e
     if (lane >= 8 && lane < 16) d.act_src[aidx * 8u + (uint32_t)(lane & 7)] = link_cnt > 0u ? res : NONE;
     if (lane == 63) {
         d.active[aidx] = id;           // grid.wgsl:323-334: the active list, in physical-id order
+        d.act_info[aidx] = make_uint4(id, bkey, btotal, pc_flag);   // (.w: the block class, where this launch computes it)
         d.block_start[id] = bstart;    // first_particle
         d.block_count[id] = btotal;    // snapshot used by P2G / grid update / G2P
         d.links_epoch[id] = epoch;     // the neighbour links and cell runs written above are those of this substep

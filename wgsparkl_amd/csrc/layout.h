@@ -162,6 +162,8 @@ struct Dev {
     uint32_t *block_count; // cap: particles whose associated cell is in the block (num_particles)
     uint32_t *block_start; // cap: exclusive scan of block_count over the active list (first_particle)
     uint32_t *active;      // cap: physical ids of the blocks active in this substep, [0, num_active_blocks)
+    uint4 *act_info;       // cap, by ACTIVE-LIST index: {block id, key, particles, CELL_LISTED if near a collider} — what P2G needs of a block in one load
+    uint2 *act_cells;      // cap*64, by ACTIVE-LIST index: {start, end} of each cell's run in perm (cell_start / cell_cursor are by block id)
     uint32_t *nbr_plus;    // cap*8: physical ids of b + {0,1}^D (always active)
     uint32_t *nbr_minus;   // cap*8: physical ids of b - {0,1}^D, NONE when inactive
     uint32_t *act_src;     // cap*8, by ACTIVE-LIST index: the b - {0,1}^D neighbours that hold particles (the slabs a node of b is
