@@ -129,6 +129,7 @@ struct wgs_data {
     uint32_t *watch = nullptr;          // pinned host copy of the device counters as of the end of the last wgs_step call
     hipEvent_t watch_event = nullptr;
     bool watch_pending = false, force_rehash = false, auto_grow = true;
+    bool gu_fused = false;   // this substep's grid update rode in its P2G launch
     uint32_t grid_grown = 0;            // times the block capacity was doubled
     uint32_t watch_skips = 0;
     uint32_t cdf_generation = 1;        // bumped whenever cached node cdfs / block classes become invalid (kernels_sort.h regroup_block)
@@ -201,6 +202,7 @@ wgs_status alloc_grid(wgs_data *d) {
     GRID_ALLOC(&dev.nodes, cap * NPB);
     GRID_ALLOC(&dev.node_cdf, cap * NPB);
     GRID_ALLOC(&dev.slab, cap * Dim<D>::TILE);
+    GRID_ALLOC(&dev.slab_epoch, cap);
     GRID_ALLOC(&dev.block_cdf_gen, cap);
     GRID_ALLOC(&dev.block_cpic, cap);
     GRID_ALLOC(&dev.cpic_list, (size_t)cap * 8);
@@ -251,7 +253,7 @@ wgs_status grow_grid(wgs_data *d, uint32_t new_cap) {
     }
     void *old_ptrs[] = {old.hkeys, old.hvals, old.block_key, old.block_count, old.block_stamp, old.links_epoch, old.block_acc, old.active,
                         old.block_start, old.act_info, old.act_cells, old.nbr_plus, old.nbr_minus, old.nbr_known, old.act_src, old.cell_head, old.chunk_a, old.chunk_b, old.group_a, old.group_b,
-                        old.cell_start, old.cell_cursor, old.nodes, old.node_cdf, old.slab, old.block_cdf_gen, old.block_cpic, old.cpic_list, old.visit_list, old.halo_list,
+                        old.cell_start, old.cell_cursor, old.nodes, old.node_cdf, old.slab, old.slab_epoch, old.block_cdf_gen, old.block_cpic, old.cpic_list, old.visit_list, old.halo_list,
                         old.imp_slab, old.mesh_min, old.mesh_aff};
     for (void *p : old_ptrs) release_alloc(d, p);
     HIP_TRY(hipMemsetAsync(dev.hkeys, 0xff, sizeof(uint32_t) * ((size_t)dev.hmask + 1), d->stream));
@@ -312,7 +314,7 @@ void fill_collider(ColliderDev &c, const wgs_collider &in) {
     for (int k = 0; k < 3; k++) c.com[k] = in.com[k];
 }
 
-constexpr uint32_t WGS_LAUNCH_SHAPE_SWITCHES = 128u | 1024u | 4096u | 8192u | 16384u | 32768u | 65536u | 131072u;  // WGS_DEBUG bits the shipped library honours
+constexpr uint32_t WGS_LAUNCH_SHAPE_SWITCHES = 128u | 1024u | 4096u | 8192u | 16384u | 32768u | 65536u | 131072u | 262144u;  // WGS_DEBUG bits the shipped library honours
 constexpr uint32_t P2G_SMALL_BUDGET_MIN_PARTICLES = 600000;  // one-way CPIC P2G body at 168 VGPRs from this size on
 #ifndef WGS_REGROUP_ROUNDS
 #define WGS_REGROUP_ROUNDS 4u
@@ -655,6 +657,7 @@ template <bool TS> wgs_status enqueue_substep(wgs_data *d, int ts_slot, int part
         }
     };
     const uint32_t epoch = (uint32_t)(d->substeps + 1);
+    d->gu_fused = false;
     dev.ctr_set = (uint32_t)(d->substeps & 1u);  // sharded runs: the set of particle counters this substep reads (layout.h)
     // chunks of 64 sorted particles per wave of the fused G2P (kernels_transfer.h); the sort files the visit list by it
     // (2D: the body keeps no state of the chunk after the next one — at most two chunks per wave)
@@ -742,27 +745,43 @@ template <bool TS> wgs_status enqueue_substep(wgs_data *d, int ts_slot, int part
             // plain body then keeps its occupancy, so the pair costs nothing while the list is empty, and the choice
             // does not follow the host's syncs (the two budgets differ in the last bit here and there).
             const bool big_one_way = !d->two_way && n >= P2G_SMALL_BUDGET_MIN_PARTICLES && !(dev.dbg & 32768u);
+            // Single-domain one-way simulations: the grid update rides in the (last) P2G launch as workgroups of its own
+            // behind the P2G workgroups (kernels_transfer.h gu_waves; GU = 2), one wave per active block as the host last saw
+            // them; a P2G launch before it hands its slabs over the same way (GU = 1). Same results as the launch of its own
+            // (dbg bit 18 brings that back): the same sums in the same order.
+            const bool fuse_gu = part == 0 && !d->two_way && !dev.sharded && !(dev.dbg & 262144u);
+            const uint32_t NW = (uint32_t)P2GCfg<D>::NW;
+            // (8, 16, 32 or 64 workgroups per CU at most: the same times at C2 / C3 / C5)
+            const uint32_t gu_wgs = !fuse_gu ? 0u : std::min((uint32_t)grid_for(d, 8), std::max((uint32_t)grid_for(d, 1), ((d->seen_nblocks + NW - 1u) / NW + 7u) & ~7u));
+            d->gu_fused = fuse_gu;
             if (d->cpic && (big_one_way || (d->last_ncpic != UINT32_MAX && d->last_ncpic >= P2G_PAIR_MIN_BLOCKS)) && !(dev.dbg & 8192u)) {
                 // many blocks near colliders (as of the last wgs_sync): both bodies in one launch (k_p2g_pair)
-                const dim3 pair_grid(2u * p2g_wgs);
-                if (d->two_way) hipLaunchKernelGGL((k_p2g_pair<D, true>), pair_grid, p2g_block, 0, s, dev, side, epoch);
-                else if (big_one_way) hipLaunchKernelGGL((k_p2g_pair<D, false, 3>), pair_grid, p2g_block, 0, s, dev, side, epoch);
-                else hipLaunchKernelGGL((k_p2g_pair<D, false>), pair_grid, p2g_block, 0, s, dev, side, epoch);
+                const dim3 pair_grid(2u * p2g_wgs + gu_wgs);
+                if (d->two_way) hipLaunchKernelGGL((k_p2g_pair<D, true>), pair_grid, p2g_block, 0, s, dev, side, epoch, p2g_wgs);
+                else if (big_one_way && fuse_gu) hipLaunchKernelGGL((k_p2g_pair<D, false, 3, 2>), pair_grid, p2g_block, 0, s, dev, side, epoch, p2g_wgs);
+                else if (big_one_way) hipLaunchKernelGGL((k_p2g_pair<D, false, 3>), pair_grid, p2g_block, 0, s, dev, side, epoch, p2g_wgs);
+                else if (fuse_gu) hipLaunchKernelGGL((k_p2g_pair<D, false, 1, 2>), pair_grid, p2g_block, 0, s, dev, side, epoch, p2g_wgs);
+                else hipLaunchKernelGGL((k_p2g_pair<D, false>), pair_grid, p2g_block, 0, s, dev, side, epoch, p2g_wgs);
             } else if (d->cpic) {
-                hipLaunchKernelGGL((k_p2g<D, false>), p2g_grid, p2g_block, 0, s, dev, side, 1, epoch);
+                const dim3 last_grid(p2g_wgs + gu_wgs);
+                if (fuse_gu) hipLaunchKernelGGL((k_p2g<D, false, false, false, 1>), p2g_grid, p2g_block, 0, s, dev, side, 1, epoch, p2g_wgs);
+                else hipLaunchKernelGGL((k_p2g<D, false>), p2g_grid, p2g_block, 0, s, dev, side, 1, epoch, p2g_wgs);
                 // near-collider list: particle cdf in the prologue (the node cdfs are complete: k_setup_scatter<CDF>, or
                 // k_cdf after k_p2g_cdf with mesh colliders), then the CPIC transfer
-                if (d->two_way) hipLaunchKernelGGL((k_p2g<D, true, true, true>), p2g_grid, p2g_block, 0, s, dev, side, 2, epoch);
-                else hipLaunchKernelGGL((k_p2g<D, true, false, true>), p2g_grid, p2g_block, 0, s, dev, side, 2, epoch);
+                if (d->two_way) hipLaunchKernelGGL((k_p2g<D, true, true, true>), p2g_grid, p2g_block, 0, s, dev, side, 2, epoch, p2g_wgs);
+                else if (fuse_gu) hipLaunchKernelGGL((k_p2g<D, true, false, true, 2>), last_grid, p2g_block, 0, s, dev, side, 2, epoch, p2g_wgs);
+                else hipLaunchKernelGGL((k_p2g<D, true, false, true>), p2g_grid, p2g_block, 0, s, dev, side, 2, epoch, p2g_wgs);
+            } else if (fuse_gu) {
+                hipLaunchKernelGGL((k_p2g<D, false, false, false, 2>), dim3(p2g_wgs + gu_wgs), p2g_block, 0, s, dev, side, 0, epoch, p2g_wgs);
             } else {
-                hipLaunchKernelGGL((k_p2g<D, false>), p2g_grid, p2g_block, 0, s, dev, side, 0, epoch);
+                hipLaunchKernelGGL((k_p2g<D, false>), p2g_grid, p2g_block, 0, s, dev, side, 0, epoch, p2g_wgs);
             }
         }
         mark(4);
     }
     if (part != 1) {
-        if (n > 0) {
-            // ---- "grid_update"
+        if (n > 0 && !(part == 0 && d->gu_fused)) {
+            // ---- "grid_update" (single-domain one-way simulations: done by waves of the P2G launch above)
             if (part == 0 && d->two_way)
                 hipLaunchKernelGGL((k_grid_update<D, 0, true>), dim3(grid_for(d, WGS_GU_WG_PER_CU)), dim3(256), 0, s, dev, epoch);
             else if (part == 0) hipLaunchKernelGGL((k_grid_update<D, 0>), dim3(grid_for(d, WGS_GU_WG_PER_CU)), dim3(256), 0, s, dev, epoch);
@@ -970,7 +989,8 @@ static wgs_status create_impl(wgs_pipeline *pipeline, const wgs_sim_params *para
     // 4096 = the two G2P bodies as two launches, 8192 = the two P2G bodies always as two launches, 16384 = never the
     // spill-free variant of the plastic G2P pair, 32768 = never the small register budget of the one-way P2G pair,
     // 65536 = never the uniform-material mode (the per-particle constants always travel with the particle), 131072 = the
-    // fused G2P always with two chunks per wave (the large-scene launch shape).
+    // fused G2P always with two chunks per wave (the large-scene launch shape), 262144 = the grid update as a launch of its
+    // own also where it could ride in the P2G launch.
     // The ablations that change the RESULTS (64 = G2P moves bytes only, 256 = P2G without its accumulation loop,
     // 512 = P2G without its particle loads) exist only in builds with -DWGS_ABLATE; the shipped library ignores them.
     dev.dbg = getenv("WGS_DEBUG") ? (uint32_t)strtoul(getenv("WGS_DEBUG"), nullptr, 0) : 0u;

@@ -50,6 +50,69 @@ template <> struct P2GCfg<2> {
     static constexpr int NQ = 3;        // XM, CV0, CV2
 };
 
+// solver/grid_update.wgsl:55-64 for one node: (momentum, mass) sum -> (velocity, mass). One definition for the grid-update
+// launch and for the grid-update waves inside the P2G launch: the same expressions, the same roundings.
+template <int D> __device__ __forceinline__ float4 node_velocity(const float4 sum, const float *g, float dt, float lim) {
+    const float mass = D == 3 ? sum.w : sum.z;
+    const float inv_mass = mass > 0.f ? 1.0f / mass : 0.f;
+    const float mom[3] = {sum.x, sum.y, sum.z};
+    float v[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < D; k++) {
+        const float vel = (mom[k] + mass * g[k] * dt) * inv_mass;
+        v[k] = fminf(fmaxf(vel, -lim), lim);
+    }
+    return D == 3 ? make_float4(v[0], v[1], v[2], mass) : make_float4(v[0], v[1], mass, 0.f);
+}
+
+// The grid update as waves INSIDE the P2G launch (k_p2g / k_p2g_pair with GU = 2; single-domain one-way simulations):
+// one wave per active block and turn, lane = node. The wave waits for the words of the (at most 2^D) slabs its nodes
+// are gathered from — P2G publishes a block's word once the slab's write-through stores have been acknowledged —,
+// gathers with agent-scope loads (past this XCD's L2, which may never have seen the slab) and from there on is the
+// loop body of k_grid_update<D, 0>: the same sums in the same order, the velocity written back into the slabs in place
+// with plain stores (their readers, the fused G2P, are another launch). These workgroups follow every P2G workgroup in
+// dispatch order and wait only for P2G workgroups: nothing they wait for can be waiting for a slot of theirs.
+template <int D> __device__ __forceinline__ void gu_waves(const Dev &d, uint32_t epoch, uint32_t wave, uint32_t nwaves, int lane) {
+    constexpr int BW = Dim<D>::BW, BS = Dim<D>::BSHIFT, TW = Dim<D>::TW, TILE = Dim<D>::TILE, NN = Dim<D>::NNBR;
+    const uint32_t B = min(d.counters[CTR_NBLOCKS], d.cap);
+    const float dt = d.sp->dt;
+    const float lim = d.h / dt;
+    const float g[3] = {d.sp->gravity[0], d.sp->gravity[1], d.sp->gravity[2]};
+    const int l[3] = {lane & (BW - 1), (lane >> BS) & (BW - 1), D == 3 ? (lane >> (2 * BS)) : 0};
+    for (uint32_t a = wave; a < B; a += nwaves) {
+        const uint32_t b = d.active[a];
+        const uint32_t mysrc = lane < NN ? d.act_src[a * 8u + (uint32_t)lane] : NONE;   // (k_regroup: "-" neighbour with particles, else NONE)
+        if (mysrc != NONE)
+            while (__hip_atomic_load(&d.slab_epoch[mysrc], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch) __builtin_amdgcn_s_sleep(2);
+        asm volatile("" ::: "memory");   // (no load below may be scheduled above the loop)
+        // Branch-free gather: one descriptor per source slab (wave-uniform, scalar registers; NO source: zero records), a lane
+        // whose node the slab does not cover asks for an offset past the end — the buffer unit returns zeros for both
+        // without touching memory, and drops such stores. All 2^D loads are in flight together.
+        __amdgpu_buffer_rsrc_t rs[NN];
+        uint32_t off[NN];
+        float4 part[NN];
+#pragma unroll
+        for (int o = 0; o < NN; o++) {
+            const uint32_t src = (uint32_t)__builtin_amdgcn_readlane((int)mysrc, o);
+            const int tt[3] = {l[0] + BW * (o & 1), l[1] + BW * ((o >> 1) & 1), l[2] + BW * ((o >> 2) & 1)};
+            const bool in_tile = tt[0] < TW && tt[1] < TW && (D == 2 || tt[2] < TW);
+            rs[o] = slab_rsrc(&d.slab[(size_t)(src != NONE ? src : 0u) * TILE], src != NONE ? TILE * 16u : 0u);
+            off[o] = in_tile ? slab_pos<D>(o, l) * 16u : 0x7ffffff0u;
+            part[o] = ld_agent(rs[o], off[o]);
+        }
+        float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int o = 0; o < NN; o++) {   // (the fixed order of k_grid_update; an absent term is +0: x + 0 == x, and no partial sum is -0)
+            sum.x += part[o].x; sum.y += part[o].y; sum.z += part[o].z; sum.w += part[o].w;
+        }
+        const float4 nv = node_velocity<D>(sum, g, dt, lim);
+#pragma unroll
+        for (int o = 0; o < NN; o++) st_plain(rs[o], off[o], nv);
+        d.nodes[b * NPB + (uint32_t)lane] = nv;
+        if (lane == 0) d.block_acc[b] = 0u;  // the sort's per-block accumulator is zero at rest (last read: k_regroup)
+    }
+}
+
 // `filter`: 0 = every block; in collider simulations the pass is launched twice, CPIC = false with
 // filter 1 (blocks whose tile sees no collider: every affinity is 0, plain MLS-MPM) and CPIC = true
 // with filter 2 (blocks near a collider).
@@ -59,9 +122,19 @@ template <> struct P2GCfg<2> {
 // bodies by the grid update (p2g.wgsl:142-155).
 // PCDF (with CPIC): the particle cdf of the block's particles (g2p_cdf.wgsl) is computed in the prologue, from the
 // node cdfs k_block_setup<CDF> left in node_cdf — the third step of k_cdf without a launch of its own.
-template <int D, bool CPIC, bool TWOWAY = false, bool PCDF = false>
-__global__ __launch_bounds__(P2GCfg<D>::NW * 64) void k_p2g(Dev d, int side, int filter, uint32_t epoch) {
+// GU (single-domain one-way simulations): 1 = the slabs are handed over inside the launch (write-through stores + the
+// block's word in slab_epoch); 2 = also, the workgroups from index `nblk` on are not P2G workgroups but run the grid
+// update (gu_waves below) — they are dispatched after every P2G workgroup and gather a node as soon as the slabs that
+// cover it are complete: no grid-update launch.
+template <int D, bool CPIC, bool TWOWAY = false, bool PCDF = false, int GU = 0>
+__global__ __launch_bounds__(P2GCfg<D>::NW * 64) void k_p2g(Dev d, int side, int filter, uint32_t epoch, uint32_t nblk) {
     using Cfg = P2GCfg<D>;
+    if constexpr (GU == 2) {
+        if (blockIdx.x >= nblk) {
+            gu_waves<D>(d, epoch, (blockIdx.x - nblk) * Cfg::NW + (threadIdx.x >> 6), (gridDim.x - nblk) * Cfg::NW, (int)(threadIdx.x & 63u));
+            return;
+        }
+    }
     constexpr int BW = Dim<D>::BW, BS = Dim<D>::BSHIFT, TW = Dim<D>::TW, TILE = Dim<D>::TILE;
     constexpr int NT = Cfg::NW * 64;
     constexpr int SLOTS = P2G_J * NPB;
@@ -80,14 +153,16 @@ __global__ __launch_bounds__(P2GCfg<D>::NW * 64) void k_p2g(Dev d, int side, int
 #define P2G_CPIC CPIC
 #define P2G_TWOWAY TWOWAY
 #define P2G_PCDF PCDF
+#define P2G_HANDOVER (GU != 0)
 #define P2G_BLK blockIdx.x
-#define P2G_NBLK gridDim.x
+#define P2G_NBLK nblk
 #include "p2g_body.inc"
 #undef P2G_CPIC
 #undef P2G_TWOWAY
 #undef P2G_PCDF
 #undef P2G_BLK
 #undef P2G_NBLK
+#undef P2G_HANDOVER
 }
 
 // Scenes with MANY blocks near colliders: the plain body (filter 1) and the CPIC body over the near-collider list
@@ -106,9 +181,16 @@ __global__ __launch_bounds__(P2GCfg<D>::NW * 64) void k_p2g(Dev d, int side, int
 // on — with the plain body at full occupancy the pair costs nothing while the list is empty —, and smaller ones keep
 // the unconstrained body, whose paired and separate forms are bit-identical. The two-way body (256 VGPRs) is not
 // offered the small budget.
-template <int D, bool TWOWAY, int WPE = 1>
-__global__ __launch_bounds__(P2GCfg<D>::NW * 64, WPE) void k_p2g_pair(Dev d, int side, uint32_t epoch) {
+// (GU: as for k_p2g; the grid is `half` CPIC + `half` plain workgroups, then the grid-update workgroups)
+template <int D, bool TWOWAY, int WPE = 1, int GU = 0>
+__global__ __launch_bounds__(P2GCfg<D>::NW * 64, WPE) void k_p2g_pair(Dev d, int side, uint32_t epoch, uint32_t half) {
     using Cfg = P2GCfg<D>;
+    if constexpr (GU == 2) {
+        if (blockIdx.x >= 2u * half) {
+            gu_waves<D>(d, epoch, (blockIdx.x - 2u * half) * Cfg::NW + (threadIdx.x >> 6), (gridDim.x - 2u * half) * Cfg::NW, (int)(threadIdx.x & 63u));
+            return;
+        }
+    }
     constexpr int BW = Dim<D>::BW, BS = Dim<D>::BSHIFT, TW = Dim<D>::TW, TILE = Dim<D>::TILE;
     constexpr int NT = Cfg::NW * 64;
     constexpr int SLOTS = P2G_J * NPB;
@@ -123,7 +205,7 @@ __global__ __launch_bounds__(P2GCfg<D>::NW * 64, WPE) void k_p2g_pair(Dev d, int
     __shared__ float4 s_nrm[TWOWAY ? P2G_J * ROW : 1];
     __shared__ NodeCdf s_ncdf[TILE];
     __shared__ float4 s_imp[TWOWAY ? Cfg::NW : 1][TWOWAY ? IMPQ : 1][TWOWAY ? TILE : 1];
-    const uint32_t half = gridDim.x >> 1;
+#define P2G_HANDOVER (GU != 0)
 #define P2G_NBLK half
     if (blockIdx.x >= half) {
         const int filter = 1;
@@ -149,6 +231,7 @@ __global__ __launch_bounds__(P2GCfg<D>::NW * 64, WPE) void k_p2g_pair(Dev d, int
 #undef P2G_BLK
     }
 #undef P2G_NBLK
+#undef P2G_HANDOVER
 }
 
 // ------------------------------------------------------------ grid update
@@ -270,16 +353,7 @@ template <int D, int PHASE, bool TWOWAY = false> __global__ __launch_bounds__(25
         if constexpr (PHASE == 3) {
             sum.x += recv.x; sum.y += recv.y; sum.z += recv.z; sum.w += recv.w;
         }
-        float mass = D == 3 ? sum.w : sum.z;
-        float inv_mass = mass > 0.f ? 1.0f / mass : 0.f;
-        float mom[3] = {sum.x, sum.y, sum.z};
-        float v[3] = {0.f, 0.f, 0.f};
-#pragma unroll
-        for (int k = 0; k < D; k++) {
-            float vel = (mom[k] + mass * g[k] * dt) * inv_mass;
-            v[k] = fminf(fmaxf(vel, -lim), lim);
-        }
-        const float4 nv = D == 3 ? make_float4(v[0], v[1], v[2], mass) : make_float4(v[0], v[1], mass, 0.f);
+        const float4 nv = node_velocity<D>(sum, g, dt, lim);
         // Write the node back into every slab entry it was gathered from: each (block, tile
         // index) pair is read and written by exactly this thread, so the slabs turn in place
         // from per-block momentum tiles into per-block VELOCITY tiles, which is what the fused

@@ -177,6 +177,8 @@ struct Dev {
     float4 *nodes;         // cap*64: velocity|momentum xyz, mass (2D: vx, vy, mass, 0)
     NodeCdf *node_cdf;     // cap*64
     float4 *slab;          // cap*TILE: per-block tile (block + its "+1" rim): momentum after P2G, velocity after the grid update
+    uint32_t *slab_epoch;  // cap: substep (epoch) of the block's last COMPLETE momentum slab — P2G's hand-over to the grid-update waves that ride in
+                           // the same launch (kernels_transfer.h): written after the slab's write-through stores have been acknowledged
     uint32_t *block_cdf_gen;  // cap: generation (Dev::cdf_gen) under which block_cpic / node_cdf of the block were last computed
     uint32_t *block_cpic;     // cap: some node of the block's (BW+2)^D tile has non-zero affinity
     uint32_t *cpic_list;      // 8 x cap: particle-bearing blocks with block_cpic set; list k = (block id & 7) at [k * cap, + counters[CTR_NCPIC + 32 k]):
@@ -316,6 +318,30 @@ __device__ inline float4 ldq_stream(const float *base, uint32_t npad, int q, uin
     asm volatile("" : "+v"(off));
     const v4f nv = __builtin_nontemporal_load(reinterpret_cast<const v4f *>(reinterpret_cast<const char *>(base) + off));
     return make_float4(nv.x, nv.y, nv.z, nv.w);
+}
+// Hand-over of 16-byte values between workgroups of ONE launch (P2G's slabs to the grid-update waves): every XCD has an L2
+// of its own, coherent with the others only at kernel boundaries — or for accesses made at agent scope, which the
+// hardware writes through / fetches past the L2 (the sc1 bit). Relaxed atomics compile to such accesses but only up to
+// 8 bytes (two half-line transactions per float4); the raw buffer instructions take the cache policy as an operand:
+// buffer_{load,store}_dwordx4 ... sc1 over a descriptor of ONE slab (wave-uniform base, 32-bit byte offset), with the
+// compiler's own wait counts. No fence is involved (an agent-scope fence is a whole-L2 write-back on this part: NOTES.md 4).
+typedef uint32_t wgs_v4u __attribute__((ext_vector_type(4)));
+constexpr int WGS_CPOL_SC1 = 16;   // gfx940+: agent scope
+__device__ inline __amdgpu_buffer_rsrc_t slab_rsrc(float4 *slab_of_block, uint32_t bytes) {
+    // (the base must be wave-uniform: callers pass a pointer computed from a readfirstlane'd block id)
+    return __builtin_amdgcn_make_buffer_rsrc(slab_of_block, 0, bytes, 0x00020000);
+}
+__device__ inline void st_agent(__amdgpu_buffer_rsrc_t r, uint32_t byte_off, const float4 v) {
+    const wgs_v4u u = {__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)};
+    __builtin_amdgcn_raw_buffer_store_b128(u, r, byte_off, 0, WGS_CPOL_SC1);
+}
+__device__ inline void st_plain(__amdgpu_buffer_rsrc_t r, uint32_t byte_off, const float4 v) {   // (bounds-checked, cached as usual)
+    const wgs_v4u u = {__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)};
+    __builtin_amdgcn_raw_buffer_store_b128(u, r, byte_off, 0, 0);
+}
+__device__ inline float4 ld_agent(__amdgpu_buffer_rsrc_t r, uint32_t byte_off) {
+    const wgs_v4u u = __builtin_amdgcn_raw_buffer_load_b128(r, byte_off, 0, WGS_CPOL_SC1);
+    return make_float4(__uint_as_float(u.x), __uint_as_float(u.y), __uint_as_float(u.z), __uint_as_float(u.w));
 }
 // persistent particle id (the caller's index) lives after the quads
 template <int D> __device__ inline uint32_t ldpid(const float *base, uint32_t npad, uint32_t i) {
