@@ -386,17 +386,18 @@ def test_g2p_launch_shapes_are_bit_identical(hip_libs, monkeypatch):
 
 
 def test_grid_update_inside_the_p2g_launch_is_bit_identical_to_its_own_launch(hip_libs, monkeypatch):
-    """Single-domain one-way simulations run the grid update as waves of the (last) P2G launch: P2G hands its slabs over
+    """Single-domain simulations run the grid update as waves of the (last) P2G launch: P2G hands its slabs over
     inside the launch (write-through stores, one word per block), the waves gather past their XCD's L2
     (kernels_transfer.h gu_waves). WGS_DEBUG = 262144 brings the launch of its own back: same sums in the same order, so
     the same bits — no colliders (one P2G launch), a floor in contact (two launches, then the paired one after the
     host has seen the list), plastic between walls, 2D; particles AND the grid (nodes, slabs' velocities feed the G2P)."""
     makes = (lambda: scenes.neo_hookean_cube(n_side=24), lambda: scenes.neo_hookean_cube(n_side=40, with_floor=True),
-             lambda: scenes.sand_column(nx=12, ny=20, nz=12, with_floor=True), lambda: scenes.elastic_block_2d(nx=50, ny=40))
+             lambda: scenes.sand_column(nx=12, ny=20, nz=12, with_floor=True), lambda: scenes.elastic_block_2d(nx=50, ny=40),
+             lambda: scenes.corotated_cube_with_paddle(n_side=32))   # (two-way coupling: node impulses gathered by the same waves)
     for make in makes:
         def run():
             sc = make()
-            if sc["colliders"]:
+            if sc["colliders"] and len(sc["colliders"]) == 1:
                 sc["particles"].pos[:, 1] -= 5.6 if sc["particles"].dim == 3 else 4.6
             sc["particles"].vel[:, 0] = 1.5
             from helpers import pipeline
@@ -406,15 +407,18 @@ def test_grid_update_inside_the_p2g_launch_is_bit_identical_to_its_own_launch(hi
             pipe.step(data, 12)
             data.sync()          # (a long near-collider list seen here switches P2G to its paired launch)
             pipe.step(data, 13)
-            return data.read_particles(), data.read_grid()
-        a, ga = run()
+            return data.read_particles(), data.read_grid(), data.read_body_poses()
+        a, ga, ba = run()
         monkeypatch.setenv("WGS_DEBUG", "262144")
-        b, gb = run()
+        b, gb, bb = run()
         monkeypatch.delenv("WGS_DEBUG")
         for f in ("pos", "vel", "def_grad", "affine", "cdf_affinity", "dp_state"):
             assert np.array_equal(getattr(a, f), getattr(b, f)), f
         for x, y in zip(ga, gb):
             assert np.array_equal(x, y)
+        for x, y in zip(ba, bb):
+            for key in ("translation", "rotation", "linvel", "angvel"):
+                assert np.array_equal(x[key], y[key]), key
 
 
 def _exploding_cube():

@@ -4,7 +4,9 @@ sys.path.insert(0, '.'); sys.path.insert(0, 'tests')
 import numpy as np
 from helpers import pipeline
 from wgsparkl_amd import MpmData, scenes
-if len(sys.argv) > 1 and sys.argv[1] in ("c2", "c3", "c5"):
+if len(sys.argv) > 1 and sys.argv[1] == "sand3":
+    sc = scenes.reference_sand3()
+elif len(sys.argv) > 1 and sys.argv[1] in ("c2", "c3", "c5"):
     sc = scenes.config_scene(sys.argv[1], n_side=int(sys.argv[2]) if len(sys.argv) > 2 else None)
 else:
     n_side = int(sys.argv[1]) if len(sys.argv) > 1 else 100

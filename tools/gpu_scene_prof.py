@@ -1,0 +1,11 @@
+"""Developer utility: one reference-sized scene under rocprofv3 (tools/gpu_scene_kstats.sh): settle, sync, then the substeps."""
+import sys; sys.path.insert(0, '.'); sys.path.insert(0, 'tests')
+from helpers import pipeline
+from wgsparkl_amd import MpmData, scenes
+name = sys.argv[1] if len(sys.argv) > 1 else "sand3"
+sc = scenes.reference_sand3() if name == "sand3" else scenes.elastic_block_2d() if name == "c1" else scenes.neo_hookean_cube(n_side=64, with_floor=True)
+pipe = pipeline(sc["particles"].dim)
+data = MpmData.new(pipe, sc["params"], sc["particles"], sc["colliders"], sc["cell_width"], sc["grid_capacity"], sc.get("model", 0))
+pipe.step(data, 100); data.sync()
+pipe.step(data, 200); data.sync()
+print(data.stats())

@@ -745,11 +745,11 @@ template <bool TS> wgs_status enqueue_substep(wgs_data *d, int ts_slot, int part
             // plain body then keeps its occupancy, so the pair costs nothing while the list is empty, and the choice
             // does not follow the host's syncs (the two budgets differ in the last bit here and there).
             const bool big_one_way = !d->two_way && n >= P2G_SMALL_BUDGET_MIN_PARTICLES && !(dev.dbg & 32768u);
-            // Single-domain one-way simulations: the grid update rides in the (last) P2G launch as workgroups of its own
+            // Single-domain simulations: the grid update rides in the (last) P2G launch as workgroups of its own
             // behind the P2G workgroups (kernels_transfer.h gu_waves; GU = 2), one wave per active block as the host last saw
             // them; a P2G launch before it hands its slabs over the same way (GU = 1). Same results as the launch of its own
             // (dbg bit 18 brings that back): the same sums in the same order.
-            const bool fuse_gu = part == 0 && !d->two_way && !dev.sharded && !(dev.dbg & 262144u);
+            const bool fuse_gu = part == 0 && !dev.sharded && !(dev.dbg & 262144u);
             const uint32_t NW = (uint32_t)P2GCfg<D>::NW;
             // (8, 16, 32 or 64 workgroups per CU at most: the same times at C2 / C3 / C5)
             const uint32_t gu_wgs = !fuse_gu ? 0u : std::min((uint32_t)grid_for(d, 8), std::max((uint32_t)grid_for(d, 1), ((d->seen_nblocks + NW - 1u) / NW + 7u) & ~7u));
@@ -757,7 +757,8 @@ template <bool TS> wgs_status enqueue_substep(wgs_data *d, int ts_slot, int part
             if (d->cpic && (big_one_way || (d->last_ncpic != UINT32_MAX && d->last_ncpic >= P2G_PAIR_MIN_BLOCKS)) && !(dev.dbg & 8192u)) {
                 // many blocks near colliders (as of the last wgs_sync): both bodies in one launch (k_p2g_pair)
                 const dim3 pair_grid(2u * p2g_wgs + gu_wgs);
-                if (d->two_way) hipLaunchKernelGGL((k_p2g_pair<D, true>), pair_grid, p2g_block, 0, s, dev, side, epoch, p2g_wgs);
+                if (d->two_way && fuse_gu) hipLaunchKernelGGL((k_p2g_pair<D, true, 1, 2>), pair_grid, p2g_block, 0, s, dev, side, epoch, p2g_wgs);
+                else if (d->two_way) hipLaunchKernelGGL((k_p2g_pair<D, true>), pair_grid, p2g_block, 0, s, dev, side, epoch, p2g_wgs);
                 else if (big_one_way && fuse_gu) hipLaunchKernelGGL((k_p2g_pair<D, false, 3, 2>), pair_grid, p2g_block, 0, s, dev, side, epoch, p2g_wgs);
                 else if (big_one_way) hipLaunchKernelGGL((k_p2g_pair<D, false, 3>), pair_grid, p2g_block, 0, s, dev, side, epoch, p2g_wgs);
                 else if (fuse_gu) hipLaunchKernelGGL((k_p2g_pair<D, false, 1, 2>), pair_grid, p2g_block, 0, s, dev, side, epoch, p2g_wgs);
@@ -768,7 +769,8 @@ template <bool TS> wgs_status enqueue_substep(wgs_data *d, int ts_slot, int part
                 else hipLaunchKernelGGL((k_p2g<D, false>), p2g_grid, p2g_block, 0, s, dev, side, 1, epoch, p2g_wgs);
                 // near-collider list: particle cdf in the prologue (the node cdfs are complete: k_setup_scatter<CDF>, or
                 // k_cdf after k_p2g_cdf with mesh colliders), then the CPIC transfer
-                if (d->two_way) hipLaunchKernelGGL((k_p2g<D, true, true, true>), p2g_grid, p2g_block, 0, s, dev, side, 2, epoch, p2g_wgs);
+                if (d->two_way && fuse_gu) hipLaunchKernelGGL((k_p2g<D, true, true, true, 2>), last_grid, p2g_block, 0, s, dev, side, 2, epoch, p2g_wgs);
+                else if (d->two_way) hipLaunchKernelGGL((k_p2g<D, true, true, true>), p2g_grid, p2g_block, 0, s, dev, side, 2, epoch, p2g_wgs);
                 else if (fuse_gu) hipLaunchKernelGGL((k_p2g<D, true, false, true, 2>), last_grid, p2g_block, 0, s, dev, side, 2, epoch, p2g_wgs);
                 else hipLaunchKernelGGL((k_p2g<D, true, false, true>), p2g_grid, p2g_block, 0, s, dev, side, 2, epoch, p2g_wgs);
             } else if (fuse_gu) {
@@ -781,7 +783,7 @@ template <bool TS> wgs_status enqueue_substep(wgs_data *d, int ts_slot, int part
     }
     if (part != 1) {
         if (n > 0 && !(part == 0 && d->gu_fused)) {
-            // ---- "grid_update" (single-domain one-way simulations: done by waves of the P2G launch above)
+            // ---- "grid_update" (single-domain simulations: done by waves of the P2G launch above)
             if (part == 0 && d->two_way)
                 hipLaunchKernelGGL((k_grid_update<D, 0, true>), dim3(grid_for(d, WGS_GU_WG_PER_CU)), dim3(256), 0, s, dev, epoch);
             else if (part == 0) hipLaunchKernelGGL((k_grid_update<D, 0>), dim3(grid_for(d, WGS_GU_WG_PER_CU)), dim3(256), 0, s, dev, epoch);

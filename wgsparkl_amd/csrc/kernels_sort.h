@@ -169,7 +169,7 @@ template <int D> __device__ __forceinline__ void rebin_body(const Dev &d, int si
     const bool in_range = i < num_slots(d);
     bool valid = in_range;
     if (d.sharded && valid) valid = ldpid<D>(in, d.npad, i) != 0xffffffffu;
-    uint32_t myid = NONE, local = 0, old = NONE;
+    uint32_t myid = NONE, local = 0, old = NONE, mykey = 0u;
     if (valid) {
         if (!d.sharded || i < ctr_cur(d, CTR_NPREV)) old = d.perm_cell[i];  // NONE only after a grid overflow: take the hash path then
         if (old != NONE) old &= ~CELL_LISTED;
@@ -189,6 +189,7 @@ template <int D> __device__ __forceinline__ void rebin_body(const Dev &d, int si
             atomicOr(&d.counters[CTR_ERRORS], ERRBIT_KEYRANGE);
         } else {
             const uint32_t key = pack_key<D>(nb);
+            mykey = key;
             myid = (old != NONE && key == okey) ? ob : activate_block(d, key, epoch);  // few particles change block
             if (myid >= d.cap) myid = NONE;
         }
@@ -198,6 +199,9 @@ template <int D> __device__ __forceinline__ void rebin_body(const Dev &d, int si
     while (todo) {
         const int leader = __ffsll((long long)todo) - 1;
         const uint32_t b1 = __shfl(myid, leader);
+        // (the block's key from the leader's own particle, not from block_key[b1]: a block handed out in THIS launch by a
+        // wave of another XCD has its key in that XCD's L2 only)
+        const uint32_t k1 = __shfl(mykey, leader);
         const unsigned long long same = __ballot(myid == b1);
         todo &= ~same;
         if (lane == leader) atomicAdd(&d.block_acc[b1], (uint32_t)__popcll(same));
@@ -211,7 +215,7 @@ template <int D> __device__ __forceinline__ void rebin_body(const Dev &d, int si
                 d.block_stamp[t1] = epoch;
             } else {
                 int kb[3] = {0, 0, 0};
-                unpack_key<D>(d.block_key[b1], kb);
+                unpack_key<D>(k1, kb);
                 int nb[3] = {kb[0] + (lane & 1), kb[1] + ((lane >> 1) & 1), kb[2] + ((lane >> 2) & 1)};
                 if (block_in_key_range<D>(nb)) activate_block(d, pack_key<D>(nb), epoch);
             }

@@ -72,7 +72,14 @@ template <int D> __device__ __forceinline__ float4 node_velocity(const float4 su
 // loop body of k_grid_update<D, 0>: the same sums in the same order, the velocity written back into the slabs in place
 // with plain stores (their readers, the fused G2P, are another launch). These workgroups follow every P2G workgroup in
 // dispatch order and wait only for P2G workgroups: nothing they wait for can be waiting for a slot of theirs.
-template <int D> __device__ __forceinline__ void gu_waves(const Dev &d, uint32_t epoch, uint32_t wave, uint32_t nwaves, int lane) {
+// TWOWAY: the node impulses P2G's CPIC body left in imp_slab are gathered the same way, converted to fixed point and summed
+// per body — in LDS first, then at most 16 x 6 global atomics per workgroup, as k_grid_update<D, PHASE, true> does.
+template <int D, bool TWOWAY = false> __device__ __forceinline__ void gu_waves(const Dev &d, uint32_t epoch, uint32_t wave, uint32_t nwaves, int lane) {
+    __shared__ int32_t s_body_imp[TWOWAY ? 128 : 1];
+    if constexpr (TWOWAY) {
+        for (uint32_t i = threadIdx.x; i < 128u; i += blockDim.x) s_body_imp[i] = 0;
+        __syncthreads();
+    }
     constexpr int BW = Dim<D>::BW, BS = Dim<D>::BSHIFT, TW = Dim<D>::TW, TILE = Dim<D>::TILE, NN = Dim<D>::NNBR;
     const uint32_t B = min(d.counters[CTR_NBLOCKS], d.cap);
     const float dt = d.sp->dt;
@@ -105,11 +112,45 @@ template <int D> __device__ __forceinline__ void gu_waves(const Dev &d, uint32_t
         for (int o = 0; o < NN; o++) {   // (the fixed order of k_grid_update; an absent term is +0: x + 0 == x, and no partial sum is -0)
             sum.x += part[o].x; sum.y += part[o].y; sum.z += part[o].z; sum.w += part[o].w;
         }
+        if constexpr (TWOWAY) {
+            constexpr int IMPQ = D == 3 ? 2 : 1;
+            float isum[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};  // node impulse: linear, angular
+#pragma unroll
+            for (int o = 0; o < NN; o++) {
+                const uint32_t src = (uint32_t)__builtin_amdgcn_readlane((int)mysrc, o);
+                if (src == NONE || d.block_cpic[src] == 0u) continue;   // (wave-uniform) only the CPIC body of P2G writes impulse partials
+                const __amdgpu_buffer_rsrc_t ri = slab_rsrc(&d.imp_slab[(size_t)src * TILE * IMPQ], TILE * IMPQ * 16u);
+                const uint32_t io = off[o] < TILE * 16u ? off[o] * IMPQ : 0x7ffffff0u;
+                const float4 a = ld_agent(ri, io);
+                isum[0] += a.x; isum[1] += a.y; isum[2] += a.z;
+                if constexpr (D == 3) {
+                    const float4 bq = ld_agent(ri, io + 16u);
+                    isum[3] += bq.x; isum[4] += bq.y; isum[5] += bq.z;
+                }
+            }
+            // p2g.wgsl:142-155: the node's total impulse goes to its closest body, in fixed point (integer atomics: order-independent)
+            const uint32_t cl = d.node_cdf[(size_t)b * NPB + (uint32_t)lane].closest_id;
+            if (cl < 16u) {
+                constexpr int NI = D == 3 ? 6 : 3;
+#pragma unroll
+                for (int k = 0; k < NI; k++) {
+                    const int32_t v = flt2int(isum[k]);
+                    if (v != 0) atomicAdd(&s_body_imp[cl * 8u + k], v);
+                }
+            }
+        }
         const float4 nv = node_velocity<D>(sum, g, dt, lim);
 #pragma unroll
         for (int o = 0; o < NN; o++) st_plain(rs[o], off[o], nv);
         d.nodes[b * NPB + (uint32_t)lane] = nv;
         if (lane == 0) d.block_acc[b] = 0u;  // the sort's per-block accumulator is zero at rest (last read: k_regroup)
+    }
+    if constexpr (TWOWAY) {
+        __syncthreads();
+        for (uint32_t i = threadIdx.x; i < 128u; i += blockDim.x) {
+            const int32_t v = s_body_imp[i];
+            if (v != 0) atomicAdd(&d.impulses[i], v);
+        }
     }
 }
 
@@ -122,7 +163,7 @@ template <int D> __device__ __forceinline__ void gu_waves(const Dev &d, uint32_t
 // bodies by the grid update (p2g.wgsl:142-155).
 // PCDF (with CPIC): the particle cdf of the block's particles (g2p_cdf.wgsl) is computed in the prologue, from the
 // node cdfs k_block_setup<CDF> left in node_cdf — the third step of k_cdf without a launch of its own.
-// GU (single-domain one-way simulations): 1 = the slabs are handed over inside the launch (write-through stores + the
+// GU (single-domain simulations): 1 = the slabs are handed over inside the launch (write-through stores + the
 // block's word in slab_epoch); 2 = also, the workgroups from index `nblk` on are not P2G workgroups but run the grid
 // update (gu_waves below) — they are dispatched after every P2G workgroup and gather a node as soon as the slabs that
 // cover it are complete: no grid-update launch.
@@ -131,7 +172,7 @@ __global__ __launch_bounds__(P2GCfg<D>::NW * 64) void k_p2g(Dev d, int side, int
     using Cfg = P2GCfg<D>;
     if constexpr (GU == 2) {
         if (blockIdx.x >= nblk) {
-            gu_waves<D>(d, epoch, (blockIdx.x - nblk) * Cfg::NW + (threadIdx.x >> 6), (gridDim.x - nblk) * Cfg::NW, (int)(threadIdx.x & 63u));
+            gu_waves<D, TWOWAY>(d, epoch, (blockIdx.x - nblk) * Cfg::NW + (threadIdx.x >> 6), (gridDim.x - nblk) * Cfg::NW, (int)(threadIdx.x & 63u));
             return;
         }
     }
@@ -187,7 +228,7 @@ __global__ __launch_bounds__(P2GCfg<D>::NW * 64, WPE) void k_p2g_pair(Dev d, int
     using Cfg = P2GCfg<D>;
     if constexpr (GU == 2) {
         if (blockIdx.x >= 2u * half) {
-            gu_waves<D>(d, epoch, (blockIdx.x - 2u * half) * Cfg::NW + (threadIdx.x >> 6), (gridDim.x - 2u * half) * Cfg::NW, (int)(threadIdx.x & 63u));
+            gu_waves<D, TWOWAY>(d, epoch, (blockIdx.x - 2u * half) * Cfg::NW + (threadIdx.x >> 6), (gridDim.x - 2u * half) * Cfg::NW, (int)(threadIdx.x & 63u));
             return;
         }
     }
