@@ -610,6 +610,8 @@ wgs_status sticky_status(wgs_data *d) {
         return fail(WGS_ERR_INVALID_ARGUMENT, "sharded run: a message buffer or the particle capacity overflowed, a particle left the decomposition, or the ranks disagree on the uniform-material mode");
     if (d->sticky_errors & ERRBIT_KEYRANGE)
         return fail(WGS_ERR_KEY_RANGE, "a particle left the packed block-key range (grid.wgsl:88-95)");
+    if (d->sticky_errors & ERRBIT_HANDOVER)
+        return fail(WGS_ERR_HIP, "internal: a grid-update wave gave up waiting for a block's P2G slab (the sort's block totals and cell runs disagree)");
     if (d->sticky_errors & ERRBIT_MATERIAL)
         return fail(WGS_ERR_INVALID_ARGUMENT, "wgs_set_uniform_material: a particle of this wgs_data carries other constants (mass, init_volume, lambda, mu)");
     return WGS_OK;

@@ -89,8 +89,19 @@ template <int D, bool TWOWAY = false> __device__ __forceinline__ void gu_waves(c
     for (uint32_t a = wave; a < B; a += nwaves) {
         const uint32_t b = d.active[a];
         const uint32_t mysrc = lane < NN ? d.act_src[a * 8u + (uint32_t)lane] : NONE;   // (k_regroup: "-" neighbour with particles, else NONE)
-        if (mysrc != NONE)
-            while (__hip_atomic_load(&d.slab_epoch[mysrc], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch) __builtin_amdgcn_s_sleep(2);
+        if (mysrc != NONE) {
+            // (bounded: ~a second. Every block the sort counted particles for is visited by a P2G workgroup of this launch,
+            // which publishes its word; should the two ever disagree the wave reports it and gathers what is there — the
+            // behaviour of the launch of its own — instead of hanging the device)
+            uint32_t spins = 0u;
+            while (__hip_atomic_load(&d.slab_epoch[mysrc], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch) {
+                __builtin_amdgcn_s_sleep(2);
+                if (++spins == (1u << 20)) {
+                    atomicOr(&d.counters[CTR_ERRORS], ERRBIT_HANDOVER);
+                    break;
+                }
+            }
+        }
         asm volatile("" ::: "memory");   // (no load below may be scheduled above the loop)
         // Branch-free gather: one descriptor per source slab (wave-uniform, scalar registers; NO source: zero records), a lane
         // whose node the slab does not cover asks for an offset past the end — the buffer unit returns zeros for both

@@ -115,7 +115,7 @@ enum { CTR_NBLOCKS = 0, CTR_ERRORS = 1, CTR_NPHYS = 2, CTR_N = 4, CTR_NV = 5,
        CTR_NCPIC = 320,  // [320 + 32 k], k = 0..7: length of list k of the near-collider blocks (Dev::cpic_list), one cache line each
        CTR_NHALO = 576,  // sharded runs: length of the list of active blocks in the interface layers (Dev::halo_list)
        CTR_COUNT = 640 };
-enum { ERRBIT_OVERFLOW = 1u, ERRBIT_KEYRANGE = 2u, ERRBIT_SHARD = 4u, ERRBIT_MATERIAL = 8u };
+enum { ERRBIT_OVERFLOW = 1u, ERRBIT_KEYRANGE = 2u, ERRBIT_SHARD = 4u, ERRBIT_MATERIAL = 8u, ERRBIT_HANDOVER = 16u };
 // Bit 31 of a perm_cell entry (block ids stay below 2^24): the particle's block is near a collider. Written by launch 2 of the
 // sort when it computes the block classes itself; the fused G2P then knows which body a particle belongs to from the sort
 // entry it loads anyway, instead of a dependent block_cpic lookup in the middle of every chunk.
