@@ -81,7 +81,7 @@ def cpu_baseline(scene, substeps):
 def g2p_roofline(timings, k_ts, mark_ms, n, n_nodes, bytes_per_particle, kernel):
     # One launch between the two marks of the "g2p" pass: the event interval IS the duration rocprofv3 reports for the
     # kernel (profiles/rNN_kernel_stats.csv; both contain the launch's dispatch gap, and the rocprofv3 durations of the
-    # five launches of a substep add up to the un-instrumented wall time per substep). Two marks recorded back to back
+    # four launches of a substep add up to the un-instrumented wall time per substep). Two marks recorded back to back
     # are 3.5 us apart (event_mark_ms, informational): that spacing is what an EMPTY pass costs the instrumented run, it
     # is not a cost inside an interval that holds a kernel — earlier rounds subtracted it and overstated the rate by 10 %.
     interval = timings["g2p"] / k_ts
@@ -323,7 +323,9 @@ def main():
             "build": {"info": build_info, "WGS_DEBUG": dbg_env, "transport_note": transport_note},
             "validation_sharded": validation_sharded,
             "notes": "the hash table of block ids is rebuilt (k_bin instead of k_rebin, ~+0.25 ms once at this size) on the first substep, every "
-                     "1024 substeps and whenever three quarters of the ids are handed out; none of these falls inside this timed region",
+                     "1024 substeps and whenever three quarters of the ids are handed out; none of these falls inside this timed region. "
+                     "pass_ms_per_step: on single-domain data the grid update runs as workgroups of the P2G launch (DESIGN.md 4): 'p2g' holds both, "
+                     "'grid_update' is then an empty interval between two event marks (~0.004 ms, like every pass without a launch)",
         }
 
     # ---- CPU baseline + validation of the HIP path on the bench data itself (rank 0, N = 1)
@@ -373,7 +375,7 @@ def main():
                                       "the C2 cube after it landed: lowered onto the floor with a -3 cells/s impact, 200 substeps before the timed region")
             sc = scenes.config_scene("c3")
             extra["c3"] = slim(measure(env, sc, 1, 0, k, w, "k_g2p_pair<plastic>"), sc["name"])
-            # the size the reference itself ships (its scenes hold 75 k - 490 k particles): latency-bound here, five dependent launches
+            # the size the reference itself ships (its scenes hold 75 k - 490 k particles): latency-bound here, four dependent launches
             sc = scenes.reference_sand3()
             extra["sand3_202k"] = slim(measure(env, sc, 1, 0, k, w, "k_g2p_pair<plastic>", settle=100), sc["name"] + ", 100 substeps before the timed region")
             del sc
