@@ -756,7 +756,11 @@ template <bool TS> wgs_status enqueue_substep(wgs_data *d, int ts_slot, int part
             // (8, 16, 32 or 64 workgroups per CU at most: the same times at C2 / C3 / C5)
             const uint32_t gu_wgs = !fuse_gu ? 0u : std::min((uint32_t)grid_for(d, 8), std::max((uint32_t)grid_for(d, 1), ((d->seen_nblocks + NW - 1u) / NW + 7u) & ~7u));
             d->gu_fused = fuse_gu;
-            if (d->cpic && (big_one_way || (d->last_ncpic != UINT32_MAX && d->last_ncpic >= P2G_PAIR_MIN_BLOCKS)) && !(dev.dbg & 8192u)) {
+            // Large TWO-WAY simulations never pair: the kernel would take the two-way CPIC body's 225 registers and the plain
+            // body — nearly every block — would run at two thirds of its occupancy (C4, 8 M particles: P2G 416 -> 347 us
+            // with the two launches). Bit-identical either way (the same body text under -ffp-contract=on).
+            const bool big_two_way = d->two_way && n >= P2G_SMALL_BUDGET_MIN_PARTICLES;
+            if (d->cpic && !big_two_way && (big_one_way || (d->last_ncpic != UINT32_MAX && d->last_ncpic >= P2G_PAIR_MIN_BLOCKS)) && !(dev.dbg & 8192u)) {
                 // many blocks near colliders (as of the last wgs_sync): both bodies in one launch (k_p2g_pair)
                 const dim3 pair_grid(2u * p2g_wgs + gu_wgs);
                 if (d->two_way && fuse_gu) hipLaunchKernelGGL((k_p2g_pair<D, true, 1, 2>), pair_grid, p2g_block, 0, s, dev, side, epoch, p2g_wgs);
