@@ -1125,6 +1125,48 @@ def test_dynamic_bodies_on_sharded_data(hip_libs, name):
         assert err < tol, (f, err)
 
 
+@pytest.mark.parametrize("dim", [3, 2])
+def test_sharded_substep_with_pack_and_interior_grid_update_inside_the_p2g_launch_is_bit_identical(hip_libs, dim, monkeypatch):
+    """Inside wgs_sharded_step the waves that pack the outgoing messages and the grid update of the interior blocks ride in
+    the P2G launch (GU = 3: slabs handed over word by word); the interface layers are updated after the
+    exchange. WGS_DEBUG = 262144 brings the k_pack_face launch and the one grid update back: the same bits on every slab
+    (3 slabs in lockstep, a floor, particles migrating, a table rebuild inside the run)."""
+    from helpers import pipeline
+    from wgsparkl_amd.sharded import native_lockstep
+    monkeypatch.setenv("WGS_REHASH_PERIOD", "64")
+    world = 3
+
+    def run():
+        if dim == 3:
+            sc = scenes.config_scene("c2", world, None, "weak", n_side=24)
+            sc["particles"].pos[:, 1] -= 5.6                  # in contact with the floor: both P2G bodies run
+        else:
+            sc = scenes.elastic_block_2d(nx=48 * world, ny=40, with_floor=True)
+            sc["particles"].pos[:, 1] -= 4.6
+        ps = sc["particles"]
+        rng = np.random.default_rng(8)
+        ps.vel[:] = rng.normal(0.0, 2.0, ps.vel.shape).astype(np.float32)
+        ps.vel[:, 0] += 8.0
+        pipe = pipeline(dim)
+        shards, part = _native_slabs(sc, world, pipe)
+        native_lockstep(pipe, shards, 40)
+        for sh in shards:
+            sh.sync()                                          # (the near-collider lists are seen here: paired launches from now on)
+        native_lockstep(pipe, shards, 40)
+        for sh in shards:
+            sh.sync()
+        return [sh.export() for sh in shards]
+    a = run()
+    monkeypatch.setenv("WGS_DEBUG", "262144")
+    b = run()
+    monkeypatch.delenv("WGS_DEBUG")
+    for x, y in zip(a, b):
+        ox, oy = np.argsort(x["ids"]), np.argsort(y["ids"])    # (the storage order of a slab follows the arrival order of its guests)
+        assert np.array_equal(x["ids"][ox], y["ids"][oy])
+        for f in ("pos", "vel", "def_grad", "affine"):
+            assert np.array_equal(x[f][ox], y[f][oy]), f
+
+
 @pytest.mark.parametrize("world,dim", [(2, 3), (3, 3), (4, 3), (2, 2)])
 def test_native_lockstep_matches_single_domain(hip_libs, world, dim, monkeypatch):
     """wgs_sharded_step_lockstep — the C++ driver of the substep protocol that wgs_sharded_step runs per rank over

@@ -102,6 +102,7 @@ struct wgs_data {
     uint64_t device_bytes = 0;
     uint32_t sticky_errors = 0;
     uint32_t last_nblocks = 0;
+    uint32_t nv_hint = 0;              // sharded data: particles this slab holds as the host last saw them (the launch bound is the capacity); picks the G2P chunk count per wave
     uint32_t seen_nblocks = 0;         // active blocks as last seen by the host, wgs_sync or the pinned watch (0: not yet): sizes the P2G grid
     uint32_t last_ncpic = UINT32_MAX;  // near-collider list length at the last wgs_sync (picks the P2G launch shape and G2P's register budget)
     uint32_t last_nvisit = UINT32_MAX; // visit-list length at the last wgs_sync (sizes the list half of k_g2p_pair)
@@ -130,6 +131,7 @@ struct wgs_data {
     hipEvent_t watch_event = nullptr;
     bool watch_pending = false, force_rehash = false, auto_grow = true;
     bool gu_fused = false;   // this substep's grid update rode in its P2G launch
+    bool shard_fused = false; // sharded substep: the pack waves and the interior blocks' grid update rode in the P2G launch
     uint32_t grid_grown = 0;            // times the block capacity was doubled
     uint32_t watch_skips = 0;
     uint32_t cdf_generation = 1;        // bumped whenever cached node cdfs / block classes become invalid (kernels_sort.h regroup_block)
@@ -282,6 +284,7 @@ wgs_status maintain_grid(wgs_data *d) {
     d->watch_skips = 0;
     d->watch_pending = false;
     const uint32_t nblocks = d->watch[CTR_NBLOCKS], nphys = d->watch[CTR_NPHYS], cap = d->dev.cap;
+    if (d->dev.sharded) d->nv_hint = std::max(d->watch[CTR_NV], d->watch[CTR_NV + CTR_SET]);
     // The observation is up to three calls old (two skips + the call that made it): a scene that is growing is judged by
     // where it will be by then at the rate of its last two observations, not by where it was.
     const uint32_t rate = nblocks > d->seen_nblocks && d->seen_nblocks != 0u ? nblocks - d->seen_nblocks : 0u;
@@ -660,11 +663,13 @@ template <bool TS> wgs_status enqueue_substep(wgs_data *d, int ts_slot, int part
     };
     const uint32_t epoch = (uint32_t)(d->substeps + 1);
     d->gu_fused = false;
+    if (part != 2) d->shard_fused = false;   // (part 2 of a sharded substep consumes what its part 1 decided)
     dev.ctr_set = (uint32_t)(d->substeps & 1u);  // sharded runs: the set of particle counters this substep reads (layout.h)
     // chunks of 64 sorted particles per wave of the fused G2P (kernels_transfer.h); the sort files the visit list by it
     // (2D: the body keeps no state of the chunk after the next one — at most two chunks per wave)
-    dev.g2p_npass = (D == 3 && dev.nv >= G2P_MANY_PASS_MIN_PARTICLES) ? (uint32_t)G2P_MANY_PASSES
-                    : (dev.nv >= G2P_TWO_PASS_MIN_PARTICLES || (dev.dbg & 131072u)) ? 2u : 1u;
+    const uint32_t nv_now = dev.sharded && d->nv_hint != 0u ? std::min(d->nv_hint, dev.nv) : dev.nv;   // (a slab launches for its capacity)
+    dev.g2p_npass = (D == 3 && nv_now >= G2P_MANY_PASS_MIN_PARTICLES) ? (uint32_t)G2P_MANY_PASSES
+                    : (nv_now >= G2P_TWO_PASS_MIN_PARTICLES || (dev.dbg & 131072u)) ? 2u : 1u;
     // Steady state: the buffer is in the sorted order of the previous substep, whose block ids, cell ids
     // (perm_cell) and neighbour links are still valid, so the particles are re-binned RELATIVE to their old
     // block (k_rebin: no hash lookups except for the few particles that changed block). The full k_bin runs
@@ -752,38 +757,61 @@ template <bool TS> wgs_status enqueue_substep(wgs_data *d, int ts_slot, int part
             // them; a P2G launch before it hands its slabs over the same way (GU = 1). Same results as the launch of its own
             // (dbg bit 18 brings that back): the same sums in the same order.
             const bool fuse_gu = part == 0 && !dev.sharded && !(dev.dbg & 262144u);
+            // Inside wgs_sharded_step (part 1 of a slab's substep): behind the P2G workgroups ride the waves that pack the
+            // outgoing messages (no k_pack_face launch) and the grid update of the INTERIOR blocks — everything that does
+            // not wait for the exchange; the interface layers are updated after it (GU = 3).
+            const bool fuse_shard = part == 1 && d->in_sharded_step && d->link && d->link->attached && !(dev.dbg & 262144u);
+            const int gum = fuse_gu ? 2 : fuse_shard ? 3 : 0;   // what rides in the LAST P2G launch of this substep
             const uint32_t NW = (uint32_t)P2GCfg<D>::NW;
             // (8, 16, 32 or 64 workgroups per CU at most: the same times at C2 / C3 / C5)
-            const uint32_t gu_wgs = !fuse_gu ? 0u : std::min((uint32_t)grid_for(d, 8), std::max((uint32_t)grid_for(d, 1), ((d->seen_nblocks + NW - 1u) / NW + 7u) & ~7u));
+            const uint32_t gu_wgs = gum == 0 ? 0u : std::min((uint32_t)grid_for(d, 8), std::max((uint32_t)grid_for(d, 1), ((d->seen_nblocks + NW - 1u) / NW + 7u) & ~7u));
+            // pack waves: one per interface block as the host last saw the grid (a face holds a fraction of the active
+            // blocks), plus a few for the guests
+            uint32_t npack = 0u, npack_blk = 0u;
+            if (fuse_shard && (d->link->has_lower || d->link->has_upper)) {
+                npack_blk = std::max(64u, std::min(2048u, d->seen_nblocks ? d->seen_nblocks : 2048u));
+                const uint32_t nmig = std::max(1u, std::min(64u, (2u * d->link->mig_cap + 63u) / 64u));
+                npack = (npack_blk + nmig + NW - 1u) / NW;
+            }
             d->gu_fused = fuse_gu;
+            d->shard_fused = fuse_shard;
+            const uint32_t ride = npack + gu_wgs;   // workgroups behind the P2G workgroups
             // Large TWO-WAY simulations never pair: the kernel would take the two-way CPIC body's 225 registers and the plain
             // body — nearly every block — would run at two thirds of its occupancy (C4, 8 M particles: P2G 416 -> 347 us
             // with the two launches). Bit-identical either way (the same body text under -ffp-contract=on).
             const bool big_two_way = d->two_way && n >= P2G_SMALL_BUDGET_MIN_PARTICLES;
+#define WGS_P2G_PAIR(TW, WPE)                                                                                                          \
+    do {                                                                                                                               \
+        const dim3 pg(2u * p2g_wgs + ride);                                                                                            \
+        if (gum == 2) hipLaunchKernelGGL((k_p2g_pair<D, TW, WPE, 2>), pg, p2g_block, 0, s, dev, side, epoch, p2g_wgs, npack, npack_blk);      \
+        else if (gum == 3) hipLaunchKernelGGL((k_p2g_pair<D, TW, WPE, 3>), pg, p2g_block, 0, s, dev, side, epoch, p2g_wgs, npack, npack_blk); \
+        else hipLaunchKernelGGL((k_p2g_pair<D, TW, WPE, 0>), pg, p2g_block, 0, s, dev, side, epoch, p2g_wgs, npack, npack_blk);               \
+    } while (0)
+#define WGS_P2G_LAST(CP, TW, PC, FILTER)                                                                                                        \
+    do {                                                                                                                                        \
+        const dim3 lg(p2g_wgs + ride);                                                                                                          \
+        if (gum == 2) hipLaunchKernelGGL((k_p2g<D, CP, TW, PC, 2>), lg, p2g_block, 0, s, dev, side, FILTER, epoch, p2g_wgs, npack, npack_blk);        \
+        else if (gum == 3) hipLaunchKernelGGL((k_p2g<D, CP, TW, PC, 3>), lg, p2g_block, 0, s, dev, side, FILTER, epoch, p2g_wgs, npack, npack_blk);   \
+        else hipLaunchKernelGGL((k_p2g<D, CP, TW, PC, 0>), lg, p2g_block, 0, s, dev, side, FILTER, epoch, p2g_wgs, npack, npack_blk);                 \
+    } while (0)
             if (d->cpic && !big_two_way && (big_one_way || (d->last_ncpic != UINT32_MAX && d->last_ncpic >= P2G_PAIR_MIN_BLOCKS)) && !(dev.dbg & 8192u)) {
                 // many blocks near colliders (as of the last wgs_sync): both bodies in one launch (k_p2g_pair)
-                const dim3 pair_grid(2u * p2g_wgs + gu_wgs);
-                if (d->two_way && fuse_gu) hipLaunchKernelGGL((k_p2g_pair<D, true, 1, 2>), pair_grid, p2g_block, 0, s, dev, side, epoch, p2g_wgs);
-                else if (d->two_way) hipLaunchKernelGGL((k_p2g_pair<D, true>), pair_grid, p2g_block, 0, s, dev, side, epoch, p2g_wgs);
-                else if (big_one_way && fuse_gu) hipLaunchKernelGGL((k_p2g_pair<D, false, 3, 2>), pair_grid, p2g_block, 0, s, dev, side, epoch, p2g_wgs);
-                else if (big_one_way) hipLaunchKernelGGL((k_p2g_pair<D, false, 3>), pair_grid, p2g_block, 0, s, dev, side, epoch, p2g_wgs);
-                else if (fuse_gu) hipLaunchKernelGGL((k_p2g_pair<D, false, 1, 2>), pair_grid, p2g_block, 0, s, dev, side, epoch, p2g_wgs);
-                else hipLaunchKernelGGL((k_p2g_pair<D, false>), pair_grid, p2g_block, 0, s, dev, side, epoch, p2g_wgs);
+                if (d->two_way) WGS_P2G_PAIR(true, 1);
+                else if (big_one_way) WGS_P2G_PAIR(false, 3);
+                else WGS_P2G_PAIR(false, 1);
             } else if (d->cpic) {
-                const dim3 last_grid(p2g_wgs + gu_wgs);
-                if (fuse_gu) hipLaunchKernelGGL((k_p2g<D, false, false, false, 1>), p2g_grid, p2g_block, 0, s, dev, side, 1, epoch, p2g_wgs);
-                else hipLaunchKernelGGL((k_p2g<D, false>), p2g_grid, p2g_block, 0, s, dev, side, 1, epoch, p2g_wgs);
+                // (the first of the two launches hands its slabs over like the last one when anything rides in that one)
+                if (gum != 0) hipLaunchKernelGGL((k_p2g<D, false, false, false, 1>), p2g_grid, p2g_block, 0, s, dev, side, 1, epoch, p2g_wgs, 0u, 0u);
+                else hipLaunchKernelGGL((k_p2g<D, false>), p2g_grid, p2g_block, 0, s, dev, side, 1, epoch, p2g_wgs, 0u, 0u);
                 // near-collider list: particle cdf in the prologue (the node cdfs are complete: k_setup_scatter<CDF>, or
                 // k_cdf after k_p2g_cdf with mesh colliders), then the CPIC transfer
-                if (d->two_way && fuse_gu) hipLaunchKernelGGL((k_p2g<D, true, true, true, 2>), last_grid, p2g_block, 0, s, dev, side, 2, epoch, p2g_wgs);
-                else if (d->two_way) hipLaunchKernelGGL((k_p2g<D, true, true, true>), p2g_grid, p2g_block, 0, s, dev, side, 2, epoch, p2g_wgs);
-                else if (fuse_gu) hipLaunchKernelGGL((k_p2g<D, true, false, true, 2>), last_grid, p2g_block, 0, s, dev, side, 2, epoch, p2g_wgs);
-                else hipLaunchKernelGGL((k_p2g<D, true, false, true>), p2g_grid, p2g_block, 0, s, dev, side, 2, epoch, p2g_wgs);
-            } else if (fuse_gu) {
-                hipLaunchKernelGGL((k_p2g<D, false, false, false, 2>), dim3(p2g_wgs + gu_wgs), p2g_block, 0, s, dev, side, 0, epoch, p2g_wgs);
+                if (d->two_way) WGS_P2G_LAST(true, true, true, 2);
+                else WGS_P2G_LAST(true, false, true, 2);
             } else {
-                hipLaunchKernelGGL((k_p2g<D, false>), p2g_grid, p2g_block, 0, s, dev, side, 0, epoch, p2g_wgs);
+                WGS_P2G_LAST(false, false, false, 0);
             }
+#undef WGS_P2G_PAIR
+#undef WGS_P2G_LAST
         }
         mark(4);
     }
@@ -791,10 +819,10 @@ template <bool TS> wgs_status enqueue_substep(wgs_data *d, int ts_slot, int part
         if (n > 0 && !(part == 0 && d->gu_fused)) {
             // ---- "grid_update" (single-domain simulations: done by waves of the P2G launch above)
             if (part == 0 && d->two_way)
-                hipLaunchKernelGGL((k_grid_update<D, 0, true>), dim3(grid_for(d, WGS_GU_WG_PER_CU)), dim3(256), 0, s, dev, epoch);
-            else if (part == 0) hipLaunchKernelGGL((k_grid_update<D, 0>), dim3(grid_for(d, WGS_GU_WG_PER_CU)), dim3(256), 0, s, dev, epoch);
-            else if (d->two_way) hipLaunchKernelGGL((k_grid_update<D, 3, true>), dim3(grid_for(d, WGS_GU_WG_PER_CU)), dim3(256), 0, s, dev, epoch);
-            else hipLaunchKernelGGL((k_grid_update<D, 3>), dim3(grid_for(d, WGS_GU_WG_PER_CU)), dim3(256), 0, s, dev, epoch);
+                hipLaunchKernelGGL((k_grid_update<D, 0, true>), dim3(grid_for(d, WGS_GU_WG_PER_CU)), dim3(256), 0, s, dev, epoch, 0u);
+            else if (part == 0) hipLaunchKernelGGL((k_grid_update<D, 0>), dim3(grid_for(d, WGS_GU_WG_PER_CU)), dim3(256), 0, s, dev, epoch, 0u);
+            else if (d->two_way) hipLaunchKernelGGL((k_grid_update<D, 3, true>), dim3(grid_for(d, WGS_GU_WG_PER_CU)), dim3(256), 0, s, dev, epoch, d->shard_fused ? 1u : 0u);
+            else hipLaunchKernelGGL((k_grid_update<D, 3>), dim3(grid_for(d, WGS_GU_WG_PER_CU)), dim3(256), 0, s, dev, epoch, d->shard_fused ? 1u : 0u);
         }
         mark(5);
         // sharded step: the particles that arrived with this substep's messages are advanced too (kernels_arrivals.h), by a
@@ -1124,6 +1152,7 @@ static wgs_status create_impl(wgs_pipeline *pipeline, const wgs_sim_params *para
         H2D(dev.counters + CTR_N, cnt, sizeof(cnt));
         H2D(dev.counters + CTR_N + CTR_SET, cnt, sizeof(cnt));   // (both sets: layout.h ctr_cur / ctr_next)
         dev.n = dev.nv = (uint32_t)particle_capacity;
+        d->nv_hint = n;
     }
     d->host_colliders.resize(WGS_MAX_COLLIDERS);
     memset(d->host_colliders.data(), 0, sizeof(ColliderDev) * WGS_MAX_COLLIDERS);

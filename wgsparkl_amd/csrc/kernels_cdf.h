@@ -220,7 +220,8 @@ template <int D, int NT> __device__ __forceinline__ void stage_node_cdf_tile(con
 // g2p_cdf.wgsl:39-250 for one particle (`src` = its slot in the buffer): affinity / sign bits, distance and normal
 // from the node cdfs of its block's tile (LDS image s_cdf, tile origin = block coordinates bc). Writes the
 // particle's cdf quads and stamps them with the substep.
-template <int D> __device__ inline void particle_cdf_update(const Dev &d, float *buf, uint32_t src, const NodeCdf *s_cdf, const int *bc,
+// AGENT: the quads are written through (agent scope) — a P2G launch whose pack waves copy a guest's record in the same launch
+template <int D, bool AGENT = false> __device__ inline void particle_cdf_update(const Dev &d, float *buf, uint32_t src, const NodeCdf *s_cdf, const int *bc,
                                                             uint32_t epoch) {
     constexpr int BW = Dim<D>::BW, TW = Dim<D>::TW;
     constexpr int N = D + 1;
@@ -334,14 +335,18 @@ template <int D> __device__ inline void particle_cdf_update(const Dev &d, float 
             aff = 0u;  // default_cdf()
         }
     }
-    if constexpr (D == 3) {
-        stq(buf, npad, P::CDF0, src, make_float4(nrm[0], nrm[1], nrm[2], dist));
-        stq(buf, npad, P::CDF1, src, make_float4(0.f, 0.f, 0.f, __uint_as_float(aff)));
+    const float4 q0 = D == 3 ? make_float4(nrm[0], nrm[1], nrm[2], dist) : make_float4(nrm[0], nrm[1], dist, __uint_as_float(aff));
+    const float4 q1 = D == 3 ? make_float4(0.f, 0.f, 0.f, __uint_as_float(aff)) : make_float4(0.f, 0.f, 0.f, 0.f);
+    if constexpr (AGENT) {
+        const __amdgpu_buffer_rsrc_t pr = particle_rsrc<D>(buf, npad);
+        st_agent(pr, quad_off(npad, P::CDF0, src), q0);
+        st_agent(pr, quad_off(npad, P::CDF1, src), q1);
+        __hip_atomic_store(stamp_ptr<D>(buf, npad, src), epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     } else {
-        stq(buf, npad, P::CDF0, src, make_float4(nrm[0], nrm[1], dist, __uint_as_float(aff)));
-        stq(buf, npad, P::CDF1, src, make_float4(0.f, 0.f, 0.f, 0.f));
+        stq(buf, npad, P::CDF0, src, q0);
+        stq(buf, npad, P::CDF1, src, q1);
+        ststamp<D>(buf, npad, src, epoch);
     }
-    ststamp<D>(buf, npad, src, epoch);
 }
 
 // The three CDF passes of a substep in ONE launch, one single-wave workgroup per active block (every active

@@ -105,16 +105,19 @@ template <int D> __device__ inline float4 gather_slabs(const Dev &d, uint32_t b,
 // slabs and appended to the outgoing messages; (b) the guests — the particles the last
 // G2P launch found outside the core range (Dev::leavers) — are copied into the message of the face they crossed. They
 // are NOT vacated here: this rank's fused G2P drops them (their block lies outside the core range).
-template <int D> __global__ __launch_bounds__(64) void k_pack_face(Dev d, int side, uint32_t epoch, uint32_t nblk_wgs) {
+// One body for the launch of its own (k_pack_face: worker = workgroup of one wave) and for the pack waves that ride in the
+// P2G launch (INLAUNCH: worker = wave behind the P2G workgroups; the slabs are then waited for word by word and gathered
+// with agent-scope loads, like gu_waves in kernels_transfer.h): workers [0, nblk_wk) walk the interface-block list, the
+// others copy the guests.
+template <int D, bool INLAUNCH> __device__ __forceinline__ void pack_face_body(const Dev &d, int side, uint32_t epoch, uint32_t wk, uint32_t nblk_wk, uint32_t nwk, int lane) {
     using H = HaloCfg<D>;
     constexpr int BW = Dim<D>::BW, BS = Dim<D>::BSHIFT, TW = Dim<D>::TW, TILE = Dim<D>::TILE, NN = Dim<D>::NNBR;
     constexpr int NQ = Pl<D>::NQ, RF = particle_record_floats<D>();
-    const int lane = threadIdx.x;
-    if (blockIdx.x == 0 && lane < 2 && d.msg.out[lane])   // layout of this rank's particle records (checked by the receiver, k_g2p_arrivals)
+    if (wk == 0 && lane < 2 && d.msg.out[lane])   // layout of this rank's particle records (checked by the receiver, k_g2p_arrivals)
         reinterpret_cast<uint32_t *>(d.msg.out[lane])[2] = d.uniform ? MSG_FLAG_UNIFORM : 0u;
-    if (blockIdx.x < nblk_wgs) {
+    if (wk < nblk_wk) {
         const uint32_t nl = min(d.counters[CTR_NHALO], d.cap);
-        for (uint32_t a = blockIdx.x; a < nl; a += nblk_wgs) {
+        for (uint32_t a = wk; a < nl; a += nblk_wk) {
             // the sort left everything needed in the list entry: block id, key and the slabs its nodes are gathered from
             // (its "-" neighbours that hold particles)
             uint32_t ew = NONE;
@@ -129,14 +132,33 @@ template <int D> __global__ __launch_bounds__(64) void k_pack_face(Dev d, int si
             // all slab loads of the node issued together, summed in the fixed order of the grid update (gather_slabs)
             const int l[3] = {lane & (BW - 1), (lane >> BS) & (BW - 1), D == 3 ? (lane >> (2 * BS)) : 0};
             float4 part[NN];
+            if constexpr (INLAUNCH) {   // the source slabs are being written by P2G workgroups of this very launch
+                if (lane < NN && src != NONE) {
+                    uint32_t spins = 0u;
+                    while (__hip_atomic_load(&d.slab_epoch[src], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch) {
+                        __builtin_amdgcn_s_sleep(2);
+                        if (++spins == (1u << 20)) {
+                            atomicOr(&d.counters[CTR_ERRORS], ERRBIT_HANDOVER);
+                            break;
+                        }
+                    }
+                }
+                asm volatile("" ::: "memory");
+            }
 #pragma unroll
             for (int o = 0; o < NN; o++) {
                 const int tt[3] = {l[0] + BW * (o & 1), l[1] + BW * ((o >> 1) & 1), l[2] + BW * ((o >> 2) & 1)};
                 const bool in_tile = tt[0] < TW && tt[1] < TW && (D == 2 || tt[2] < TW);
-                const uint32_t so = __shfl(src, o);
-                part[o] = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (in_tile && so != NONE && (((m.send_lo | m.send_hi) >> tag) & 1u))
-                    part[o] = d.slab[(size_t)so * TILE + slab_pos<D>(o, l)];
+                const bool wanted = in_tile && (((m.send_lo | m.send_hi) >> tag) & 1u);
+                if constexpr (INLAUNCH) {
+                    const uint32_t so = (uint32_t)__builtin_amdgcn_readlane((int)src, o);   // (wave-uniform: the slab's descriptor lives in scalar registers)
+                    part[o] = ld_agent(slab_rsrc(&d.slab[(size_t)(so != NONE ? so : 0u) * TILE], so != NONE ? TILE * 16u : 0u),
+                                       wanted ? slab_pos<D>(o, l) * 16u : 0x7ffffff0u);   // (no source / not wanted: zeros, no access)
+                } else {
+                    const uint32_t so = __shfl(src, o);
+                    part[o] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (wanted && so != NONE) part[o] = d.slab[(size_t)so * TILE + slab_pos<D>(o, l)];
+                }
             }
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
@@ -170,7 +192,7 @@ template <int D> __global__ __launch_bounds__(64) void k_pack_face(Dev d, int si
     const uint32_t n = num_slots(d);
     const uint32_t nl = min(d.counters[CTR_NLEAVE], d.leavers_cap);
     const uint32_t nl64 = (nl + 63u) & ~63u;   // (whole waves: the slots of a wave's guests are handed out with one atomic per face)
-    for (uint32_t t = (blockIdx.x - nblk_wgs) * 64u + (uint32_t)lane; t < nl64; t += (gridDim.x - nblk_wgs) * 64u) {
+    for (uint32_t t = (wk - nblk_wk) * 64u + (uint32_t)lane; t < nl64; t += (nwk - nblk_wk) * 64u) {
         int face = -1;
         uint32_t i = 0, pid = PID_DEAD;
         if (t < nl) {
@@ -180,6 +202,25 @@ template <int D> __global__ __launch_bounds__(64) void k_pack_face(Dev d, int si
                 const float4 xm = ldq(buf, npad, Pl<D>::XM, i);
                 const int bx = assoc_cell(xm.x, d.h, d.inv_h, d.h_pow2 != 0u) >> BS;
                 face = bx < d.shard_lo ? 0 : (bx >= d.shard_hi ? 1 : -1);
+                if constexpr (INLAUNCH) {
+                    // A guest of a block near a collider gets its cdf quads rewritten by the CPIC prologue of this very launch
+                    // (p2g_body.inc): its record is copied once its block's slab word says the block is done.
+                    if (face >= 0 && d.n_colliders != 0u) {
+                        int gb[3] = {bx, assoc_cell(xm.y, d.h, d.inv_h, d.h_pow2 != 0u) >> BS, 0};
+                        if constexpr (D == 3) gb[2] = assoc_cell(xm.z, d.h, d.inv_h, d.h_pow2 != 0u) >> BS;
+                        const uint32_t gid = hmap_find(d, pack_key<D>(gb), epoch);
+                        if (gid != NONE) {
+                            uint32_t spins = 0u;
+                            while (__hip_atomic_load(&d.slab_epoch[gid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch) {
+                                __builtin_amdgcn_s_sleep(2);
+                                if (++spins == (1u << 20)) {
+                                    atomicOr(&d.counters[CTR_ERRORS], ERRBIT_HANDOVER);
+                                    break;
+                                }
+                            }
+                        }
+                    }
+                }
             }
         }
         uint32_t slot = NONE;
@@ -206,12 +247,17 @@ template <int D> __global__ __launch_bounds__(64) void k_pack_face(Dev d, int si
         float *rec = msg_particles<D>(msg, d.msg.halo_cap) + (size_t)slot * RF;
 #pragma unroll
         for (int qd = 0; qd < NQ; qd++) {
-            const float4 v = ldq(buf, npad, qd, i);
+            // (INLAUNCH: the cdf quads may have been written through by a P2G workgroup of another XCD in this launch)
+            const float4 v = INLAUNCH ? ld_agent(particle_rsrc<D>(const_cast<float *>(buf), npad), quad_off(npad, qd, i)) : ldq(buf, npad, qd, i);
             rec[qd * 4 + 0] = v.x; rec[qd * 4 + 1] = v.y; rec[qd * 4 + 2] = v.z; rec[qd * 4 + 3] = v.w;
         }
         rec[NQ * 4] = __uint_as_float(pid);
-        rec[NQ * 4 + 1] = __uint_as_float(ldstamp<D>(buf, npad, i));
+        rec[NQ * 4 + 1] = __uint_as_float(INLAUNCH ? __hip_atomic_load(stamp_ptr<D>(const_cast<float *>(buf), npad, i), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                                                   : ldstamp<D>(buf, npad, i));
     }
+}
+template <int D> __global__ __launch_bounds__(64) void k_pack_face(Dev d, int side, uint32_t epoch, uint32_t nblk_wgs) {
+    pack_face_body<D, false>(d, side, epoch, blockIdx.x, nblk_wgs, gridDim.x, (int)threadIdx.x);
 }
 
 // The halo area of a message is an OPEN-ADDRESSING TABLE of records keyed by (block key, pair): the sender claims the slot

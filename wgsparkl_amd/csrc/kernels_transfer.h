@@ -74,7 +74,9 @@ template <int D> __device__ __forceinline__ float4 node_velocity(const float4 su
 // dispatch order and wait only for P2G workgroups: nothing they wait for can be waiting for a slot of theirs.
 // TWOWAY: the node impulses P2G's CPIC body left in imp_slab are gathered the same way, converted to fixed point and summed
 // per body — in LDS first, then at most 16 x 6 global atomics per workgroup, as k_grid_update<D, PHASE, true> does.
-template <int D, bool TWOWAY = false> __device__ __forceinline__ void gu_waves(const Dev &d, uint32_t epoch, uint32_t wave, uint32_t nwaves, int lane) {
+// INTERIOR (one slab of a decomposition): only the blocks whose layer neither receives a neighbour's sums nor travels to
+// one — the others wait for the exchange and are updated by k_grid_update<D, 3> with IFACE_ONLY set.
+template <int D, bool TWOWAY = false, bool INTERIOR = false> __device__ __forceinline__ void gu_waves(const Dev &d, uint32_t epoch, uint32_t wave, uint32_t nwaves, int lane) {
     __shared__ int32_t s_body_imp[TWOWAY ? 128 : 1];
     if constexpr (TWOWAY) {
         for (uint32_t i = threadIdx.x; i < 128u; i += blockDim.x) s_body_imp[i] = 0;
@@ -88,6 +90,12 @@ template <int D, bool TWOWAY = false> __device__ __forceinline__ void gu_waves(c
     const int l[3] = {lane & (BW - 1), (lane >> BS) & (BW - 1), D == 3 ? (lane >> (2 * BS)) : 0};
     for (uint32_t a = wave; a < B; a += nwaves) {
         const uint32_t b = d.active[a];
+        if constexpr (INTERIOR) {
+            int bc[3] = {0, 0, 0};
+            unpack_key<D>(d.act_info[a].y, bc);
+            const IfaceMasks m = iface_masks<D>(d, bc[0]);
+            if ((m.recv | m.send_lo | m.send_hi) != 0u) continue;   // (wave-uniform)
+        }
         const uint32_t mysrc = lane < NN ? d.act_src[a * 8u + (uint32_t)lane] : NONE;   // (k_regroup: "-" neighbour with particles, else NONE)
         if (mysrc != NONE) {
             // (bounded: ~a second. Every block the sort counted particles for is visited by a P2G workgroup of this launch,
@@ -178,12 +186,25 @@ template <int D, bool TWOWAY = false> __device__ __forceinline__ void gu_waves(c
 // block's word in slab_epoch); 2 = also, the workgroups from index `nblk` on are not P2G workgroups but run the grid
 // update (gu_waves below) — they are dispatched after every P2G workgroup and gather a node as soon as the slabs that
 // cover it are complete: no grid-update launch.
+// GU = 3 (one slab of a decomposition, inside wgs_sharded_step): behind the P2G workgroups first `npack` workgroups whose
+// waves pack the outgoing messages (kernels_shard.h pack_face_body; `npack_blk` of their waves walk the interface-block
+// list, the others copy the guests), then the grid update of the INTERIOR blocks; the interface layers are updated after
+// the exchange (k_grid_update<D, 3> with iface_only).
 template <int D, bool CPIC, bool TWOWAY = false, bool PCDF = false, int GU = 0>
-__global__ __launch_bounds__(P2GCfg<D>::NW * 64) void k_p2g(Dev d, int side, int filter, uint32_t epoch, uint32_t nblk) {
+__global__ __launch_bounds__(P2GCfg<D>::NW * 64) void k_p2g(Dev d, int side, int filter, uint32_t epoch, uint32_t nblk, uint32_t npack, uint32_t npack_blk) {
     using Cfg = P2GCfg<D>;
     if constexpr (GU == 2) {
         if (blockIdx.x >= nblk) {
             gu_waves<D, TWOWAY>(d, epoch, (blockIdx.x - nblk) * Cfg::NW + (threadIdx.x >> 6), (gridDim.x - nblk) * Cfg::NW, (int)(threadIdx.x & 63u));
+            return;
+        }
+    }
+    if constexpr (GU == 3) {
+        if (blockIdx.x >= nblk) {
+            const uint32_t t = blockIdx.x - nblk, w = threadIdx.x >> 6;
+            const int lane = (int)(threadIdx.x & 63u);
+            if (t < npack) pack_face_body<D, true>(d, side, epoch, t * Cfg::NW + w, npack_blk, npack * Cfg::NW, lane);
+            else gu_waves<D, TWOWAY, true>(d, epoch, (t - npack) * Cfg::NW + w, (gridDim.x - nblk - npack) * Cfg::NW, lane);
             return;
         }
     }
@@ -206,6 +227,7 @@ __global__ __launch_bounds__(P2GCfg<D>::NW * 64) void k_p2g(Dev d, int side, int
 #define P2G_TWOWAY TWOWAY
 #define P2G_PCDF PCDF
 #define P2G_HANDOVER (GU != 0)
+#define P2G_GUESTS_INLAUNCH (GU == 3)
 #define P2G_BLK blockIdx.x
 #define P2G_NBLK nblk
 #include "p2g_body.inc"
@@ -215,6 +237,7 @@ __global__ __launch_bounds__(P2GCfg<D>::NW * 64) void k_p2g(Dev d, int side, int
 #undef P2G_BLK
 #undef P2G_NBLK
 #undef P2G_HANDOVER
+#undef P2G_GUESTS_INLAUNCH
 }
 
 // Scenes with MANY blocks near colliders: the plain body (filter 1) and the CPIC body over the near-collider list
@@ -235,11 +258,20 @@ __global__ __launch_bounds__(P2GCfg<D>::NW * 64) void k_p2g(Dev d, int side, int
 // offered the small budget.
 // (GU: as for k_p2g; the grid is `half` CPIC + `half` plain workgroups, then the grid-update workgroups)
 template <int D, bool TWOWAY, int WPE = 1, int GU = 0>
-__global__ __launch_bounds__(P2GCfg<D>::NW * 64, WPE) void k_p2g_pair(Dev d, int side, uint32_t epoch, uint32_t half) {
+__global__ __launch_bounds__(P2GCfg<D>::NW * 64, WPE) void k_p2g_pair(Dev d, int side, uint32_t epoch, uint32_t half, uint32_t npack, uint32_t npack_blk) {
     using Cfg = P2GCfg<D>;
     if constexpr (GU == 2) {
         if (blockIdx.x >= 2u * half) {
             gu_waves<D, TWOWAY>(d, epoch, (blockIdx.x - 2u * half) * Cfg::NW + (threadIdx.x >> 6), (gridDim.x - 2u * half) * Cfg::NW, (int)(threadIdx.x & 63u));
+            return;
+        }
+    }
+    if constexpr (GU == 3) {
+        if (blockIdx.x >= 2u * half) {
+            const uint32_t t = blockIdx.x - 2u * half, w = threadIdx.x >> 6;
+            const int lane = (int)(threadIdx.x & 63u);
+            if (t < npack) pack_face_body<D, true>(d, side, epoch, t * Cfg::NW + w, npack_blk, npack * Cfg::NW, lane);
+            else gu_waves<D, TWOWAY, true>(d, epoch, (t - npack) * Cfg::NW + w, (gridDim.x - 2u * half - npack) * Cfg::NW, lane);
             return;
         }
     }
@@ -258,6 +290,7 @@ __global__ __launch_bounds__(P2GCfg<D>::NW * 64, WPE) void k_p2g_pair(Dev d, int
     __shared__ NodeCdf s_ncdf[TILE];
     __shared__ float4 s_imp[TWOWAY ? Cfg::NW : 1][TWOWAY ? IMPQ : 1][TWOWAY ? TILE : 1];
 #define P2G_HANDOVER (GU != 0)
+#define P2G_GUESTS_INLAUNCH (GU == 3)
 #define P2G_NBLK half
     if (blockIdx.x >= half) {
         const int filter = 1;
@@ -284,6 +317,7 @@ __global__ __launch_bounds__(P2GCfg<D>::NW * 64, WPE) void k_p2g_pair(Dev d, int
     }
 #undef P2G_NBLK
 #undef P2G_HANDOVER
+#undef P2G_GUESTS_INLAUNCH
 }
 
 // ------------------------------------------------------------ grid update
@@ -310,7 +344,7 @@ template <int D> __device__ inline float4 gather_slabs(const Dev &d, uint32_t b,
     return sum;
 }
 
-template <int D, int PHASE, bool TWOWAY = false> __global__ __launch_bounds__(256) void k_grid_update(Dev d, uint32_t epoch) {
+template <int D, int PHASE, bool TWOWAY = false> __global__ __launch_bounds__(256) void k_grid_update(Dev d, uint32_t epoch, uint32_t iface_only) {
     constexpr int BW = Dim<D>::BW, BS = Dim<D>::BSHIFT, TW = Dim<D>::TW, TILE = Dim<D>::TILE, NN = Dim<D>::NNBR;
     const uint32_t B = min(d.counters[CTR_NBLOCKS], d.cap);
     const uint32_t total = B * NPB;
@@ -329,6 +363,14 @@ template <int D, int PHASE, bool TWOWAY = false> __global__ __launch_bounds__(25
     for (uint32_t t = blockIdx.x * 256 + threadIdx.x; t < total; t += gridDim.x * 256) {
         const uint32_t b = d.active[t >> 6], ln = t & 63u;
         const uint32_t node = b * NPB + ln;
+        if constexpr (PHASE == 3) {
+            if (iface_only) {   // the interior blocks were updated by waves of the P2G launch (gu_waves<.., INTERIOR>)
+                int kc[3] = {0, 0, 0};
+                unpack_key<D>(d.block_key[b], kc);
+                const IfaceMasks im = iface_masks<D>(d, kc[0]);
+                if ((im.recv | im.send_lo | im.send_hi) == 0u) continue;   // (wave-uniform: a wave is one block)
+            }
+        }
         if (ln == 0u) d.block_acc[b] = 0u;  // the sort's per-block accumulator is zero at rest (last read: k_regroup)
         int l[3];
         l[0] = ln & (BW - 1);

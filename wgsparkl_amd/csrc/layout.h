@@ -364,6 +364,15 @@ template <int D> __device__ inline void ststamp(float *base, uint32_t npad, uint
     asm volatile("" : "+v"(off));
     *reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(base) + off) = e;
 }
+// A descriptor over one whole particle buffer (< 4 GiB by construction) for the agent-scope accesses of values handed over
+// inside a launch (st_agent / ld_agent above): quad q of slot i sits at byte (q * npad + i) * 16.
+template <int D> __device__ inline __amdgpu_buffer_rsrc_t particle_rsrc(float *base, uint32_t npad) {
+    return __builtin_amdgcn_make_buffer_rsrc(base, 0, ((uint32_t)Pl<D>::NQ * 4u + 2u) * npad * 4u, 0x00020000);
+}
+__device__ inline uint32_t quad_off(uint32_t npad, int q, uint32_t i) { return ((uint32_t)q * npad + i) * 16u; }
+template <int D> __device__ inline uint32_t *stamp_ptr(float *base, uint32_t npad, uint32_t i) {
+    return reinterpret_cast<uint32_t *>(base) + ((size_t)((uint32_t)Pl<D>::NQ * 4u + 1u) * npad + i);
+}
 template <int D> __device__ inline void stpid(float *base, uint32_t npad, uint32_t i, uint32_t pid) {
     uint32_t off = ((uint32_t)Pl<D>::NQ * 4u * npad + i) * 4u;
     asm volatile("" : "+v"(off));
