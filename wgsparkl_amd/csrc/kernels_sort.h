@@ -156,75 +156,110 @@ template <int D> __global__ __launch_bounds__(SORT_THREADS) void k_bin(Dev d, in
 // b * 64 + new local cell and the blocks to activate are b's neighbour links of the previous substep —
 // no hash lookup, no LDS set. Only particles that changed block go through the hash map, and only particles
 // that changed CELL are pushed on a list.
+// REBIN_K particles per thread (slices of SORT_THREADS consecutive slots, so every slice is coalesced and a wave's 64 lanes
+// are 64 consecutive sorted particles — one or two blocks): the kernel's life is one dependent chain per wave (sort entry ->
+// block key -> links -> stamps / atomics, ~4.5 us at full occupancy), so K slices with all their first loads in flight
+// together cost about one chain. Measured (sort pass, A/B on one box): K = 2: C5 256 -> 220 us, C4 154 -> ~140 us, C2 25.0 -> 24.1 us;
+// K = 4: 224 / 25.1; K = 8: 228 / 29.2 — the atomics and the per-slice stamping do not shrink with K.
+#ifndef WGS_REBIN_K
+#define WGS_REBIN_K 2
+#endif
+constexpr int REBIN_K = WGS_REBIN_K;
 template <int D> __device__ __forceinline__ void rebin_body(const Dev &d, int side, uint32_t epoch, uint32_t bid) {
-    constexpr int BS = Dim<D>::BSHIFT, BW = Dim<D>::BW, NN = Dim<D>::NNBR;
+    constexpr int BS = Dim<D>::BSHIFT, BW = Dim<D>::BW, NN = Dim<D>::NNBR, K = REBIN_K;
     const float *in = d.buf[side];
     const int tid = threadIdx.x, lane = tid & 63;
-    const uint32_t i = bid * SORT_THREADS + tid;
     if (bid == 0u && tid < 16) d.counters[(tid < 8 ? (int)CTR_NCPIC : (int)CTR_NVISIT - 256) + 32 * tid] = 0;  // near-collider lists of this substep (k_regroup appends)
     if (bid == 0u && tid == 16) d.counters[CTR_NHALO] = 0;  // interface-block list (sharded runs)
     // sharded runs: the residents minus the slots vacated by particles that now live on a neighbour, and behind them,
     // in [NPREV, N), the particles that arrived in the last substep (kernels_arrivals.h): they have no previous cell and
     // take the hash path below like a particle that changed block
-    const bool in_range = i < num_slots(d);
-    bool valid = in_range;
-    if (d.sharded && valid) valid = ldpid<D>(in, d.npad, i) != 0xffffffffu;
-    uint32_t myid = NONE, local = 0, old = NONE, mykey = 0u;
-    if (valid) {
-        if (!d.sharded || i < ctr_cur(d, CTR_NPREV)) old = d.perm_cell[i];  // NONE only after a grid overflow: take the hash path then
-        if (old != NONE) old &= ~CELL_LISTED;
-        const uint32_t ob = old >> 6;
-        const uint32_t okey = old != NONE ? d.block_key[ob] : 0u;
-        int c[D], nb[3] = {0, 0, 0};
-        load_cell<D>(d, in, i, c);
-        uint32_t shift = 0;
+    const uint32_t nslots = num_slots(d);
+    const uint32_t nprev = d.sharded ? ctr_cur(d, CTR_NPREV) : 0u;
+    uint32_t idx[K], old[K];
+    bool in_range[K], valid[K];
+    float4 xm[K];
+    // ---- round 1: everything that depends on the slot alone
 #pragma unroll
-        for (int k = 0; k < D; k++) {
-            nb[k] = c[k] >> BS;
-            local |= (uint32_t)(c[k] & (BW - 1)) << shift;
-            shift += BS;
-        }
-        int hi[3] = {nb[0] + 1, nb[1] + 1, nb[2] + 1};
-        if (!block_in_key_range<D>(nb) || !block_in_key_range<D>(hi)) {
-            atomicOr(&d.counters[CTR_ERRORS], ERRBIT_KEYRANGE);
-        } else {
-            const uint32_t key = pack_key<D>(nb);
-            mykey = key;
-            myid = (old != NONE && key == okey) ? ob : activate_block(d, key, epoch);  // few particles change block
-            if (myid >= d.cap) myid = NONE;
+    for (int k = 0; k < K; k++) {
+        idx[k] = (bid * (uint32_t)K + (uint32_t)k) * SORT_THREADS + (uint32_t)tid;
+        in_range[k] = idx[k] < nslots;
+        valid[k] = in_range[k];
+        old[k] = NONE;
+        xm[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (in_range[k]) {
+            if (!d.sharded || idx[k] < nprev) old[k] = d.perm_cell[idx[k]];  // NONE only after a grid overflow: take the hash path then
+            xm[k] = ldq(in, d.npad, Pl<D>::XM, idx[k]);
+            if (d.sharded) valid[k] = ldpid<D>(in, d.npad, idx[k]) != 0xffffffffu;
         }
     }
-    // activate every distinct block of the wave and its +1 neighbours (grid.wgsl:300-320), count its particles
-    unsigned long long todo = __ballot(myid != NONE);
-    while (todo) {
-        const int leader = __ffsll((long long)todo) - 1;
-        const uint32_t b1 = __shfl(myid, leader);
-        // (the block's key from the leader's own particle, not from block_key[b1]: a block handed out in THIS launch by a
-        // wave of another XCD has its key in that XCD's L2 only)
-        const uint32_t k1 = __shfl(mykey, leader);
-        const unsigned long long same = __ballot(myid == b1);
-        todo &= ~same;
-        if (lane == leader) atomicAdd(&d.block_acc[b1], (uint32_t)__popcll(same));
-        if (lane < NN) {
-            // links of the previous substep when they exist: a plain idempotent store. A block created just now,
-            // re-activated after a pause, or whose neighbour was not active (it held no particle) goes
-            // through the hash map.
-            const uint32_t le = d.links_epoch[b1], link = d.nbr_plus[b1 * 8u + lane];  // independent loads
-            const uint32_t t1 = le == epoch - 1u ? link : NONE;
-            if (t1 != NONE) {
-                d.block_stamp[t1] = epoch;
+    // ---- round 2: the key of the previous block
+    uint32_t okey[K];
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+        if (old[k] != NONE) old[k] &= ~CELL_LISTED;
+        okey[k] = (valid[k] && old[k] != NONE) ? d.block_key[old[k] >> 6] : 0u;
+    }
+    const bool p2 = d.h_pow2 != 0u;
+    uint32_t last_b1 = NONE;   // (wave-uniform) the block whose neighbours this wave stamped last: consecutive slices mostly share it
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+        uint32_t myid = NONE, local = 0u, mykey = 0u;
+        if (valid[k]) {
+            const uint32_t ob = old[k] >> 6;
+            int c[3] = {assoc_cell(xm[k].x, d.h, d.inv_h, p2), assoc_cell(xm[k].y, d.h, d.inv_h, p2), D == 3 ? assoc_cell(xm[k].z, d.h, d.inv_h, p2) : 0};
+            int nb[3] = {0, 0, 0};
+            uint32_t shift = 0;
+#pragma unroll
+            for (int a = 0; a < D; a++) {
+                nb[a] = c[a] >> BS;
+                local |= (uint32_t)(c[a] & (BW - 1)) << shift;
+                shift += BS;
+            }
+            int hi[3] = {nb[0] + 1, nb[1] + 1, nb[2] + 1};
+            if (!block_in_key_range<D>(nb) || !block_in_key_range<D>(hi)) {
+                atomicOr(&d.counters[CTR_ERRORS], ERRBIT_KEYRANGE);
             } else {
-                int kb[3] = {0, 0, 0};
-                unpack_key<D>(k1, kb);
-                int nb[3] = {kb[0] + (lane & 1), kb[1] + ((lane >> 1) & 1), kb[2] + ((lane >> 2) & 1)};
-                if (block_in_key_range<D>(nb)) activate_block(d, pack_key<D>(nb), epoch);
+                const uint32_t key = pack_key<D>(nb);
+                mykey = key;
+                myid = (old[k] != NONE && key == okey[k]) ? ob : activate_block(d, key, epoch);  // few particles change block
+                if (myid >= d.cap) myid = NONE;
             }
         }
-    }
-    if (in_range) {  // (a vacated slot gets NONE: k_regroup skips it)
-        const uint32_t cid = myid == NONE ? NONE : myid * NPB + local;
-        d.cellid[i] = cid;
-        if (cid != NONE && cid != old) push_mover(d, cid, i);
+        // activate every distinct block of the wave and its +1 neighbours (grid.wgsl:300-320), count its particles
+        unsigned long long todo = __ballot(myid != NONE);
+        while (todo) {
+            const int leader = __ffsll((long long)todo) - 1;
+            const uint32_t b1 = __shfl(myid, leader);
+            // (the block's key from the leader's own particle, not from block_key[b1]: a block handed out in THIS launch by a
+            // wave of another XCD has its key in that XCD's L2 only)
+            const uint32_t k1 = __shfl(mykey, leader);
+            const unsigned long long same = __ballot(myid == b1);
+            todo &= ~same;
+            if (lane == leader) atomicAdd(&d.block_acc[b1], (uint32_t)__popcll(same));
+            if (b1 == last_b1) continue;   // its neighbours carry this substep's stamp already (this wave wrote it a slice ago)
+            last_b1 = b1;
+            if (lane < NN) {
+                // links of the previous substep when they exist: a plain idempotent store. A block created just now,
+                // re-activated after a pause, or whose neighbour was not active (it held no particle) goes
+                // through the hash map.
+                const uint32_t le = d.links_epoch[b1], link = d.nbr_plus[b1 * 8u + lane];  // independent loads
+                const uint32_t t1 = le == epoch - 1u ? link : NONE;
+                if (t1 != NONE) {
+                    d.block_stamp[t1] = epoch;
+                } else {
+                    int kb[3] = {0, 0, 0};
+                    unpack_key<D>(k1, kb);
+                    int nb[3] = {kb[0] + (lane & 1), kb[1] + ((lane >> 1) & 1), kb[2] + ((lane >> 2) & 1)};
+                    if (block_in_key_range<D>(nb)) activate_block(d, pack_key<D>(nb), epoch);
+                }
+            }
+        }
+        if (in_range[k]) {  // (a vacated slot gets NONE: k_regroup skips it)
+            const uint32_t cid = myid == NONE ? NONE : myid * NPB + local;
+            d.cellid[idx[k]] = cid;
+            if (cid != NONE && cid != old[k]) push_mover(d, cid, idx[k]);
+        }
     }
 }
 template <int D> __global__ __launch_bounds__(SORT_THREADS) void k_rebin(Dev d, int side, uint32_t epoch) {
