@@ -305,7 +305,8 @@ wgs_status wgs_set_uniform_material(wgs_data *data, float mass, float init_volum
  * outruns the check (more than half a capacity of new blocks inside one call). */
 wgs_status wgs_set_grid_growth(wgs_data *data, int32_t enabled);
 /* Environment (read once per wgs_data_create; developer switches, none of them changes a result): WGS_DEBUG = bit mask of
- * launch-SHAPE choices (two launches instead of one paired launch, the general binning pass on every substep, ...) and
+ * launch-SHAPE choices (two launches instead of one paired launch, the general binning pass on every substep, the grid
+ * update and the message packing as launches of their own instead of workgroups of the P2G launch, ...) and
  * WGS_REHASH_PERIOD = substeps between unconditional rebuilds of the block table — used by the A/B tools and by the tests
  * that assert those shapes are bit-identical; WGS_TRACE drains the stream at every pass boundary and says so on stderr.
  * bench.py refuses to run with WGS_DEBUG / WGS_REHASH_PERIOD set. Switches that DO change results (ablations for timing
