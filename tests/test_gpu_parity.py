@@ -419,6 +419,15 @@ def test_grid_update_inside_the_p2g_launch_is_bit_identical_to_its_own_launch(hi
         for x, y in zip(ba, bb):
             for key in ("translation", "rotation", "linvel", "angvel"):
                 assert np.array_equal(x[key], y[key]), key
+        if len(ba) > 1:      # moving bodies: integrate_bodies rides in the next substep's first sort launch (524288: a launch of its own)
+            monkeypatch.setenv("WGS_DEBUG", "524288")
+            c, _, bc = run()
+            monkeypatch.delenv("WGS_DEBUG")
+            for f in ("pos", "vel", "def_grad", "affine", "cdf_affinity"):
+                assert np.array_equal(getattr(a, f), getattr(c, f)), f
+            for x, y in zip(ba, bc):
+                for key in ("translation", "rotation", "linvel", "angvel"):
+                    assert np.array_equal(x[key], y[key]), key
 
 
 def _exploding_cube():

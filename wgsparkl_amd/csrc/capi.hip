@@ -130,6 +130,7 @@ struct wgs_data {
     uint32_t *watch = nullptr;          // pinned host copy of the device counters as of the end of the last wgs_step call
     hipEvent_t watch_event = nullptr;
     bool watch_pending = false, force_rehash = false, auto_grow = true;
+    bool bodies_pending = false;   // integrate_bodies of the last substep has not run yet (it rides in the next sort launch)
     bool gu_fused = false;   // this substep's grid update rode in its P2G launch
     bool shard_fused = false; // sharded substep: the pack waves and the interior blocks' grid update rode in the P2G launch
     uint32_t grid_grown = 0;            // times the block capacity was doubled
@@ -317,7 +318,7 @@ void fill_collider(ColliderDev &c, const wgs_collider &in) {
     for (int k = 0; k < 3; k++) c.com[k] = in.com[k];
 }
 
-constexpr uint32_t WGS_LAUNCH_SHAPE_SWITCHES = 128u | 1024u | 4096u | 8192u | 16384u | 32768u | 65536u | 131072u | 262144u;  // WGS_DEBUG bits the shipped library honours
+constexpr uint32_t WGS_LAUNCH_SHAPE_SWITCHES = 128u | 1024u | 4096u | 8192u | 16384u | 32768u | 65536u | 131072u | 262144u | 524288u;  // WGS_DEBUG bits the shipped library honours
 constexpr uint32_t P2G_SMALL_BUDGET_MIN_PARTICLES = 600000;  // one-way CPIC P2G body at 168 VGPRs from this size on
 #ifndef WGS_REGROUP_ROUNDS
 #define WGS_REGROUP_ROUNDS 4u
@@ -707,8 +708,11 @@ template <bool TS> wgs_status enqueue_substep(wgs_data *d, int ts_slot, int part
             hipLaunchKernelGGL(k_rigid_transform<D>, dim3(grid_for(d, 1)), dim3(256), 0, s, dev);
         if (n > 0) {
             // (sharded runs: k_rebin also bins the particles that arrived in the last substep, behind the residents)
-            if (use_rebin) hipLaunchKernelGGL(k_rebin<D>, dim3((pgrid + REBIN_K - 1) / REBIN_K), dim3(SORT_THREADS), 0, s, dev, side, epoch);
-            else hipLaunchKernelGGL(k_bin<D>, dim3(pgrid), dim3(SORT_THREADS), 0, s, dev, side, epoch);
+            // (a pending integrate_bodies of the previous substep rides in workgroup 0 of this launch)
+            const uint32_t do_bodies = d->bodies_pending ? 1u : 0u;
+            d->bodies_pending = false;
+            if (use_rebin) hipLaunchKernelGGL(k_rebin<D>, dim3((pgrid + REBIN_K - 1) / REBIN_K), dim3(SORT_THREADS), 0, s, dev, side, epoch, do_bodies);
+            else hipLaunchKernelGGL(k_bin<D>, dim3(pgrid), dim3(SORT_THREADS), 0, s, dev, side, epoch, do_bodies);
             if (dev.n_rigid > 0) {  // blocks a mesh sample reaches must exist (sort.wgsl:38-86)
                 hipLaunchKernelGGL(k_rigid_mark<D>, dim3(grid_for(d, 1)), dim3(256), 0, s, dev, epoch);
                 hipLaunchKernelGGL(k_rigid_touch<D>, dim3(grid_for(d, 1)), dim3(256), 0, s, dev, epoch);
@@ -914,7 +918,10 @@ template <bool TS> wgs_status enqueue_substep(wgs_data *d, int ts_slot, int part
                 wgs_status rst = allreduce_impulses(d);
                 if (rst != WGS_OK) return rst;
             }
-            hipLaunchKernelGGL(k_bodies_integrate<D>, dim3(1), dim3(16), 0, s, dev);
+            // Single-domain simulations without mesh colliders: left to the first launch of the next substep (or to the end of
+            // this wgs_step call, flush_bodies) — a 16-thread launch of its own costs a dependent launch, ~5 us, per substep.
+            if (part == 0 && !dev.sharded && dev.n_rigid == 0 && n > 0 && !(dev.dbg & 524288u)) d->bodies_pending = true;
+            else hipLaunchKernelGGL(k_bodies_integrate<D>, dim3(1), dim3(16), 0, s, dev);
         }
         mark(8);
         d->side ^= 1;
@@ -1026,7 +1033,7 @@ static wgs_status create_impl(wgs_pipeline *pipeline, const wgs_sim_params *para
     // spill-free variant of the plastic G2P pair, 32768 = never the small register budget of the one-way P2G pair,
     // 65536 = never the uniform-material mode (the per-particle constants always travel with the particle), 131072 = the
     // fused G2P always with two chunks per wave (the large-scene launch shape), 262144 = the grid update as a launch of its
-    // own also where it could ride in the P2G launch.
+    // own also where it could ride in the P2G launch, 524288 = integrate_bodies as a launch of its own at the tail of every substep.
     // The ablations that change the RESULTS (64 = G2P moves bytes only, 256 = P2G without its accumulation loop,
     // 512 = P2G without its particle loads) exist only in builds with -DWGS_ABLATE; the shipped library ignores them.
     dev.dbg = getenv("WGS_DEBUG") ? (uint32_t)strtoul(getenv("WGS_DEBUG"), nullptr, 0) : 0u;
@@ -1298,6 +1305,10 @@ wgs_status wgs_step(wgs_pipeline *pipeline, wgs_data *d, uint32_t num_substeps, 
             st = enqueue_substep<false>(d, 0, 0);
         }
         if (st != WGS_OK) return st;
+    }
+    if (d->bodies_pending) {   // the last substep's integrate_bodies: every other entry point finds the bodies integrated
+        hipLaunchKernelGGL(k_bodies_integrate<D>, dim3(1), dim3(16), 0, d->stream, d->dev);
+        d->bodies_pending = false;
     }
     if (timestamps) d->timings_pending = true;
     return watch_counters(d);

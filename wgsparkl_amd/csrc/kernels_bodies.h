@@ -69,9 +69,11 @@ template <int D> __global__ __launch_bounds__(16) void k_bodies_refresh(Dev d, u
     if (i < d.n_colliders) body_refresh<D>(d, i, (com_given >> i) & 1u);
 }
 
-template <int D> __global__ __launch_bounds__(16) void k_bodies_integrate(Dev d) {
+// integrate_bodies for body i (one thread per body). A function of its own: single-domain simulations without mesh colliders run
+// it at the head of the NEXT substep's first sort launch (k_rebin / k_bin, workgroup 0) instead of as a 16-thread launch
+// of its own at the tail of every substep — nothing in between reads a pose, a velocity or an impulse (capi.hip).
+template <int D> __device__ inline void bodies_integrate_one(const Dev &d, uint32_t i) {
     constexpr int ANG = D == 3 ? 3 : 1;
-    const uint32_t i = threadIdx.x;
     if (i >= d.n_colliders) return;
     ColliderDev &c = d.colliders[i];
     const BodyDev &b = d.bodies[i];
@@ -144,4 +146,5 @@ template <int D> __global__ __launch_bounds__(16) void k_bodies_integrate(Dev d)
     body_refresh<D>(d, i, false);
 }
 
+template <int D> __global__ __launch_bounds__(16) void k_bodies_integrate(Dev d) { bodies_integrate_one<D>(d, threadIdx.x); }
 }  // namespace wgs

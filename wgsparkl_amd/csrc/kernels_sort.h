@@ -146,7 +146,9 @@ template <int D> __device__ __forceinline__ void bin_body(const Dev &d, int side
         if (cid != NONE) push_mover(d, cid, i);
     }
 }
-template <int D> __global__ __launch_bounds__(SORT_THREADS) void k_bin(Dev d, int side, uint32_t epoch) {
+// do_bodies: the previous substep left integrate_bodies to this launch (kernels_bodies.h bodies_integrate_one)
+template <int D> __global__ __launch_bounds__(SORT_THREADS) void k_bin(Dev d, int side, uint32_t epoch, uint32_t do_bodies) {
+    if (do_bodies && blockIdx.x == 0 && threadIdx.x < 16) bodies_integrate_one<D>(d, threadIdx.x);
     bin_body<D>(d, side, epoch, blockIdx.x);
 }
 
@@ -262,7 +264,8 @@ template <int D> __device__ __forceinline__ void rebin_body(const Dev &d, int si
         }
     }
 }
-template <int D> __global__ __launch_bounds__(SORT_THREADS) void k_rebin(Dev d, int side, uint32_t epoch) {
+template <int D> __global__ __launch_bounds__(SORT_THREADS) void k_rebin(Dev d, int side, uint32_t epoch, uint32_t do_bodies) {
+    if (do_bodies && blockIdx.x == 0 && threadIdx.x < 16) bodies_integrate_one<D>(d, threadIdx.x);
     rebin_body<D>(d, side, epoch, blockIdx.x);
 }
 // ---------------------------------------------------------------------------------------------------------------
