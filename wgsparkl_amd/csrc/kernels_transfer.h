@@ -65,7 +65,7 @@ template <int D> __device__ __forceinline__ float4 node_velocity(const float4 su
     return D == 3 ? make_float4(v[0], v[1], v[2], mass) : make_float4(v[0], v[1], mass, 0.f);
 }
 
-// The grid update as waves INSIDE the P2G launch (k_p2g / k_p2g_pair with GU = 2; single-domain one-way simulations):
+// The grid update as waves INSIDE the P2G launch (k_p2g / k_p2g_pair with GU = 2; single-domain simulations):
 // one wave per active block and turn, lane = node. The wave waits for the words of the (at most 2^D) slabs its nodes
 // are gathered from — P2G publishes a block's word once the slab's write-through stores have been acknowledged —,
 // gathers with agent-scope loads (past this XCD's L2, which may never have seen the slab) and from there on is the
