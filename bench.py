@@ -47,6 +47,7 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the extra legs (landed cube, c3, c5)")
     ap.add_argument("--no-floor", action="store_true", help="c2 without the floor cuboid of SURVEY 8d (no CPIC passes)")
+    ap.add_argument("--no-live-pmc", action="store_true", help="roofline.traffic from the committed rocprofv3 passes instead of two child runs under rocprofv3 --pmc")
     ap.add_argument("--allow-debug-switches", action="store_true", help="run although WGS_DEBUG is set (A/B of launch shapes)")
     return ap.parse_args()
 
@@ -76,6 +77,39 @@ def cpu_baseline(scene, substeps):
     st.step(substeps)
     dt = time.perf_counter() - t0
     return ps.n * substeps / dt, dt, orc.num_threads, st
+
+
+def live_pmc_traffic():
+    """HBM bytes per launch of the fused G2P kernel, measured NOW: two child runs of this script (the headline workload, 20
+    substeps) under `rocprofv3 --kernel-trace --pmc`, one counter each as MI355X_MICROARCH.md prescribes (FETCH_SIZE, WRITE_SIZE;
+    units of 1 KiB; FETCH_SIZE doubled: gfx950 counts the 128-B requests of 16-B-per-lane streams as 64 B) — the very recipe of
+    tools/gpu_round_profile.sh + tools/summarize_profiles.py behind profiles/rNN_pmc_g2p.json. None when rocprofv3 is missing,
+    fails or times out (the caller then quotes the committed passes)."""
+    import csv, glob, shutil, tempfile
+    rp = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(rp):
+        return None
+    vals = {}
+    for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+        tmp = tempfile.mkdtemp(prefix="wgs_pmc_", dir="/tmp")
+        try:
+            cmd = [rp, "--kernel-trace", "--pmc", ctr, "--output-format", "csv", "-d", tmp, "--", sys.executable, os.path.abspath(__file__),
+                   "--steps", "20", "--warmup", "5", "--no-cpu-baseline", "--no-extra", "--no-live-pmc"]
+            subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=180)
+            rows = []
+            for f in glob.glob(os.path.join(tmp, "**", "*counter_collection.csv"), recursive=True):
+                for r in csv.DictReader(open(f)):
+                    if r.get("Counter_Name") == ctr and ("k_g2p_pair" in r.get("Kernel_Name", "") or "k_g2p_update" in r.get("Kernel_Name", "")):
+                        rows.append(float(r["Counter_Value"]))
+            if len(rows) < 8:
+                return None
+            rows = rows[len(rows) // 2:]          # the launches of the timed half: the cube is in steady free fall
+            vals[ctr] = sum(rows) / len(rows)
+        except Exception:  # noqa: BLE001 — any failure of the profiler means "not measured", never a failed bench
+            return None
+        finally:
+            shutil.rmtree(tmp, ignore_errors=True)
+    return vals["FETCH_SIZE"] * 1024.0 * 2.0 + vals["WRITE_SIZE"] * 1024.0
 
 
 def g2p_roofline(timings, k_ts, mark_ms, n, n_nodes, bytes_per_particle, kernel):
@@ -304,7 +338,14 @@ def main():
     if rank == 0:
         rl = main_res["roofline"]
         prof = sorted(__import__("glob").glob(os.path.join(ROOT, "profiles", "r*_pmc_g2p.json")))[-1:]
-        if prof and default_workload and world == 1:
+        live = None
+        if default_workload and world == 1 and not args.no_live_pmc and not args.no_extra:
+            live = live_pmc_traffic()   # two short child runs of this workload under rocprofv3 --pmc (one counter each)
+        if live is not None:
+            rl["traffic"] = live
+            rl["traffic_source"] = ("measured by this run: two child runs of the headline workload under rocprofv3 --kernel-trace --pmc (FETCH_SIZE, "
+                                    "WRITE_SIZE; one counter per run), FETCH_SIZE x 2 x 1 KiB + WRITE_SIZE x 1 KiB per MI355X_MICROARCH.md, fused G2P launches only")
+        elif prof and default_workload and world == 1:
             try:   # PMC byte counters of this very command, collected by rocprofv3 in its own passes and committed
                 rl["traffic"] = json.load(open(prof[0])).get("hbm_bytes_per_launch")
                 rl["traffic_source"] = os.path.relpath(prof[0], ROOT) + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, committed; not measured in this run)"
