@@ -329,6 +329,8 @@ typedef uint32_t wgs_v4u __attribute__((ext_vector_type(4)));
 constexpr int WGS_CPOL_SC1 = 16;   // gfx940+: agent scope
 __device__ inline __amdgpu_buffer_rsrc_t slab_rsrc(float4 *slab_of_block, uint32_t bytes) {
     // (the base must be wave-uniform: callers pass a pointer computed from a readfirstlane'd block id)
+    // (stride 0 = raw buffer: `bytes` records of one byte, every access bounds-checked against it — out of range loads return
+    // zeros, stores are dropped; 0x00020000 = word 3 of a raw-buffer descriptor on gfx90a / gfx94x / gfx950: 32-bit data format)
     return __builtin_amdgcn_make_buffer_rsrc(slab_of_block, 0, bytes, 0x00020000);
 }
 __device__ inline void st_agent(__amdgpu_buffer_rsrc_t r, uint32_t byte_off, const float4 v) {
