@@ -74,6 +74,23 @@ def mesh_floor3d():
     return sc
 
 
+def tied_mesh3d():
+    """Mesh colliders whose triangles have TIED longest edges (particle3d.rs:348-362: bc, then ca, else ab): an elastic cube
+    lands on a regular octahedron (every face equilateral) beside a square pyramid (isosceles sides) that moves into it."""
+    sc = scenes.neo_hookean_cube(n_side=8, with_floor=False)
+    sc["particles"].vel[:, 1] = -3.0
+    octa_v = np.array([[3, 0, 0], [-3, 0, 0], [0, 3, 0], [0, -3, 0], [0, 0, 3], [0, 0, -3]], np.float32)
+    octa_i = np.array([[0, 2, 4], [2, 1, 4], [1, 3, 4], [3, 0, 4], [2, 0, 5], [1, 2, 5], [3, 1, 5], [0, 3, 5]], np.uint32)
+    pyr_v = np.array([[-2, 0, -2], [2, 0, -2], [2, 0, 2], [-2, 0, 2], [0, 3, 0]], np.float32)
+    pyr_i = np.array([[0, 1, 4], [1, 2, 4], [2, 3, 4], [3, 0, 4], [0, 2, 1], [0, 3, 2]], np.uint32)
+    x0, z0 = (float(sc["particles"].pos[:, k].mean()) for k in (0, 2))
+    y0 = float(sc["particles"].pos[:, 1].min())
+    sc["colliders"] = [Collider.trimesh(octa_v, octa_i, (x0 + 0.37, y0 - 3.3, z0 - 0.21)),
+                       Collider.trimesh(pyr_v, pyr_i, (x0 - 4.4, y0 - 0.6, z0 + 0.3), linvel=(0.7, 0.0, 0.0), angvel=(0.0, 0.4, 0.0))]
+    sc["grid_capacity"] = 1024
+    return sc
+
+
 def polyline2d():
     """2D polyline collider: a V-shaped ground under an elastic block."""
     sc = scenes.elastic_block_2d(nx=20, ny=16, with_floor=False)
@@ -88,4 +105,5 @@ def polyline2d():
 
 CASES = {"cloud3d": (cloud3d, 3), "cloud2d": (cloud2d, 3), "sand3d": (sand3d, 2), "floor3d": (floor3d, 20),
          "tilted_box2d": (tilted_box2d, 20), "dynamic_ball2d": (dynamic_ball2d, 120),
-         "dynamic_ball3d": (dynamic_ball3d, 120), "mesh_floor3d": (mesh_floor3d, 80), "polyline2d": (polyline2d, 140)}
+         "dynamic_ball3d": (dynamic_ball3d, 120), "mesh_floor3d": (mesh_floor3d, 80), "polyline2d": (polyline2d, 140),
+         "tied_mesh3d": (tied_mesh3d, 80)}

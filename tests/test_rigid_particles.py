@@ -39,11 +39,42 @@ def test_vectorised_mesh_sampler_reproduces_the_reference_loops():
     rv, ri = ref_sampling.heightfield_to_trimesh((0.3 * np.sin(0.9 * ii) * np.cos(0.7 * jj)).astype(np.float32), (18.0, 1.5, 14.0))
     assert np.array_equal(hv, rv) and np.array_equal(hi, ri)
     _same(sampling.sample_mesh(hv, hi, 1.0), ref_sampling.sample_mesh(rv, ri, 1.0))
-    # degenerate: a zero-area sliver, a repeated vertex, a triangle smaller than the spacing, an isosceles tie of the longest edge
+    # degenerate: a zero-area sliver, a repeated vertex, a triangle smaller than the spacing
     v = np.array([[0, 0, 0], [3, 0, 0], [1.5, 0, 0], [0, 0, 0], [0.1, 0, 0], [0, 0.1, 0], [2, 0, 0], [1, 1.7, 0], [0, 3, 0], [3, 3, 0]], np.float32)
     idx = np.array([[0, 1, 2], [0, 3, 1], [3, 4, 5], [0, 6, 7], [0, 1, 8], [1, 9, 8]], np.uint32)
     _same(sampling.sample_mesh(v, idx, 0.5), ref_sampling.sample_mesh(v, idx, 0.5))
     assert sampling.sample_mesh(v, np.zeros((0, 3), np.uint32), 0.5)[0].shape == (0, 3)
+
+
+def test_longest_edge_ties_go_to_bc_then_ca_then_ab():
+    """particle3d.rs:348-362 tests `max == bc` first, then `max == ca`, and keeps ab only otherwise. Triangles whose longest
+    edge is tied (exactly, in fp32) in every combination, an equilateral face, an octahedron and a square pyramid."""
+    tied = {
+        "ab=bc": [(0, 0, 0), (3, 4, 0), (-1, 1, 0)],
+        "ab=bc (advisor)": [(0, 0, 0), (1, 3, 0), (-1, 3, 0)],
+        "ab=ca": [(0, 0, 0), (3, 4, 0), (5, 0, 0)],
+        "bc=ca": [(-3, 0, 0), (3, 0, 0), (0, 0, 8)],
+        "ab=bc=ca": [(1, 0, 0), (0, 1, 0), (0, 0, 1)],
+    }
+    for name, tri in tied.items():
+        v = np.array(tri, np.float32)
+        d = [np.float32(np.sqrt(np.sum((v[(k + 1) % 3] - v[k]) ** 2, dtype=np.float32))) for k in range(3)]
+        assert sum(x == max(d) for x in d) >= 2, (name, d)                      # the tie is exact in fp32
+        for spacing in (0.5, 0.31, 1.0):
+            for rolled in range(3):                                             # every rotation of the vertex order
+                idx = np.array([np.roll(np.arange(3), rolled)], np.uint32)
+                got = sampling.sample_mesh(v, idx, spacing)
+                assert got[0].shape[0] > 0
+                _same(got, ref_sampling.sample_mesh(v, idx, spacing))
+    octa_v = np.array([[2, 0, 0], [-2, 0, 0], [0, 2, 0], [0, -2, 0], [0, 0, 2], [0, 0, -2]], np.float32)
+    octa_i = np.array([[0, 2, 4], [2, 1, 4], [1, 3, 4], [3, 0, 4], [2, 0, 5], [1, 2, 5], [3, 1, 5], [0, 3, 5]], np.uint32)
+    pyr_v = np.array([[-2, 0, -2], [2, 0, -2], [2, 0, 2], [-2, 0, 2], [0, 3, 0]], np.float32)
+    pyr_i = np.array([[0, 1, 4], [1, 2, 4], [2, 3, 4], [3, 0, 4], [0, 2, 1], [0, 3, 2]], np.uint32)
+    fan_v = np.array([[0, 0, 0]] + [[3 * np.cos(k * np.pi / 3), 0, 3 * np.sin(k * np.pi / 3)] for k in range(6)], np.float32)
+    fan_i = np.array([[0, 1 + k, 1 + (k + 1) % 6] for k in range(6)], np.uint32)
+    for v, idx in ((octa_v, octa_i), (pyr_v, pyr_i), (fan_v, fan_i)):
+        for spacing in (0.4, 0.75):
+            _same(sampling.sample_mesh(v, idx, spacing), ref_sampling.sample_mesh(v, idx, spacing))
 
 
 def test_vectorised_polyline_sampler_reproduces_the_reference_loops():

@@ -75,8 +75,8 @@ def _triangle_points(a: np.ndarray, b: np.ndarray, c: np.ndarray, spacing_xy: fl
     spacing = F32(F32(spacing_xy) / _INV_SQRT2_DEN)
     dab, dbc, dca = _len(b - a), _len(c - b), _len(a - c)
     mx = np.maximum(np.maximum(dab, dbc), dca)
-    # the longest edge becomes the base a -> b (ties: ab, then bc)
-    rot = np.where(mx == dab, 0, np.where(mx == dbc, 1, 2))
+    # the longest edge becomes the base a -> b; a tie goes to bc, then ca, and only otherwise ab (particle3d.rs:348-362)
+    rot = np.where(mx == dbc, 1, np.where(mx == dca, 2, 0))
     tri = np.stack([a, b, c], 1)                                    # [T, 3, 3]
     pick = lambda k: np.take_along_axis(tri, ((rot + k) % 3)[:, None, None].repeat(3, 2), 1)[:, 0, :]
     a, b, c = pick(0), pick(1), pick(2)
