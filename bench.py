@@ -85,17 +85,31 @@ def live_pmc_traffic():
     units of 1 KiB; FETCH_SIZE doubled: gfx950 counts the 128-B requests of 16-B-per-lane streams as 64 B) — the very recipe of
     tools/gpu_round_profile.sh + tools/summarize_profiles.py behind profiles/rNN_pmc_g2p.json. None when rocprofv3 is missing,
     fails or times out (the caller then quotes the committed passes)."""
-    import csv, glob, shutil, tempfile
+    import csv, glob, shutil, signal, tempfile
     rp = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
     if not os.path.exists(rp):
         return None
     vals = {}
+    # the children are plain single-GPU runs: nothing of a launcher's or this harness's environment goes along
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "GROUP_RANK", "ROLE_RANK")
+           and not k.startswith(("MASTER_", "WGS_BENCH_", "TORCHELASTIC_"))}
+    env["TMPDIR"] = "/tmp"
     for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
         tmp = tempfile.mkdtemp(prefix="wgs_pmc_", dir="/tmp")
         try:
             cmd = [rp, "--kernel-trace", "--pmc", ctr, "--output-format", "csv", "-d", tmp, "--", sys.executable, os.path.abspath(__file__),
                    "--steps", "20", "--warmup", "5", "--no-cpu-baseline", "--no-extra", "--no-live-pmc"]
-            subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=180)
+            # a session of its own: on a timeout the whole group goes (rocprofv3 AND the bench process under it), never by pattern
+            child = subprocess.Popen(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, start_new_session=True)
+            try:
+                child.wait(timeout=150)
+            except subprocess.TimeoutExpired:
+                try:
+                    os.killpg(child.pid, signal.SIGKILL)
+                except ProcessLookupError:
+                    pass
+                child.wait()
+                return None
             rows = []
             for f in glob.glob(os.path.join(tmp, "**", "*counter_collection.csv"), recursive=True):
                 for r in csv.DictReader(open(f)):
@@ -109,7 +123,9 @@ def live_pmc_traffic():
             return None
         finally:
             shutil.rmtree(tmp, ignore_errors=True)
-    return vals["FETCH_SIZE"] * 1024.0 * 2.0 + vals["WRITE_SIZE"] * 1024.0
+    return {"bytes": vals["FETCH_SIZE"] * 1024.0 * 2.0 + vals["WRITE_SIZE"] * 1024.0,
+            "raw_counters_per_launch": {"FETCH_SIZE_KiB": vals["FETCH_SIZE"], "WRITE_SIZE_KiB": vals["WRITE_SIZE"],
+                                        "note": "bytes = FETCH_SIZE x 2 (gfx950 counts the 128-B requests of 16-B-per-lane streams as 64 B: MI355X_MICROARCH.md) x 1 KiB + WRITE_SIZE x 1 KiB"}}
 
 
 def g2p_roofline(timings, k_ts, mark_ms, n, n_nodes, bytes_per_particle, kernel):
@@ -130,11 +146,15 @@ def g2p_roofline(timings, k_ts, mark_ms, n, n_nodes, bytes_per_particle, kernel)
 class Leg:
     """One timed workload on this rank: single-domain data (world == 1) or one slab of the decomposition."""
 
-    def __init__(self, env, scene, world, rank):
+    def __init__(self, env, scene, world, rank, frame=0):
         from wgsparkl_amd import MpmData
         self.env, self.scene, self.world, self.rank = env, scene, world, rank
-        pipe = env["pipe"]
+        self.frame = frame      # > 0: the caller's frame loop — wgs_step calls of `frame` substeps with the pose read-back between them
         ps = scene["particles"]
+        if ps.dim == 2 and env.get("pipe2") is None:
+            from wgsparkl_amd import MpmPipeline
+            env["pipe2"] = MpmPipeline(env["dev_index"], 2)
+        pipe = self.pipe = env["pipe2"] if ps.dim == 2 else env["pipe"]
         self.n = ps.n
         self.sharded = world > 1 or env["force_sharded"]
         self.n_total = scene.get("global_particles", ps.n) if self.sharded else ps.n
@@ -163,8 +183,16 @@ class Leg:
         self.handle = self.data._h
 
     def run(self, k):
-        if not self.sharded:
-            self.env["pipe"].step(self.data, k)
+        if self.frame:
+            # one call per frame and the blocking pose read-back behind it (src_testbed/step.rs:122-132,175-176): the launch
+            # shapes that follow "the host's last look" see a look every `frame` substeps
+            for _ in range(k // self.frame):
+                self.pipe.step(self.data, self.frame)
+                self.data.read_body_poses()
+            if k % self.frame:
+                self.pipe.step(self.data, k % self.frame)
+        elif not self.sharded:
+            self.pipe.step(self.data, k)
         else:
             self.data.step(k)
 
@@ -173,12 +201,15 @@ class Leg:
         torch, dist = env["torch"], env["dist"]
         self.run(warmup)
         self.data.sync()
+        movers0 = None if self.sharded else self.data.stats()["cell_changers"]
         env["barrier"]()
         t0 = time.perf_counter()
         self.run(steps)                      # exactly K substeps
         self.data.sync()
         env["barrier"]()
         elapsed = time.perf_counter() - t0
+        # particles that changed their associated cell per substep of the timed region (device counter, wgs_stats.cell_changers)
+        self.mover_fraction = None if movers0 is None else (self.data.stats()["cell_changers"] - movers0) / max(1, self.n * steps)
         if dist is not None:
             t = torch.tensor([elapsed], device=env["device"], dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -192,7 +223,7 @@ class Leg:
         """Throughput + per-pass device times (HIP events on the data's own stream) of up to 64 more substeps of the local
         data (a slab steps without its neighbours here: kernel timing only, after the timed region)."""
         from wgsparkl_amd import _ffi
-        pipe = self.env["pipe"]
+        pipe = self.pipe
         k_ts = min(steps, 64)
         _ffi.check(pipe.lib, pipe.lib.wgs_step(pipe._h, self.handle, k_ts, 1))
         self.data.sync()
@@ -206,6 +237,7 @@ class Leg:
         nblocks = int(st.num_active_blocks)
         return {"value": self.n_total * steps / elapsed, "ms_per_step": elapsed / steps * 1e3, "steps": steps,
                 "global_particles": self.n_total, "active_blocks_rank0": nblocks, "near_collider_blocks_rank0": int(st.num_near_collider_blocks),
+                "mover_fraction": self.mover_fraction,
                 "parallelism": self.parallelism,
                 "roofline": g2p_roofline(timings, k_ts, float(ovh.value), self.n, nblocks * 64, self.bytes_per_particle, kernel_name),
                 "pass_ms_per_step": {k: v / k_ts for k, v in timings.items()}}
@@ -214,8 +246,8 @@ class Leg:
         self.data.close()
 
 
-def measure(env, scene, world, rank, steps, warmup, kernel_name, settle=0):
-    leg = Leg(env, scene, world, rank)
+def measure(env, scene, world, rank, steps, warmup, kernel_name, settle=0, frame=0):
+    leg = Leg(env, scene, world, rank, frame=frame)
     if settle:
         leg.run(settle)
     res = leg.result(steps, leg.timed(steps, warmup), kernel_name)
@@ -282,7 +314,7 @@ def main():
     if "WGS_ABLATE" in build_info and os.environ.get("WGS_BENCH_ALLOW_ABLATE") != "1":
         print("bench.py: the library was built with -DWGS_ABLATE (ablation switches compiled in): not a product build", file=sys.stderr)
         sys.exit(2)
-    env = dict(torch=torch, dist=dist, pipe=pipe, barrier=barrier, device=device, force_sharded=force_sharded, comm=None)
+    env = dict(torch=torch, dist=dist, pipe=pipe, pipe2=None, dev_index=dev_index, barrier=barrier, device=device, force_sharded=force_sharded, comm=None)
     transport_note = None
     if sharded_path:
         # The substep protocol runs inside the library over RCCL (wgs_sharded_step); torch.distributed only makes the
@@ -331,6 +363,31 @@ def main():
         scene = scenes.config_scene(args.config, world, rank if sharded_path else None, args.scaling, n_side=args.n_side)
         if args.no_floor:
             scene["colliders"] = []
+    def partition_ok(sc):
+        """Every rank checks the cut it was given against what wgs_shard_attach accepts (a slab between two neighbours is at
+        least MIN_INTERIOR_WIDTH blocks wide) and the ranks agree on the verdict BEFORE any of them builds a slab: one rank
+        raising alone would leave the others blocked in their first ncclRecv."""
+        if not sharded_path or "partition" not in sc:
+            return True
+        from wgsparkl_amd.sharded import MIN_INTERIOR_WIDTH
+        ok = world < 3 or sc["partition"].min_interior_width() >= MIN_INTERIOR_WIDTH
+        if dist is not None:
+            t = torch.tensor([1 if ok else 0], device=device, dtype=torch.int32)
+            dist.all_reduce(t, op=dist.ReduceOp.MIN)
+            ok = int(t.item()) == 1
+        return ok
+
+    if not partition_ok(scene):
+        if rank == 0:
+            from wgsparkl_amd.sharded import MIN_INTERIOR_WIDTH
+            emit({"metric": "particle-steps/sec", "value": None, "unit": "particle-steps/s", "n_gpus": world,
+                  "error": f"--config {args.config} --scaling {args.scaling} cut into {world} x-slabs leaves a slab between two neighbours narrower than the "
+                           f"{MIN_INTERIOR_WIDTH} blocks the one-message halo protocol needs (kernels_shard.h): nothing was timed"})
+            print(f"bench.py: the decomposition of --config {args.config} into {world} slabs is too narrow; nothing was timed", file=sys.stderr)
+        if dist is not None:
+            dist.barrier()
+            dist.destroy_process_group()
+        sys.exit(5)
     main_res = measure(env, scene, world, rank, args.steps, args.warmup,
                        ("k_g2p_pair<plastic>" if args.config == "c3" else KERNEL_ELASTIC) if scene["colliders"] else "k_g2p_update (fused G2P + particle update)")
 
@@ -338,14 +395,9 @@ def main():
     if rank == 0:
         rl = main_res["roofline"]
         prof = sorted(__import__("glob").glob(os.path.join(ROOT, "profiles", "r*_pmc_g2p.json")))[-1:]
-        live = None
-        if default_workload and world == 1 and not args.no_live_pmc and not args.no_extra:
-            live = live_pmc_traffic()   # two short child runs of this workload under rocprofv3 --pmc (one counter each)
-        if live is not None:
-            rl["traffic"] = live
-            rl["traffic_source"] = ("measured by this run: two child runs of the headline workload under rocprofv3 --kernel-trace --pmc (FETCH_SIZE, "
-                                    "WRITE_SIZE; one counter per run), FETCH_SIZE x 2 x 1 KiB + WRITE_SIZE x 1 KiB per MI355X_MICROARCH.md, fused G2P launches only")
-        elif prof and default_workload and world == 1:
+        # (the live measurement — two child runs under rocprofv3 — comes after every timed leg, below: the children use this GPU;
+        # until then the committed passes of this very command stand in)
+        if prof and default_workload and world == 1:
             try:   # PMC byte counters of this very command, collected by rocprofv3 in its own passes and committed
                 rl["traffic"] = json.load(open(prof[0])).get("hbm_bytes_per_launch")
                 rl["traffic_source"] = os.path.relpath(prof[0], ROOT) + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, committed; not measured in this run)"
@@ -404,7 +456,7 @@ def main():
         k, w = min(args.steps, 50), 5
         slim = lambda r, name: {"workload": name, "value": r["value"], "unit": "particle-steps/s", "ms_per_step": r["ms_per_step"],
                                 "global_particles": r["global_particles"], "active_blocks_rank0": r["active_blocks_rank0"],
-                                "near_collider_blocks_rank0": r["near_collider_blocks_rank0"], "steps": r["steps"],
+                                "near_collider_blocks_rank0": r["near_collider_blocks_rank0"], "steps": r["steps"], "mover_fraction": r["mover_fraction"],
                                 "roofline_g2p": {x: r["roofline"][x] for x in ("achieved", "frac", "avg_launch_ms", "algorithmic_bytes_per_launch")},
                                 "pass_ms_per_step": r["pass_ms_per_step"], "parallelism": r["parallelism"]}
         if not sharded_path:
@@ -419,34 +471,64 @@ def main():
             # the size the reference itself ships (its scenes hold 75 k - 490 k particles): latency-bound here, four dependent launches
             sc = scenes.reference_sand3()
             extra["sand3_202k"] = slim(measure(env, sc, 1, 0, k, w, "k_g2p_pair<plastic>", settle=100), sc["name"] + ", 100 substeps before the timed region")
+            # the reference's largest shipping scene is 2D (crates/wgsparkl2d/examples/sand2.rs:33-50)
+            sc = scenes.reference_sand2()
+            extra["sand2_490k"] = slim(measure(env, sc, 1, 0, k, w, "k_g2p_pair<2D, plastic>", settle=100), sc["name"] + ", 100 substeps before the timed region")
+            # particles that CHANGE CELLS: the headline cube is in free fall and moves 2e-4 cells in the timed region — the sort sees
+            # no mover. Here it flies through the grid at (48, 48, 48) cells/s while spinning at 1.5 rad/s about its vertical axis:
+            # more than one particle in ten changes its cell in every substep (mover_fraction: counted on the device)
+            sc = scenes.neo_hookean_cube(n_side=100, with_floor=True)
+            c = sc["particles"].pos.mean(0)
+            rel = sc["particles"].pos - c
+            sc["particles"].vel[:, 0] = 48.0 + 1.5 * rel[:, 2]
+            sc["particles"].vel[:, 1] = 48.0
+            sc["particles"].vel[:, 2] = 48.0 - 1.5 * rel[:, 0]
+            sc["bytes_per_particle"] = 160.0
+            extra["c2_stirred"] = slim(measure(env, sc, 1, 0, k, w, KERNEL_ELASTIC),
+                                       "the C2 cube flying through the grid at (48, 48, 48) cells/s and spinning at 1.5 rad/s: particles change cells in every substep")
+            # the caller's frame loop: 20 substeps per wgs_step call, the blocking pose read-back between the calls
+            # (src_testbed/step.rs:122-132,175-176; sand3.rs runs 20 substeps per frame)
+            sc = scenes.neo_hookean_cube(n_side=100, with_floor=True)
+            sc["bytes_per_particle"] = 160.0
+            extra["c2_frames"] = slim(measure(env, sc, 1, 0, 60 if k >= 50 else 20, 20, KERNEL_ELASTIC, frame=20),
+                                      "the headline workload stepped as the testbed does: one wgs_step call of 20 substeps per frame, wgs_read_body_poses after each")
             del sc
         sc = scenes.config_scene("c5", world, rank if sharded_path else None, "strong")
-        r = measure(env, sc, world, rank, k, w, KERNEL_ELASTIC)
-        if rank == 0:
-            extra["c5_strong"] = slim(r, sc["name"] + (f", cut into {world} x-slabs (strong scaling: fixed 16 M global)" if world > 1 else ", one GPU"))
+        if partition_ok(sc):
+            r = measure(env, sc, world, rank, k, w, KERNEL_ELASTIC)
+            if rank == 0:
+                extra["c5_strong"] = slim(r, sc["name"] + (f", cut into {world} x-slabs (strong scaling: fixed 16 M global)" if world > 1 else ", one GPU"))
         del sc
         if sharded_path and world > 1:
-            # the headline's own 1 M cube cut N ways (BASELINE.json's metric read as strong scaling). A slab must be at
-            # least two blocks wide (kernels_shard.h): 12.5 block columns cut 8 ways are not, so N = 8 has no such leg
+            # the headline's own 1 M cube cut N ways (BASELINE.json's metric read as strong scaling). A slab between two
+            # neighbours must be at least MIN_INTERIOR_WIDTH = 3 blocks wide (kernels_shard.h, wgs_shard_attach): 12.5 block
+            # columns cut 5 or more ways are not, so those N have no such leg
             sc = scenes.config_scene("c2", world, rank, "strong")
-            cuts = sc["partition"].cuts
-            if all(cuts[i + 1] - cuts[i] >= 2 for i in range(1, world - 1)):      # interior slabs
+            if partition_ok(sc):
                 r = measure(env, sc, world, rank, k, w, KERNEL_ELASTIC)
                 if rank == 0:
                     extra["c2_strong"] = slim(r, sc["name"] + f", cut into {world} x-slabs (strong scaling: fixed 1 M global)")
             elif rank == 0:
-                extra["c2_strong"] = {"skipped": f"the 50-cell cube cut into {world} x-slabs leaves slabs narrower than the two blocks the halo protocol needs"}
+                extra["c2_strong"] = {"skipped": f"the 50-cell cube cut into {world} x-slabs leaves slabs narrower than the three blocks the halo protocol needs"}
             del sc
         if sharded_path and world == 4:
             # BASELINE.json configs[3]: 8 M corotated + kinematic rotating cuboid on 4 GPUs (x-slabs)
             sc = scenes.config_scene("c4", world, rank, "strong")
-            r = measure(env, sc, world, rank, k, w, KERNEL_ELASTIC)
-            if rank == 0:
-                extra["c4_strong"] = slim(r, sc["name"] + ", cut into 4 x-slabs")
+            if partition_ok(sc):
+                r = measure(env, sc, world, rank, k, w, KERNEL_ELASTIC)
+                if rank == 0:
+                    extra["c4_strong"] = slim(r, sc["name"] + ", cut into 4 x-slabs")
             del sc
         if rank == 0:
             out["extra"] = extra
 
+    if rank == 0 and default_workload and world == 1 and not sharded_path and not args.no_live_pmc and not args.no_extra:
+        live = live_pmc_traffic()   # two short child runs of the headline workload under rocprofv3 --pmc (one counter each)
+        if live is not None:
+            out["roofline"]["traffic"] = live["bytes"]
+            out["roofline"]["traffic_raw"] = live["raw_counters_per_launch"]
+            out["roofline"]["traffic_source"] = ("measured by this run, after its timed legs: two child runs of the headline workload under rocprofv3 --kernel-trace "
+                                                 "--pmc (FETCH_SIZE, WRITE_SIZE; one counter per run), fused G2P launches only")
     if rank == 0:
         emit(out)
     if dist is not None:

@@ -166,6 +166,8 @@ typedef struct {
     uint64_t device_bytes;        /* HBM held by this wgs_data */
     uint32_t num_near_collider_blocks; /* particle-bearing blocks whose tile sees a collider (the CPIC passes' list), last substep */
     uint32_t grid_growths;        /* times the block capacity was doubled (wgs_set_grid_growth) */
+    uint64_t cell_changers;       /* particles that changed their associated cell since creation (they are what the sort has to move:
+                                     the difference of two reads / (particles x substeps) is the mover fraction per substep) */
 } wgs_stats;
 
 typedef struct wgs_pipeline wgs_pipeline;

@@ -385,6 +385,37 @@ def test_g2p_launch_shapes_are_bit_identical(hip_libs, monkeypatch):
             assert np.array_equal(getattr(a, f), getattr(b, f)), f
 
 
+@pytest.mark.parametrize("seed", [1, 4, 9, 12])
+def test_binning_inside_the_fused_g2p_is_bit_identical_to_the_rebin_launch(hip_libs, seed, monkeypatch):
+    """Single-domain data: the fused G2P bins its own output for the next substep (new cell ids, block activation and totals,
+    mover lists: g2p_body.inc, Dev::bin_next), and launch 1 of that substep's sort (k_rebin) is not launched. WGS_DEBUG =
+    1048576 brings k_rebin back. The sort is only a permutation with a canonical order inside a cell, so 150 substeps — random
+    colliders, particles flying through blocks, two table rebuilds, the calls cut at odd places with a wgs_sync between them —
+    must end bit-identical, particles, grid, block set and counts; and both must have counted the same cell-changers."""
+    from helpers import pipeline
+    from wgsparkl_amd import MpmData
+    monkeypatch.setenv("WGS_REHASH_PERIOD", "64")             # (developer override, same results; the default is 1024)
+
+    def run():
+        sc = _random_scene(seed)
+        pipe = pipeline(sc["particles"].dim)
+        data = MpmData.new(pipe, sc["params"], sc["particles"], sc["colliders"], sc["cell_width"], sc["grid_capacity"], sc["model"])
+        for k in (1, 7, 63, 2, 77):
+            pipe.step(data, k)
+            data.sync()
+        return data.read_particles(), data.read_grid(), data.read_blocks(), data.stats()
+    a, ga, ka, sa = run()
+    monkeypatch.setenv("WGS_DEBUG", "1048576")
+    b, gb, kb, sb = run()
+    for f in ("pos", "vel", "def_grad", "affine", "cdf_affinity", "dp_state"):
+        assert np.array_equal(getattr(a, f), getattr(b, f)), f
+    for x, y in zip(ga, gb):
+        assert np.array_equal(x, y)
+    assert np.array_equal(ka[0], kb[0]) and np.array_equal(ka[2], kb[2])   # (block set and counts; where a block sits in memory is up to the atomics)
+    assert sa["cell_changers"] == sb["cell_changers"] and sa["cell_changers"] > 0
+    assert sa["overflow"] == 0 and sb["overflow"] == 0
+
+
 def test_grid_update_inside_the_p2g_launch_is_bit_identical_to_its_own_launch(hip_libs, monkeypatch):
     """Single-domain simulations run the grid update as waves of the (last) P2G launch: P2G hands its slabs over
     inside the launch (write-through stores, one word per block), the waves gather past their XCD's L2

@@ -1,5 +1,5 @@
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-run() { name=$1; shift; rm -rf gpurun_out/pmc_$name; mkdir -p gpurun_out/pmc_$name; timeout 300 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d gpurun_out/pmc_$name -- python3 bench.py --steps 8 --warmup 4 --no-cpu-baseline $BENCHARGS > gpurun_out/pmc_$name/bench.log 2>&1; }
+run() { name=$1; shift; rm -rf gpurun_out/pmc_$name; mkdir -p gpurun_out/pmc_$name; timeout 300 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d gpurun_out/pmc_$name -- python3 bench.py --steps 8 --warmup 4 --no-cpu-baseline --no-live-pmc $BENCHARGS > gpurun_out/pmc_$name/bench.log 2>&1; }
 run sq1 SQ_WAVES SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY
 run sq2 SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_VALU SQ_INSTS_SALU SQ_WAIT_INST_LDS GRBM_GUI_ACTIVE
 run sq3 SQ_INSTS_SMEM SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_LDS SQ_INST_CYCLES_VMEM_WR SQ_INST_CYCLES_VMEM_RD SQ_WAVES SQ_INSTS_VALU

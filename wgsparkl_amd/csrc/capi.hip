@@ -106,6 +106,9 @@ struct wgs_data {
     uint32_t seen_nblocks = 0;         // active blocks as last seen by the host, wgs_sync or the pinned watch (0: not yet): sizes the P2G grid
     uint32_t last_ncpic = UINT32_MAX;  // near-collider list length at the last wgs_sync (picks the P2G launch shape and G2P's register budget)
     uint32_t last_nvisit = UINT32_MAX; // visit-list length at the last wgs_sync (sizes the list half of k_g2p_pair)
+    uint32_t last_movers = 0;          // CTR_MOVERS at the last wgs_sync (cumulative, modulo 2^32)
+    uint64_t movers_total = 0;         // the same, accumulated in 64 bits over the host's looks
+    bool prebinned = false;            // the last fused G2P binned its output for the coming substep (Dev::bin_next): no k_rebin launch then
     uint32_t capacity = 0;      // particle slots allocated
     uint32_t *shard_counts = nullptr;  // device scratch for pack kernels
     std::vector<void *> allocs;
@@ -263,6 +266,7 @@ wgs_status grow_grid(wgs_data *d, uint32_t new_cap) {
     HIP_TRY(hipMemsetAsync(dev.hvals, 0xff, sizeof(uint32_t) * ((size_t)dev.hmask + 1), d->stream));
     HIP_TRY(hipMemsetAsync(dev.counters + CTR_NPHYS, 0, sizeof(uint32_t), d->stream));
     d->prev_sorted = false;      // block ids start over: the next substep bins every particle through the hash map
+    d->prebinned = false;        // (what the last G2P binned went with the old arrays)
     d->cdf_generation++;
     d->last_ncpic = UINT32_MAX;
     d->last_nvisit = UINT32_MAX;
@@ -318,7 +322,7 @@ void fill_collider(ColliderDev &c, const wgs_collider &in) {
     for (int k = 0; k < 3; k++) c.com[k] = in.com[k];
 }
 
-constexpr uint32_t WGS_LAUNCH_SHAPE_SWITCHES = 128u | 1024u | 4096u | 8192u | 16384u | 32768u | 65536u | 131072u | 262144u | 524288u;  // WGS_DEBUG bits the shipped library honours
+constexpr uint32_t WGS_LAUNCH_SHAPE_SWITCHES = 128u | 1024u | 4096u | 8192u | 16384u | 32768u | 65536u | 131072u | 262144u | 524288u | 1048576u;  // WGS_DEBUG bits the shipped library honours
 constexpr uint32_t P2G_SMALL_BUDGET_MIN_PARTICLES = 600000;  // one-way CPIC P2G body at 168 VGPRs from this size on
 #ifndef WGS_REGROUP_ROUNDS
 #define WGS_REGROUP_ROUNDS 4u
@@ -596,11 +600,15 @@ wgs_status fetch_counters(wgs_data *d) {
     HIP_TRY(hipStreamSynchronize(d->stream));
     d->last_nblocks = host[CTR_NBLOCKS] < d->dev.cap ? host[CTR_NBLOCKS] : d->dev.cap;
     d->seen_nblocks = d->last_nblocks;
+    // (the list counters of the last substep: the set of its parity, layout.h; epoch of substep number s = s, counted from 1)
+    const uint32_t last_epoch = (uint32_t)d->substeps;
     d->last_ncpic = 0;  // the eight lists together
-    for (int k = 0; k < 8; k++) d->last_ncpic += std::min(host[CTR_NCPIC + 32 * k], d->dev.cap);
+    for (uint32_t k = 0; k < 8; k++) d->last_ncpic += std::min(host[ctr_ncpic(k, last_epoch)], d->dev.cap);
     d->last_ncpic = std::min(d->last_ncpic, d->dev.cap);
     d->last_nvisit = 0;  // the longest of the eight lists
-    for (int k = 0; k < 8; k++) d->last_nvisit = std::max(d->last_nvisit, std::min(host[CTR_NVISIT + 32 * k], d->dev.visit_cap));
+    for (uint32_t k = 0; k < 8; k++) d->last_nvisit = std::max(d->last_nvisit, std::min(host[ctr_nvisit(k, last_epoch)], d->dev.visit_cap));
+    d->movers_total += (uint32_t)(host[CTR_MOVERS] - d->last_movers);   // (modulo 2^32 on the device)
+    d->last_movers = host[CTR_MOVERS];
     d->sticky_errors |= host[CTR_ERRORS];
     if (host[CTR_NBLOCKS] > d->dev.cap) d->sticky_errors |= ERRBIT_OVERFLOW;
     if (host[CTR_NPHYS] > d->dev.cap / 4u * 3u) d->force_rehash = true;
@@ -685,6 +693,18 @@ template <bool TS> wgs_status enqueue_substep(wgs_data *d, int ts_slot, int part
     const bool fused_cdf = d->cpic && dev.n_rigid == 0 && !(dev.dbg & 1024u);  // (mesh cdfs are only complete after k_p2g_cdf)
     if (part != 2) dev.listed_in_perm = fused_cdf ? 1u : 0u;  // (part 2 of a sharded substep consumes what its part 1 wrote)
     const bool use_rebin = d->prev_sorted && !rehash && !(dev.dbg & 128u);
+    // Single-domain data: the fused G2P of this substep also bins its output for the next one (g2p_body.inc, Dev::bin_next), unless
+    // that substep rebuilds the table anyway (dbg bit 20 brings launch 1 of the sort, k_rebin, back: same results, tested).
+    // `prebinned`: the previous substep's G2P did so for this one.
+    const bool binned = use_rebin && d->prebinned && part == 0;
+    if (part != 2 && d->prebinned && !binned) {
+        // (a table rebuild nobody could foresee — ids three quarters handed out, seen by the host in between: what the G2P
+        // accumulated for the old ids is dropped; the stamps it left mean nothing once the ids are handed out anew)
+        HIP_TRY(hipMemsetAsync(dev.block_acc, 0, sizeof(uint32_t) * (size_t)dev.cap, s));
+        HIP_TRY(hipMemsetAsync(dev.cell_head, 0, sizeof(uint32_t) * (size_t)dev.cap * NPB, s));
+    }
+    if (part != 2) d->prebinned = false;
+    dev.bin_next = (part == 0 && !dev.sharded && !(dev.dbg & (128u | 1048576u)) && (d->substeps + 1) % d->rehash_period != 0) ? 1u : 0u;
     // the fused G2P drops the guests only inside the sharded step (kernels_shard.h); wgs_step on a slab advances what it holds
     dev.skip_guests = (d->in_sharded_step && dev.sharded) ? 1u : 0u;
     if (dev.sharded && d->needs_compact && part != 2) {
@@ -711,7 +731,9 @@ template <bool TS> wgs_status enqueue_substep(wgs_data *d, int ts_slot, int part
             // (a pending integrate_bodies of the previous substep rides in workgroup 0 of this launch)
             const uint32_t do_bodies = d->bodies_pending ? 1u : 0u;
             d->bodies_pending = false;
-            if (use_rebin) hipLaunchKernelGGL(k_rebin<D>, dim3((pgrid + REBIN_K - 1) / REBIN_K), dim3(SORT_THREADS), 0, s, dev, side, epoch, do_bodies);
+            if (binned) {   // launch 1 ran inside the previous substep's fused G2P
+                if (do_bodies) hipLaunchKernelGGL(k_bodies_integrate<D>, dim3(1), dim3(16), 0, s, dev);
+            } else if (use_rebin) hipLaunchKernelGGL(k_rebin<D>, dim3((pgrid + REBIN_K - 1) / REBIN_K), dim3(SORT_THREADS), 0, s, dev, side, epoch, do_bodies);
             else hipLaunchKernelGGL(k_bin<D>, dim3(pgrid), dim3(SORT_THREADS), 0, s, dev, side, epoch, do_bodies);
             if (dev.n_rigid > 0) {  // blocks a mesh sample reaches must exist (sort.wgsl:38-86)
                 hipLaunchKernelGGL(k_rigid_mark<D>, dim3(grid_for(d, 1)), dim3(256), 0, s, dev, epoch);
@@ -920,13 +942,15 @@ template <bool TS> wgs_status enqueue_substep(wgs_data *d, int ts_slot, int part
             }
             // Single-domain simulations without mesh colliders: left to the first launch of the next substep (or to the end of
             // this wgs_step call, flush_bodies) — a 16-thread launch of its own costs a dependent launch, ~5 us, per substep.
-            if (part == 0 && !dev.sharded && dev.n_rigid == 0 && n > 0 && !(dev.dbg & 524288u)) d->bodies_pending = true;
+            // (not when this substep's G2P binned for the next one: that substep has no launch in front of the node cdfs of its sort)
+            if (part == 0 && !dev.sharded && dev.n_rigid == 0 && n > 0 && !(dev.dbg & 524288u) && !dev.bin_next) d->bodies_pending = true;
             else hipLaunchKernelGGL(k_bodies_integrate<D>, dim3(1), dim3(16), 0, s, dev);
         }
         mark(8);
         d->side ^= 1;
         d->substeps++;
         d->prev_sorted = true;
+        d->prebinned = dev.bin_next != 0u && dev.nv > 0;
         dev.n = dev.nv;  // the buffer just written holds the valid particles only, in sorted order
         // sharded: the counters of the new buffer (CTR_N / CTR_NPREV / CTR_NV) are set by k_g2p_arrivals; a slab stepped
         // without its neighbours (wgs_step) sets them at the head of its next substep (k_shard_compacted)
@@ -1293,23 +1317,31 @@ wgs_status wgs_step(wgs_pipeline *pipeline, wgs_data *d, uint32_t num_substeps, 
         wgs_status mst = maintain_grid(d);
         if (mst != WGS_OK) return mst;
     }
+    auto flush_bodies = [&]() {   // the last substep's integrate_bodies: every other entry point finds the bodies integrated
+        if (d->bodies_pending) {
+            hipLaunchKernelGGL(k_bodies_integrate<D>, dim3(1), dim3(16), 0, d->stream, d->dev);
+            d->bodies_pending = false;
+        }
+    };
     for (uint32_t i = 0; i < num_substeps; i++) {
-        wgs_status st;
+        wgs_status st = WGS_OK;
         if (i > 0 && i % 64u == 0u) {  // long calls: keep an eye on the table inside the call too (bounded run-ahead)
-            if ((st = watch_counters(d)) != WGS_OK || (st = maintain_grid(d)) != WGS_OK) return st;
+            if ((st = watch_counters(d)) == WGS_OK) st = maintain_grid(d);
         }
-        if (timestamps && d->events.used < Events::MAX_SUBSTEPS) {
-            st = enqueue_substep<true>(d, d->events.used, 0);
-            d->events.used++;
-        } else {
-            st = enqueue_substep<false>(d, 0, 0);
+        if (st == WGS_OK) {
+            if (timestamps && d->events.used < Events::MAX_SUBSTEPS) {
+                st = enqueue_substep<true>(d, d->events.used, 0);
+                d->events.used++;
+            } else {
+                st = enqueue_substep<false>(d, 0, 0);
+            }
         }
-        if (st != WGS_OK) return st;
+        if (st != WGS_OK) {   // (the substeps enqueued so far stand: a pose read-back after a failed call sees their bodies integrated)
+            flush_bodies();
+            return st;
+        }
     }
-    if (d->bodies_pending) {   // the last substep's integrate_bodies: every other entry point finds the bodies integrated
-        hipLaunchKernelGGL(k_bodies_integrate<D>, dim3(1), dim3(16), 0, d->stream, d->dev);
-        d->bodies_pending = false;
-    }
+    flush_bodies();
     if (timestamps) d->timings_pending = true;
     return watch_counters(d);
 }
@@ -1773,6 +1805,7 @@ wgs_status wgs_get_stats(wgs_data *d, wgs_stats *out) {
     out->device_bytes = d->device_bytes;
     out->num_near_collider_blocks = d->cpic && d->last_ncpic != UINT32_MAX ? d->last_ncpic : 0u;
     out->grid_growths = d->grid_grown;
+    out->cell_changers = d->movers_total;
     return WGS_OK;
 }
 

@@ -88,13 +88,13 @@ __device__ inline uint32_t hmap_find(const Dev &d, uint32_t key, uint32_t epoch)
 // the visits, and a group stays together so that its later chunks find the block's node tile staged. One atomic per
 // group, all groups of the block at once (one lane each). The order inside a list does not matter: every particle is
 // advanced exactly once, by the visit of its chunk for its block.
-__device__ inline void append_visits(const Dev &d, uint32_t id, uint32_t start, uint32_t count, int lane) {
+__device__ inline void append_visits(const Dev &d, uint32_t id, uint32_t start, uint32_t count, int lane, uint32_t epoch) {
     const uint32_t np = d.g2p_npass;
     const uint32_t c0 = start >> 6, c1 = (start + count - 1u) >> 6, g0 = c0 / np, ng = c1 / np - g0 + 1u;
     for (uint32_t t = (uint32_t)lane; t < ng; t += 64u) {
         const uint32_t g = g0 + t, k = g & 7u;
         const uint32_t cs = max(c0, g * np), ce = min(c1, g * np + np - 1u), n = ce - cs + 1u;
-        const uint32_t slot = atomicAdd(&d.counters[CTR_NVISIT + 32u * k], n);
+        const uint32_t slot = atomicAdd(&d.counters[ctr_nvisit(k, epoch)], n);
         for (uint32_t e = 0; e < n; e++)
             if (slot + e < d.visit_cap) d.visit_list[(size_t)k * d.visit_cap + slot + e] = make_uint2(id, cs + e);
             else atomicOr(&d.counters[CTR_ERRORS], ERRBIT_OVERFLOW);  // (cannot happen within the capacity the lists are sized for; never silently)

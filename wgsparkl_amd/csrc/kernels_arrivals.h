@@ -3,8 +3,9 @@
 // the inbound messages instead of the sorted buffer: no block tile, no sort entry — every (arrival, stencil node) pair
 // looks its node up (the block's velocity if the block is active here, else the neighbour's partial sum from the
 // message, which is then the node's total), the arrival is advanced from those 3^D values and written BEHIND the
-// sorted output of the fused G2P, where the next substep's sort finds it as a new particle (k_bin, tail = 1).
-// The last workgroup to finish does the bookkeeping of the migration round.
+// sorted output of the fused G2P, in slots [NPREV, N), where launch 1 of the next substep's sort (k_rebin, or k_bin on a table
+// rebuild) bins it through the hash path like a particle that changed block. A launch of its own behind the fused G2P (capi.hip);
+// its last workgroup to finish does the bookkeeping of the migration round (the particle counters of the next substep).
 #pragma once
 #include "kernels_transfer.h"
 
@@ -12,7 +13,7 @@ namespace wgs {
 
 constexpr int ARR_PER_WG = 8;  // arrivals per 256-thread workgroup: 32 lanes look up the 3^D nodes of one arrival
 
-// Stand-alone form (launch shapes whose fused G2P does not carry the arrivals: the two-launch debug path).
+// (always a launch of its own: inside the fused G2P launch it cost more than the launch it saved)
 template <int D, int MODEL, bool PLASTIC>
 __global__ __launch_bounds__(256) void k_g2p_arrivals(Dev d, int side, uint32_t epoch) {
     __shared__ float4 s_nv[ARR_PER_WG][Dim<D>::NBH];   // node velocity (, mass)

@@ -417,9 +417,9 @@ template <int D> __global__ __launch_bounds__(CDF_THREADS) void k_cdf(Dev d, int
         const bool any = s_any[it] != 0u;
         if (tid == 0) {
             d.block_cpic[b] = any ? 1u : 0u;
-            if (any && cnt > 0) d.cpic_list[(size_t)(b & 7u) * d.cap + atomicAdd(&d.counters[CTR_NCPIC + 32u * (b & 7u)], 1u)] = b;
+            if (any && cnt > 0) d.cpic_list[(size_t)(b & 7u) * d.cap + atomicAdd(&d.counters[ctr_ncpic(b & 7u, epoch)], 1u)] = b;
         }
-        if (any && cnt > 0 && tid < 64) append_visits(d, b, d.block_start[b], cnt, tid);  // (the first wave of the workgroup)
+        if (any && cnt > 0 && tid < 64) append_visits(d, b, d.block_start[b], cnt, tid, epoch);  // (the first wave of the workgroup)
         // (3: the particle cdf of the listed blocks runs in the prologue of the CPIC P2G launch, three waves per block)
     }
 }

@@ -116,7 +116,7 @@ template <int D, bool INLAUNCH> __device__ __forceinline__ void pack_face_body(c
     if (wk == 0 && lane < 2 && d.msg.out[lane])   // layout of this rank's particle records (checked by the receiver, k_g2p_arrivals)
         reinterpret_cast<uint32_t *>(d.msg.out[lane])[2] = d.uniform ? MSG_FLAG_UNIFORM : 0u;
     if (wk < nblk_wk) {
-        const uint32_t nl = min(d.counters[CTR_NHALO], d.cap);
+        const uint32_t nl = min(d.counters[ctr_nhalo(epoch)], d.cap);
         for (uint32_t a = wk; a < nl; a += nblk_wk) {
             // the sort left everything needed in the list entry: block id, key and the slabs its nodes are gathered from
             // (its "-" neighbours that hold particles)

@@ -65,8 +65,6 @@ template <int D> __device__ __forceinline__ void bin_body(const Dev &d, int side
     const float *in = d.buf[side];
     const int tid = threadIdx.x, lane = tid & 63;
     if (tid < TOUCH_SET) s_keys[tid] = NONE;
-    if (bid == 0u && tid < 16) d.counters[(tid < 8 ? (int)CTR_NCPIC : (int)CTR_NVISIT - 256) + 32 * tid] = 0;  // near-collider lists of this substep (k_regroup appends)
-    if (bid == 0u && tid == 16) d.counters[CTR_NHALO] = 0;  // interface-block list (sharded runs)
     __syncthreads();
     const uint32_t i = bid * SORT_THREADS + tid;
     uint32_t slots_end = num_slots(d);
@@ -171,8 +169,6 @@ template <int D> __device__ __forceinline__ void rebin_body(const Dev &d, int si
     constexpr int BS = Dim<D>::BSHIFT, BW = Dim<D>::BW, NN = Dim<D>::NNBR, K = REBIN_K;
     const float *in = d.buf[side];
     const int tid = threadIdx.x, lane = tid & 63;
-    if (bid == 0u && tid < 16) d.counters[(tid < 8 ? (int)CTR_NCPIC : (int)CTR_NVISIT - 256) + 32 * tid] = 0;  // near-collider lists of this substep (k_regroup appends)
-    if (bid == 0u && tid == 16) d.counters[CTR_NHALO] = 0;  // interface-block list (sharded runs)
     // sharded runs: the residents minus the slots vacated by particles that now live on a neighbour, and behind them,
     // in [NPREV, N), the particles that arrived in the last substep (kernels_arrivals.h): they have no previous cell and
     // take the hash path below like a particle that changed block
@@ -382,6 +378,9 @@ __device__ __forceinline__ void scan_chunk(const Dev &d, uint32_t epoch, uint32_
     if (tid == 0) g_prof[WGS_PROF_ROWS - 1][0] = wall_clock64();
 #endif
     if (k == 0 && tid == 0) d.counters[CTR_NPHYS_SEEN + (epoch & 1u)] = d.counters[CTR_NPHYS];
+    // the list counters of the NEXT substep (the other set: nothing of this substep reads or appends to it; layout.h)
+    if (k == 0 && tid < 16) d.counters[tid < 8 ? ctr_ncpic((uint32_t)tid, epoch + 1u) : ctr_nvisit((uint32_t)tid - 8u, epoch + 1u)] = 0u;
+    if (k == 0 && tid == 16) d.counters[ctr_nhalo(epoch + 1u)] = 0u;
     if constexpr (SHARD) {
         if (k == 0 && tid < 4 && d.msg.out[tid >> 1]) reinterpret_cast<uint32_t *>(d.msg.out[tid >> 1])[tid & 1] = 0u;  // record counts of this substep's outgoing messages
     }
@@ -533,6 +532,12 @@ __device__ __forceinline__ void regroup_block(const Dev &d, int side, uint32_t e
                     a_pid[k + 1] = tp; a_slot[k + 1] = ts;
                 }
     }
+    if (have_old) {  // statistics: cell-changers of this substep (wgs_stats.cell_changers; every particle is on a list otherwise)
+        uint32_t na = n_arr;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) na += __shfl_xor(na, off);
+        if (lane == 0 && na != 0u) atomicAdd(&d.counters[CTR_MOVERS], na);
+    }
     const uint32_t total = n_stay + n_arr;
     uint32_t inc = total;
 #pragma unroll
@@ -553,7 +558,7 @@ __device__ __forceinline__ void regroup_block(const Dev &d, int side, uint32_t e
     const bool cdf_cached = CDF && d.cdf_gen != 0u && btotal > 0u && cdf_seen == d.cdf_gen;
     if (cdf_cached) {
         const bool any = cdf_class != 0u;
-        if (lane == 0 && any) d.cpic_list[(size_t)(id & 7u) * d.cap + atomicAdd(&d.counters[CTR_NCPIC + 32u * (id & 7u)], 1u)] = id;
+        if (lane == 0 && any) d.cpic_list[(size_t)(id & 7u) * d.cap + atomicAdd(&d.counters[ctr_ncpic(id & 7u, epoch)], 1u)] = id;
         listed = any;
         pc_flag = any ? CELL_LISTED : 0u;
     } else if (CDF WGS_ABLATE_AND(!(d.dbg & (1u << 21)))) {
@@ -603,7 +608,7 @@ __device__ __forceinline__ void regroup_block(const Dev &d, int side, uint32_t e
         if (lane == 0) {
             d.block_cpic[id] = any ? 1u : 0u;
             if (d.cdf_gen != 0u && btotal > 0u) d.block_cdf_gen[id] = d.cdf_gen;
-            if (any && btotal > 0u) d.cpic_list[(size_t)(id & 7u) * d.cap + atomicAdd(&d.counters[CTR_NCPIC + 32u * (id & 7u)], 1u)] = id;
+            if (any && btotal > 0u) d.cpic_list[(size_t)(id & 7u) * d.cap + atomicAdd(&d.counters[ctr_ncpic(id & 7u, epoch)], 1u)] = id;
         }
         listed = any && btotal > 0u;
         pc_flag = any ? CELL_LISTED : 0u;
@@ -705,13 +710,13 @@ __device__ __forceinline__ void regroup_block(const Dev &d, int side, uint32_t e
         d.links_epoch[id] = epoch;     // the neighbour links and cell runs written above are those of this substep
         // (block_acc is cleared by the grid update: the waves of this group read it)
     }
-    if (listed) append_visits(d, id, bstart, btotal, lane);
+    if (listed) append_visits(d, id, bstart, btotal, lane, epoch);
     if constexpr (SHARD) {  // block layers that travel to a neighbour: an entry k_pack_face can work from without another look-up —
         // [id, key, the 2^D slabs the block's nodes are gathered from (its "-" neighbours that hold particles: lanes 8..15)]
         const IfaceMasks im = iface_masks<D>(d, b[0]);
         if ((im.send_lo | im.send_hi) != 0u) {  // wave-uniform
             uint32_t e = 0u;
-            if (lane == 0) e = atomicAdd(&d.counters[CTR_NHALO], 1u);
+            if (lane == 0) e = atomicAdd(&d.counters[ctr_nhalo(epoch)], 1u);
             e = __shfl(e, 0);
             if (e < d.cap) {
                 uint32_t *ent = d.halo_list + (size_t)e * HALO_ENT;

@@ -25,6 +25,9 @@ namespace wgs {
 // [rank][cell] so that the 64 lanes of a wave read 64 consecutive float4 (conflict-free
 // ds_read_b128) while the global side reads whole 64-byte runs of the cell-sorted arrays.
 constexpr int P2G_J = 4;
+#ifndef WGS_P2G_ROW_PAD
+#define WGS_P2G_ROW_PAD 2   // (see ROW below; 4 = rounds 1-3)
+#endif
 #ifdef WGS_ABLATE
 // stage clocks of P2G (timing experiments, tools/gpu_p2g_prof.py): one row per active-list index of the plain body
 constexpr int WGS_P2G_ROWS = 8192;
@@ -162,7 +165,9 @@ template <int D, bool TWOWAY = false, bool INTERIOR = false> __device__ __forcei
 #pragma unroll
         for (int o = 0; o < NN; o++) st_plain(rs[o], off[o], nv);
         d.nodes[b * NPB + (uint32_t)lane] = nv;
-        if (lane == 0) d.block_acc[b] = 0u;  // the sort's per-block accumulator is zero at rest (last read: k_regroup)
+        // the sort's per-block accumulator is zero at rest (last read: k_regroup) — unless the fused G2P of this substep keeps it up
+        // to date for the next one (Dev::bin_next: only the particles that change block move a unit)
+        if (lane == 0 && !d.bin_next) d.block_acc[b] = 0u;
     }
     if constexpr (TWOWAY) {
         __syncthreads();
@@ -211,12 +216,13 @@ __global__ __launch_bounds__(P2GCfg<D>::NW * 64) void k_p2g(Dev d, int side, int
     constexpr int BW = Dim<D>::BW, BS = Dim<D>::BSHIFT, TW = Dim<D>::TW, TILE = Dim<D>::TILE;
     constexpr int NT = Cfg::NW * 64;
     constexpr int SLOTS = P2G_J * NPB;
-    constexpr int ROW = NPB + 4;                 // padded [rank] row: the J float4 a (cell) group writes land on distinct banks
+    constexpr int ROW = NPB + WGS_P2G_ROW_PAD;   // padded [rank] row: ds_write_b128 serves 8 contiguous lanes per cycle over 8 slots of 16 bytes (bank = dword mod 32);
+                                                 // the 8 lanes hold 4 ranks of 2 cells, and 2 rank + cell takes 8 values for ROW = 2 mod 8 (+ 4: ranks 0 / 2 and 1 / 3 collided)
     constexpr int KS = (SLOTS + NT - 1) / NT;    // staging slots per thread and round
     constexpr int NQ = Cfg::NQ;
     __shared__ float4 s_q[NQ][P2G_J * ROW];
     __shared__ uint32_t s_aff[CPIC ? P2G_J * ROW : 1];
-    __shared__ float4 s_tile[Cfg::NW][TILE];
+    __shared__ float4 s_tile[Cfg::NW][TileSwz<D>::SIZE];   // (swizzled: layout.h TileSwz)
     __shared__ uint32_t s_cs[NPB], s_cn[NPB];
     constexpr int IMPQ = D == 3 ? 2 : 1;  // impulse quads per node: (lin, 0), (ang, 0) | (lin.xy, ang, 0)
     __shared__ float4 s_nrm[TWOWAY ? P2G_J * ROW : 1];
@@ -278,12 +284,12 @@ __global__ __launch_bounds__(P2GCfg<D>::NW * 64, WPE) void k_p2g_pair(Dev d, int
     constexpr int BW = Dim<D>::BW, BS = Dim<D>::BSHIFT, TW = Dim<D>::TW, TILE = Dim<D>::TILE;
     constexpr int NT = Cfg::NW * 64;
     constexpr int SLOTS = P2G_J * NPB;
-    constexpr int ROW = NPB + 4;
+    constexpr int ROW = NPB + WGS_P2G_ROW_PAD;
     constexpr int KS = (SLOTS + NT - 1) / NT;
     constexpr int NQ = Cfg::NQ;
     __shared__ float4 s_q[NQ][P2G_J * ROW];
     __shared__ uint32_t s_aff[P2G_J * ROW];
-    __shared__ float4 s_tile[Cfg::NW][TILE];
+    __shared__ float4 s_tile[Cfg::NW][TileSwz<D>::SIZE];   // (swizzled: layout.h TileSwz)
     __shared__ uint32_t s_cs[NPB], s_cn[NPB];
     constexpr int IMPQ = D == 3 ? 2 : 1;
     __shared__ float4 s_nrm[TWOWAY ? P2G_J * ROW : 1];
@@ -371,7 +377,7 @@ template <int D, int PHASE, bool TWOWAY = false> __global__ __launch_bounds__(25
                 if ((im.recv | im.send_lo | im.send_hi) == 0u) continue;   // (wave-uniform: a wave is one block)
             }
         }
-        if (ln == 0u) d.block_acc[b] = 0u;  // the sort's per-block accumulator is zero at rest (last read: k_regroup)
+        if (ln == 0u && !d.bin_next) d.block_acc[b] = 0u;  // the sort's per-block accumulator is zero at rest (last read: k_regroup; see gu_waves)
         int l[3];
         l[0] = ln & (BW - 1);
         l[1] = (ln >> BS) & (BW - 1);

@@ -114,7 +114,16 @@ enum { CTR_NBLOCKS = 0, CTR_ERRORS = 1, CTR_NPHYS = 2, CTR_N = 4, CTR_NV = 5,
        CTR_NVISIT = 64,  // [64 + 32 k], k = 0..7: length of the visit list of XCD k (Dev::visit_list), one cache line each
        CTR_NCPIC = 320,  // [320 + 32 k], k = 0..7: length of list k of the near-collider blocks (Dev::cpic_list), one cache line each
        CTR_NHALO = 576,  // sharded runs: length of the list of active blocks in the interface layers (Dev::halo_list)
+       CTR_MOVERS = 608,  // particles pushed on a mover list since creation (modulo 2^32; wgs_get_stats: cell-changers per substep)
        CTR_COUNT = 640 };
+// The three list counters exist TWICE, 16 words apart (same cache line of their own): launch 2 of the sort of substep `epoch`
+// appends to set epoch & 1 — which P2G, the fused G2P and the pack waves of that substep read — and its scan workgroup
+// zeroes the other set for the next substep. No launch has to run in front of the sort just to reset them (the binning of a
+// steady-state substep is done by the fused G2P of the substep before it: g2p_body.inc).
+constexpr uint32_t CTR_PARITY = 16;
+__host__ __device__ inline uint32_t ctr_ncpic(uint32_t k, uint32_t epoch) { return (uint32_t)CTR_NCPIC + 32u * k + CTR_PARITY * (epoch & 1u); }
+__host__ __device__ inline uint32_t ctr_nvisit(uint32_t k, uint32_t epoch) { return (uint32_t)CTR_NVISIT + 32u * k + CTR_PARITY * (epoch & 1u); }
+__host__ __device__ inline uint32_t ctr_nhalo(uint32_t epoch) { return (uint32_t)CTR_NHALO + CTR_PARITY * (epoch & 1u); }
 enum { ERRBIT_OVERFLOW = 1u, ERRBIT_KEYRANGE = 2u, ERRBIT_SHARD = 4u, ERRBIT_MATERIAL = 8u, ERRBIT_HANDOVER = 16u };
 // Bit 31 of a perm_cell entry (block ids stay below 2^24): the particle's block is near a collider. Written by launch 2 of the
 // sort when it computes the block classes itself; the fused G2P then knows which body a particle belongs to from the sort
@@ -192,6 +201,8 @@ struct Dev {
                               // (a block keeps its id and therefore its place); 0: recompute every substep
     uint32_t listed_in_perm;  // this substep's perm_cell entries carry CELL_LISTED (launch 2 of the sort computed the block classes)
     uint32_t g2p_npass;       // chunks per wave of the fused G2P of this substep (defines the eighths; set by the host per substep)
+    uint32_t bin_next;        // single-domain data: the fused G2P of this substep also BINS its output for the next substep (new cell ids,
+                              // block activation and totals, mover lists — launch 1 of the next sort, k_rebin, is then not launched)
     uint32_t *counters;    // CTR_COUNT
     const SimParamsDev *sp;
     ColliderDev *colliders;  // poses / velocities are integrated on the device (kernels_bodies.h)
@@ -228,8 +239,7 @@ struct Dev {
 
 // Sharded runs keep TWO sets of the three particle counters (CTR_N, CTR_NV, CTR_NPREV; the second set CTR_SET slots
 // further): the kernels of substep n read set n & 1 (Dev::ctr_set), and the bookkeeping of the migration round — done by
-// the arrivals' workgroups INSIDE the fused G2P launch, while other waves of that launch still read the current counts —
-// writes the set of substep n + 1.
+// the last workgroup of k_g2p_arrivals (kernels_arrivals.h) — writes the set of substep n + 1.
 constexpr uint32_t CTR_SET = 16;
 __device__ inline uint32_t &ctr_cur(const Dev &d, uint32_t which) { return d.counters[which + CTR_SET * d.ctr_set]; }
 __device__ inline uint32_t &ctr_next(const Dev &d, uint32_t which) { return d.counters[which + CTR_SET * (d.ctr_set ^ 1u)]; }
@@ -290,6 +300,33 @@ template <int D> struct SlabTileMap {
     }
 };
 __constant__ SlabTileMap<WGS_DIM> g_slab_tile_map = SlabTileMap<WGS_DIM>();
+
+// P2G's per-wave accumulation tile in LDS (p2g_body.inc): NOT x + TW y + TW^2 z. In each of the nine (sx, sy) phases lane = cell
+// (lx + BW ly + BW^2 lz) reads, adds to and writes back the float4 of node (lx + sx, ly + sy, lz + sz), and with the linear
+// layout the 16-lane groups of ds_read_b128 ({0-3, 12-15, 20-27}, ...: MI355X_MICROARCH.md, LDS) land three deep on the same
+// 16-byte slots (x + 6 y mod 16 for y = 0, 3 and two rows of the next z layer), the 8-lane groups of ds_write_b128 two deep:
+// 3.0 conflict cycles per LDS instruction of the kernel (round 3, SQ_LDS_BANK_CONFLICT). Here the node (x, y, z) sits at
+//   (x mod BW) + BW (y mod BW) + BW^2 z + REG ((x div BW) + 2 (y div BW)),   REG = BW^2 * (TW layers in 3D, 1 in 2D):
+// inside a phase x mod BW and y mod BW take every value once over a z layer of cells, a z layer is a whole number of bank rows
+// and so is REG, so every lane group of either instruction touches distinct slots — no conflict in any phase — for
+// (BW / 2 + 1)^2-ish more LDS: 384 float4 per wave instead of 216 (3D), 256 instead of 100 (2D).
+template <int D> struct TileSwz {
+    static constexpr int BW = Dim<D>::BW, BS = Dim<D>::BSHIFT, TW = Dim<D>::TW;
+#ifdef WGS_P2G_LINEAR_TILE   // (A/B builds only: the layout of rounds 1-3, x + TW y + TW^2 z)
+    static constexpr int SIZE = Dim<D>::TILE;
+    __host__ __device__ static constexpr int fx(int x) { return x; }
+    __host__ __device__ static constexpr int fy(int y) { return TW * y; }
+    __host__ __device__ static constexpr int fz(int z) { return D == 3 ? TW * TW * z : 0; }
+#else
+    static constexpr int REG = BW * BW * (D == 3 ? TW : 1);
+    static constexpr int SIZE = 4 * REG;
+    __host__ __device__ static constexpr int fx(int x) { return (x & (BW - 1)) + REG * (x >> BS); }
+    __host__ __device__ static constexpr int fy(int y) { return BW * (y & (BW - 1)) + 2 * REG * (y >> BS); }
+    __host__ __device__ static constexpr int fz(int z) { return D == 3 ? BW * BW * z : 0; }
+#endif
+    // ... of tile index n = x + TW y (+ TW^2 z)
+    __host__ __device__ static constexpr int of_tile(int n) { return fx(n % TW) + fy((n / TW) % TW) + fz(D == 3 ? n / (TW * TW) : 0); }
+};
 
 // Quad access = (one uniform 64-bit buffer base in SGPRs) + (32-bit per-lane byte offset):
 // `global_load_dwordx4 v[..], v_off, s[base:base+1]`. Valid while one ping-pong buffer is

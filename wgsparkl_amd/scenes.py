@@ -11,7 +11,7 @@ import numpy as np
 
 from .models import (MODEL_COROTATED, MODEL_NEO_HOOKEAN, DruckerPrager,
                      ElasticCoefficients, ParticlePhase)
-from .solver import Collider, ParticleSet, SimulationParams
+from .solver import SHAPE_CAPSULE, Collider, ParticleSet, SimulationParams
 
 F32 = np.float32
 FLT_MAX = float(np.finfo(np.float32).max)
@@ -62,6 +62,36 @@ def reference_sand3():
                 cell_width=h, grid_capacity=60_000, model=MODEL_COROTATED,
                 name="the reference's sand3 example as shipped: 45x100x45 Drucker-Prager sand, floor + 4 walls + kinematic rotating cuboid",
                 bytes_per_particle=216.0)
+
+
+def reference_sand2():
+    """The reference's largest shipping scene as written (crates/wgsparkl2d/examples/sand2.rs:21-175): 700 x 700 = 490 000
+    Drucker-Prager sand particles (E = 1e7, nu = 0.2, rho = 1000, phase None) at spacing h/2 with h = 0.2, lifted by 46; a floor
+    and two tilted walls (fixed cuboids), three spinning cuboids, a spinning ball and a spinning capsule (kinematic), eight
+    dynamic cuboids of density 10 + 100 k dropped from y = 120; dt = 1/600, capacity 60 000. That is 16 coupled colliders,
+    the reference's limit (quirk B11). rapier's body-body contacts are not part of the MPM path: the dynamic cuboids move
+    under gravity and the sand's impulses."""
+    h = 0.2
+    i, j = np.meshgrid(np.arange(700), np.arange(700), indexing="ij")
+    pos = (np.stack([i.ravel() + 0.5, j.ravel() + 0.5], 1) * (h / 2.0)).astype(F32)
+    pos[:, 1] += F32(46.0)
+    ps = ParticleSet.uniform(pos, h / 4.0, 1000.0, ElasticCoefficients.from_young_modulus(1.0e7, 0.2),
+                             plasticity=DruckerPrager.new(1.0e7, 0.2), phase=None)
+    w = 1.0
+    colliders = [Collider.cuboid((42.0, 1.0), (35.0, -1.0), rotation=(0.0,)),
+                 Collider.cuboid((1.0, 52.0), (-25.0, 45.0), rotation=(0.5,)), Collider.cuboid((1.0, 52.0), (95.0, 45.0), rotation=(-0.5,)),
+                 Collider.cuboid((1.0, 10.0), (5.0, 35.0), rotation=(0.0,), angvel=(w,)),
+                 Collider.cuboid((10.0, 1.0), (35.0, 35.0), rotation=(0.0,), angvel=(-w,)),
+                 Collider.cuboid((1.0, 10.0), (65.0, 35.0), rotation=(0.0,), angvel=(w,)),
+                 Collider.ball(5.0, (20.0, 20.0), rotation=(0.0,), angvel=(-w,)),
+                 Collider(SHAPE_CAPSULE, (5.0, 3.0), (50.0, 20.0), rotation=(0.0,), angvel=(-w,))]
+    for k in range(8):
+        colliders.append(Collider.cuboid((5.0, 1.0), (35.0 + 3.0 * k, 120.0), rotation=(0.0,)).with_density(10.0 + 100.0 * k, 2))
+    return dict(particles=ps, params=SimulationParams(gravity=(0.0, -9.81), dt=(1.0 / 60.0) / 10.0), colliders=colliders,
+                cell_width=h, grid_capacity=60_000, model=MODEL_COROTATED,
+                name="the reference's sand2 example as shipped (2D): 700x700 Drucker-Prager sand, h = 0.2, 16 coupled colliders "
+                     "(3 fixed, 5 kinematic spinning, 8 dynamic cuboids)",
+                bytes_per_particle=144.0)
 
 
 def elastic_block_2d(nx=100, ny=100, with_floor=True, jitter=0.05):
