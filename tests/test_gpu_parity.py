@@ -416,6 +416,45 @@ def test_binning_inside_the_fused_g2p_is_bit_identical_to_the_rebin_launch(hip_l
     assert sa["overflow"] == 0 and sb["overflow"] == 0
 
 
+@pytest.mark.parametrize("which", ["dynamic_ball_and_polyline_2d", "cube_on_floor_3d", "sand_between_walls_3d"])
+def test_data_stepped_concurrently_on_their_own_streams_stay_bit_identical(hip_libs, which):
+    """Several wgs_data of one pipeline may run at the same time, each on its own stream (threading). The grid
+    update waits INSIDE the P2G launch for slabs of other workgroups (kernels_transfer.h gu_waves) — a wait that must make
+    progress, and hand over complete data, also while kernels of other data occupy the device. Four copies of a scene are
+    stepped interleaved, no synchronisation between the calls (their kernels overlap), and must end with the same bits as a
+    copy that ran alone; nobody may report a hand-over time-out."""
+    from helpers import pipeline
+    from wgsparkl_amd import MpmData
+
+    def make():
+        if which == "dynamic_ball_and_polyline_2d":
+            sc = _random_scene(1)          # a dynamic ball pushed to its velocity cap, a kinematic cuboid, a moving polyline
+        elif which == "cube_on_floor_3d":
+            sc = scenes.neo_hookean_cube(n_side=40, with_floor=True)
+            sc["particles"].pos[:, 1] -= 5.6
+            sc["particles"].vel[:, 0] = 1.5
+        else:
+            sc = scenes.sand_column(nx=12, ny=20, nz=12, with_floor=True)
+        pipe = pipeline(sc["particles"].dim)
+        return pipe, MpmData.new(pipe, sc["params"], sc["particles"], sc["colliders"], sc["cell_width"], sc["grid_capacity"], sc["model"])
+    pipe, alone = make()
+    for k in (3, 17, 20):
+        pipe.step(alone, k)
+    alone.sync()
+    ref = alone.read_particles()
+    copies = [make()[1] for _ in range(4)]
+    for k in (3, 17, 20):
+        for _ in range(k):
+            for c in copies:
+                pipe.step(c, 1)
+    for c in copies:
+        c.sync()                 # (raises on ERRBIT_HANDOVER)
+        got = c.read_particles()
+        for f in ("pos", "vel", "def_grad", "affine", "cdf_affinity", "dp_state"):
+            assert np.array_equal(getattr(got, f), getattr(ref, f)), f
+        assert c.stats()["overflow"] == 0
+
+
 def test_grid_update_inside_the_p2g_launch_is_bit_identical_to_its_own_launch(hip_libs, monkeypatch):
     """Single-domain simulations run the grid update as waves of the (last) P2G launch: P2G hands its slabs over
     inside the launch (write-through stores, one word per block), the waves gather past their XCD's L2

@@ -373,7 +373,10 @@ __device__ __forceinline__ void scan_chunk(const Dev &d, uint32_t epoch, uint32_
     const unsigned long long run = base + wave_off + inc - sum;
     publish_tagged(&d.group_a[k * SORT_THREADS + tid], epoch, (uint32_t)(run >> 32));
     publish_tagged(&d.group_b[k * SORT_THREADS + tid], epoch, (uint32_t)run);
-    if (tid == 0 && k + 1 == nchunks) d.counters[CTR_NBLOCKS] = (uint32_t)((base + total) >> 32);
+    if (tid == 0 && k + 1 == nchunks) {
+        d.counters[CTR_NBLOCKS] = (uint32_t)((base + total) >> 32);
+        d.counters[CTR_NSORTED] = (uint32_t)(base + total);
+    }
 #ifdef WGS_ABLATE
     if (tid == 0) g_prof[WGS_PROF_ROWS - 1][0] = wall_clock64();
 #endif

@@ -536,6 +536,7 @@ template <int D, int MODEL, bool PLASTIC, int CMODE, int NPASS = 1, bool SHARD =
 __global__ __launch_bounds__(G2P_THREADS, G2P_WAVES_PER_EU) void k_g2p_update(Dev d, int side, uint32_t epoch) {
     constexpr uint32_t npass = NPASS;  // (a template parameter: as a kernel argument the second pass's registers spilled in the one-pass launch)
     __shared__ float4 s_node[Dim<D>::TILE];
+    __shared__ uint32_t s_nbr[16];   // Dev::bin_next: ids of the staged block's 2^D "+" and 2^D "-" neighbours (nbr_known)
     __shared__ NodeCdf s_cdf[CMODE == 2 ? Dim<D>::TILE : 1];
 #define G2P_CMODE CMODE
 #define G2P_BX blockIdx.x
@@ -563,6 +564,7 @@ template <int D, int MODEL, bool PLASTIC, int WPE = G2P_WAVES_PER_EU, int NPASS 
 __global__ __launch_bounds__(G2P_THREADS, WPE) void k_g2p_pair(Dev d, int side, uint32_t epoch, uint32_t nmain, uint32_t nlist) {
     constexpr uint32_t npass = NPASS;
     __shared__ float4 s_node[Dim<D>::TILE];
+    __shared__ uint32_t s_nbr[16];   // Dev::bin_next: ids of the staged block's 2^D "+" and 2^D "-" neighbours (nbr_known)
     __shared__ NodeCdf s_cdf[Dim<D>::TILE];
     if (blockIdx.x >= 8u * nlist) {
         const uint32_t widx = blockIdx.x - 8u * nlist;

@@ -106,7 +106,9 @@ struct NodeCdf {        // grid.wgsl:233-240
 // Counter slots in Dev::counters
 // (the list counters sit in cache lines of their own: thousands of waves add to them in launch 2 of a collider-heavy scene while
 // every wave of that launch reads the counters of the first line; sharing a line made those reads queue behind the atomics)
-enum { CTR_NBLOCKS = 0, CTR_ERRORS = 1, CTR_NPHYS = 2, CTR_N = 4, CTR_NV = 5,
+enum { CTR_NBLOCKS = 0, CTR_ERRORS = 1, CTR_NPHYS = 2,
+       CTR_NSORTED = 3,  // particles in this substep's sorted order (the scan's grand total): all of them, unless a grid overflow or the key range left some out
+       CTR_N = 4, CTR_NV = 5,
        CTR_NPREV = 6,  // sharded runs: slots [0, NPREV) are the sorted output of the last substep, [NPREV, N) arrivals
        CTR_NLEAVE = 7,  // sharded runs: particles the last fused G2P launches found outside the core range (Dev::leavers): next substep's guests
        CTR_TICKET = 10,  // sharded runs: workgroups of k_g2p_arrivals that are done (the last one does the bookkeeping)
