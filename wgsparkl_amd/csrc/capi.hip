@@ -190,6 +190,9 @@ wgs_status alloc_grid(wgs_data *d) {
     GRID_ALLOC(&dev.block_stamp, cap);
     GRID_ALLOC(&dev.links_epoch, cap);
     GRID_ALLOC(&dev.block_acc, cap);
+    GRID_ALLOC(&dev.block_dirty, cap);
+    GRID_ALLOC(&dev.blk_narr, cap);
+    GRID_ALLOC(&dev.blk_arr, cap * BLK_ARR);
     GRID_ALLOC(&dev.active, cap);
     GRID_ALLOC(&dev.block_start, cap);
     GRID_ALLOC(&dev.act_info, cap);
@@ -257,7 +260,7 @@ wgs_status grow_grid(wgs_data *d, uint32_t new_cap) {
         hipGetLastError();  // (the failed hipMalloc is not this call's error)
         return WGS_OK;
     }
-    void *old_ptrs[] = {old.hkeys, old.hvals, old.block_key, old.block_count, old.block_stamp, old.links_epoch, old.block_acc, old.active,
+    void *old_ptrs[] = {old.hkeys, old.hvals, old.block_key, old.block_count, old.block_stamp, old.links_epoch, old.block_acc, old.block_dirty, old.blk_narr, old.blk_arr, old.active,
                         old.block_start, old.act_info, old.act_cells, old.nbr_plus, old.nbr_minus, old.nbr_known, old.act_src, old.cell_head, old.chunk_a, old.chunk_b, old.group_a, old.group_b,
                         old.cell_start, old.cell_cursor, old.nodes, old.node_cdf, old.slab, old.slab_epoch, old.block_cdf_gen, old.block_cpic, old.cpic_list, old.visit_list, old.halo_list,
                         old.imp_slab, old.mesh_min, old.mesh_aff};
@@ -702,6 +705,7 @@ template <bool TS> wgs_status enqueue_substep(wgs_data *d, int ts_slot, int part
         // accumulated for the old ids is dropped; the stamps it left mean nothing once the ids are handed out anew)
         HIP_TRY(hipMemsetAsync(dev.block_acc, 0, sizeof(uint32_t) * (size_t)dev.cap, s));
         HIP_TRY(hipMemsetAsync(dev.cell_head, 0, sizeof(uint32_t) * (size_t)dev.cap * NPB, s));
+        HIP_TRY(hipMemsetAsync(dev.blk_narr, 0, sizeof(uint32_t) * (size_t)dev.cap, s));
     }
     if (part != 2) d->prebinned = false;
     dev.bin_next = (part == 0 && !dev.sharded && !(dev.dbg & (128u | 1048576u)) && (d->substeps + 1) % d->rehash_period != 0) ? 1u : 0u;

@@ -44,6 +44,13 @@ template <int D> __device__ inline void load_cell(const Dev &d, const float *in,
 // sort.wgsl:129-137 (per-cell linked list), for movers only: slot i becomes the head of its destination
 // cell's list. cell_head holds slot + 1 (0 = empty: the array is zero at rest, k_regroup resets what it consumed).
 __device__ inline void push_mover(const Dev &d, uint32_t cid, uint32_t i) { d.mv_next[i] = atomicExch(&d.cell_head[cid], i + 1u); }
+// ... for a particle that came from another block (steady state): the first BLK_ARR arrivals of a block are recorded in the block's
+// array — the wave that regroups the block fetches them with one coalesced load —, the others go on their cell's list.
+__device__ inline void push_arrival(const Dev &d, uint32_t cid, uint32_t i) {
+    const uint32_t pos = atomicAdd(&d.blk_narr[cid >> 6], 1u);
+    if (pos < BLK_ARR) d.blk_arr[(size_t)(cid >> 6) * BLK_ARR + pos] = i;
+    else push_mover(d, cid, i);
+}
 
 // sort.wgsl:89-99 update_block_particle_count, aggregated: one atomic per (wave, block). Wave-uniform control flow.
 __device__ inline void count_blocks(const Dev &d, int lane, uint32_t myid) {
@@ -256,7 +263,10 @@ template <int D> __device__ __forceinline__ void rebin_body(const Dev &d, int si
         if (in_range[k]) {  // (a vacated slot gets NONE: k_regroup skips it)
             const uint32_t cid = myid == NONE ? NONE : myid * NPB + local;
             d.cellid[idx[k]] = cid;
-            if (cid != NONE && cid != old[k]) push_mover(d, cid, idx[k]);
+            if (old[k] != NONE && cid != old[k]) d.block_dirty[old[k] >> 6] = epoch;   // its previous block's run changes
+            // (on a list only when it came from another block — or from a neighbouring rank: no previous cell;
+            // a particle that changed cell inside its block is met by the wave that regroups the block)
+            if (cid != NONE && (old[k] == NONE || (cid >> 6) != (old[k] >> 6))) push_arrival(d, cid, idx[k]);
         }
     }
 }
@@ -441,6 +451,9 @@ __device__ __forceinline__ void regroup_block(const Dev &d, int side, uint32_t e
     uint32_t cs_old = d.cell_start[idx], ce_old = d.cell_cursor[idx];
     const uint32_t head = d.cell_head[idx];
     const uint32_t bkey = d.block_key[id];
+    const uint32_t dirty_at = d.block_dirty[id];
+    const uint32_t narr = d.blk_narr[id];                                 // arrivals from other blocks ...
+    uint32_t a_ent = NONE;                                                // ... lane's entry of their array (fetched when there are any)
     uint32_t cdf_seen = 0u, cdf_class = 0u;
     if constexpr (CDF) {
         cdf_seen = d.block_cdf_gen[id];
@@ -468,12 +481,26 @@ __device__ __forceinline__ void regroup_block(const Dev &d, int side, uint32_t e
     const uint32_t run0 = __shfl(cs_old, 0), run1 = __shfl(ce_old, 63);
     const uint32_t runlen = run1 - run0;
     const bool in_lds = runlen <= (uint32_t)RUNCAP;
-    const bool any_arr = __ballot(head != 0u) != 0ull;
-    if (in_lds) {
-        for (uint32_t t = lane; t < runlen; t += 64) s_in[t] = d.cellid[run0 + t];
-        if (any_arr)
-            for (uint32_t t = lane; t < runlen; t += 64) s_pid[t] = ldpid<D>(in, d.npad, run0 + t);
+    const uint32_t narr_in = min(narr, BLK_ARR);          // (wave-uniform)
+    const bool any_arr = __ballot(head != 0u) != 0ull || narr != 0u;   // particles from other blocks
+    uint32_t a_cell = NONE, a_epid = 0u;                  // the array arrival of this lane: its new cell and its id
+    if ((uint32_t)lane < narr_in) {
+        a_ent = d.blk_arr[(size_t)id * BLK_ARR + (uint32_t)lane];
+        a_cell = d.cellid[a_ent];
+        a_epid = ldpid<D>(in, d.npad, a_ent);
+        if ((a_cell >> 6) != id) a_cell = NONE;           // (never: the particle named this block)
+    } else {
+        a_ent = NONE;
     }
+    // Every particle of the previous run is still in its cell (nobody flagged the block for this substep; a slab cannot
+    // tell: a slot vacated by a migrated particle is not flagged by anybody it belongs to): the runs only move, nothing
+    // of the run has to be looked at — unless particles arrive, whose ids are merged with the stayers'.
+    const bool clean = !SHARD && dirty_at != epoch;
+    const bool need_ids = !clean || any_arr;
+    if (in_lds && !clean)
+        for (uint32_t t = lane; t < runlen; t += 64) s_in[t] = d.cellid[run0 + t];
+    if (in_lds && need_ids)
+        for (uint32_t t = lane; t < runlen; t += 64) s_pid[t] = ldpid<D>(in, d.npad, run0 + t);
     // ---- neighbour links (replaces the per-thread hash lookups of p2g.wgsl:238-275 / g2p.wgsl:72-132)
     uint32_t res = NONE;
     int b[3] = {0, 0, 0};
@@ -504,18 +531,51 @@ __device__ __forceinline__ void regroup_block(const Dev &d, int side, uint32_t e
     auto new_cell_of = [&](uint32_t i) {
         return in_lds ? __hip_atomic_load(&s_in[i - run0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT) : d.cellid[i];
     };
+    // (a particle of this cell's previous run that is still in the cell)
+    auto stays_here = [&](uint32_t i) { return clean || new_cell_of(i) == idx; };
     auto pid_of_old = [&](uint32_t i) {
         return in_lds ? __hip_atomic_load(&s_pid[i - run0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT) : ldpid<D>(in, d.npad, i);
     };
     WGS_PROF(1)
-    // ---- pass 1: members of the new run = stayers of the previous run + arrivals on the list. The first ARRC
-    // arrivals are kept in registers with their ids (next pointer and id of a node are fetched together).
+    // ---- pass 1: members of the new run = stayers of the previous run + arrivals. Arrivals from OTHER blocks are on the
+    // cell's list (sort.wgsl:129-137, for them only); a particle that changed cell INSIDE the block is on no list: the lane of
+    // its old cell meets it here, in its own range of the previous run, and hands it to its new cell through LDS (a
+    // counter and ARRC slots per cell; LDS atomics: the order of the slots is arbitrary, they are sorted by id below).
+    // The first ARRC arrivals of a cell are kept in registers with their ids.
     constexpr int ARRC = 4;
     uint32_t a_slot[ARRC], a_pid[ARRC];
 #pragma unroll
     for (int k = 0; k < ARRC; k++) { a_slot[k] = NONE; a_pid[k] = NONE; }
-    uint32_t n_stay = 0, n_arr = 0;
-    for (uint32_t i = cs_old; i < ce_old; i++) n_stay += new_cell_of(i) == idx ? 1u : 0u;
+    uint32_t n_stay = ce_old - cs_old, n_arr = 0, n_in = 0;
+    static_assert(RUNCAP >= 64 + 2 * 64 * ARRC, "the hand-over arrays alias the output stage");
+    uint32_t *s_acnt = s_out, *s_aslot = s_out + 64, *s_apid = s_out + 64 + 64 * ARRC;   // (aliases: read into registers before pass 2 writes s_out)
+    auto hand_over = [&](uint32_t c, uint32_t slot, uint32_t pid) {   // to cell c of this block
+        const uint32_t k = __hip_atomic_fetch_add(&s_acnt[c & 63u], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+        if (k < (uint32_t)ARRC) {
+            __hip_atomic_store(&s_aslot[(c & 63u) * ARRC + k], slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+            __hip_atomic_store(&s_apid[(c & 63u) * ARRC + k], pid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+        }
+    };
+    if (!clean || narr_in != 0u) {
+        __hip_atomic_store(&s_acnt[lane], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+        if (!clean) {
+            n_stay = 0;
+            for (uint32_t i = cs_old; i < ce_old; i++) {
+                const uint32_t c = new_cell_of(i);
+                if (c == idx) n_stay++;
+                else if ((c >> 6) == id) hand_over(c, i, pid_of_old(i));   // (NONE, a particle left out of the sort, is nobody's)
+            }
+        }
+        if (a_cell != NONE) hand_over(a_cell, a_ent, a_epid);   // the arrivals from other blocks, from the block's array
+        n_in = __hip_atomic_load(&s_acnt[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);   // (the wave ran all of the above in every lane)
+#pragma unroll
+        for (int k = 0; k < ARRC; k++)
+            if ((uint32_t)k < n_in) {
+                a_slot[k] = __hip_atomic_load(&s_aslot[lane * ARRC + k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                a_pid[k] = __hip_atomic_load(&s_apid[lane * ARRC + k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+            }
+        n_arr = n_in;
+    }
     for (uint32_t a = head; a != 0u;) {
         const uint32_t nxt = d.mv_next[a - 1u], p = ldpid<D>(in, d.npad, a - 1u);
 #pragma unroll
@@ -639,6 +699,10 @@ __device__ __forceinline__ void regroup_block(const Dev &d, int side, uint32_t e
     bool have_last = false;
     uint32_t last_pid = 0, last_slot = 0;
     const bool cached = n_arr <= (uint32_t)ARRC;
+    // A cell with more arrivals than fit the registers (rare in a steady flow) is sorted by the WHOLE wave further down when the
+    // block fits the LDS stages and the cell holds at most 64 particles; its lane sits the merge out.
+    const bool coop_ok = in_lds && out_lds;   // (wave-uniform)
+    const bool coop_me = !cached && coop_ok && total <= 64u;
     auto next_arrival = [&]() {
         arr_slot = NONE;
         if (cached) {  // k-th entry of the sorted register copy
@@ -648,9 +712,10 @@ __device__ __forceinline__ void regroup_block(const Dev &d, int side, uint32_t e
             arr_k++;
             return;
         }
-        // long list: smallest (id, slot) on it that is above the last one taken. Ids are unique in a healthy run; after
-        // a reported grid overflow the buffer can hold the same particle twice, and the merge must still place every
-        // list node exactly once (slots are unique).
+        // more than ARRC arrivals (rare): the smallest (id, slot) above the last one taken, among the list (other blocks)
+        // and the particles of the block's previous run that name this cell as their new one (other cells of this block).
+        // Ids are unique in a healthy run; after a reported grid overflow the buffer can hold the same particle twice, and
+        // the merge must still place every arrival exactly once (slots are unique).
         unsigned long long best = ~0ull;
         const unsigned long long last_key = ((unsigned long long)last_pid << 32) | last_slot;
         for (uint32_t a = head; a != 0u; a = d.mv_next[a - 1u]) {
@@ -658,14 +723,30 @@ __device__ __forceinline__ void regroup_block(const Dev &d, int side, uint32_t e
             if (have_last && key <= last_key) continue;
             if (key < best) best = key;
         }
+        if (n_in != 0u) {
+            if (!clean)
+                for (uint32_t i = run0; i < run1; i++) {
+                    if ((i >= cs_old && i < ce_old) || new_cell_of(i) != idx) continue;
+                    const unsigned long long key = ((unsigned long long)pid_of_old(i) << 32) | i;
+                    if (have_last && key <= last_key) continue;
+                    if (key < best) best = key;
+                }
+            for (uint32_t t = 0; t < narr_in; t++) {   // (the block's array of arrivals from other blocks)
+                const uint32_t sl = d.blk_arr[(size_t)id * BLK_ARR + t];
+                if (d.cellid[sl] != idx) continue;
+                const unsigned long long key = ((unsigned long long)ldpid<D>(in, d.npad, sl) << 32) | sl;
+                if (have_last && key <= last_key) continue;
+                if (key < best) best = key;
+            }
+        }
         if (best != ~0ull) {
             arr_slot = (uint32_t)best;
             arr_pid = (uint32_t)(best >> 32);
         }
     };
-    if (n_arr) next_arrival();
-    for (uint32_t i = cs_old; i < ce_old; i++) {
-        if (new_cell_of(i) != idx) continue;
+    if (n_arr && !coop_me) next_arrival();
+    for (uint32_t i = cs_old; i < (coop_me ? cs_old : ce_old); i++) {
+        if (!stays_here(i)) continue;
         if (arr_slot != NONE) {
             const uint32_t ps = pid_of_old(i);
             while (arr_slot != NONE && arr_pid < ps) {
@@ -685,6 +766,51 @@ __device__ __forceinline__ void regroup_block(const Dev &d, int side, uint32_t e
         last_slot = arr_slot;
         next_arrival();
     }
+    // ---- cells with many arrivals, one at a time, by the whole wave: (1) the members of the new run — the particles of the
+    // block's previous run that name the cell (stayers and arrivals from other cells alike: one coalesced look at the staged
+    // cell ids) and the list of arrivals from other blocks — go to the cell's range of the output stage in any order;
+    // (2) lane m holds member m with its id and counts the members with a smaller (id, slot): its place in canonical order.
+    for (unsigned long long slow = __ballot(coop_me); slow != 0ull; slow &= slow - 1ull) {
+        const int c = __ffsll((long long)slow) - 1;
+        const uint32_t c_idx = id * NPB + (uint32_t)c;
+        const uint32_t c_cs = __shfl(cs_old, c), c_ce = __shfl(ce_old, c), c_head = __shfl(head, c), c_lstart = __shfl(lstart, c), c_total = __shfl(total, c);
+        uint32_t cnt = 0u;
+        for (uint32_t t0 = 0; t0 < runlen; t0 += 64u) {
+            const uint32_t t = t0 + (uint32_t)lane, i = run0 + t;
+            const bool m = t < runlen && (clean ? (i >= c_cs && i < c_ce) : new_cell_of(i) == c_idx);
+            const unsigned long long mm = __ballot(m);
+            if (m) {
+                const uint32_t at = c_lstart + cnt + (uint32_t)__popcll(mm & ((1ull << lane) - 1ull));
+                if (at < c_lstart + c_total) __hip_atomic_store(&s_out[at], i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+            }
+            cnt += (uint32_t)__popcll(mm);
+        }
+        {   // the arrivals from other blocks that name the cell: from the block's array (lane = entry) ...
+            const bool m = a_cell == c_idx;
+            const unsigned long long mm = __ballot(m);
+            if (m) {
+                const uint32_t at = c_lstart + cnt + (uint32_t)__popcll(mm & ((1ull << lane) - 1ull));
+                if (at < c_lstart + c_total) __hip_atomic_store(&s_out[at], a_ent, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+            }
+            cnt += (uint32_t)__popcll(mm);
+        }
+        if (lane == 0)   // ... and from the cell's list
+            for (uint32_t a = c_head; a != 0u && cnt < c_total; a = d.mv_next[a - 1u]) {
+                __hip_atomic_store(&s_out[c_lstart + cnt], a - 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                cnt++;
+            }
+        // (c_total = stayers + arrivals as counted in pass 1: the same particles)
+        unsigned long long key = ~0ull;
+        if ((uint32_t)lane < c_total) {
+            const uint32_t sl = __hip_atomic_load(&s_out[c_lstart + (uint32_t)lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+            const uint32_t pd = (sl >= run0 && sl < run1) ? pid_of_old(sl) : ldpid<D>(in, d.npad, sl);
+            key = ((unsigned long long)pd << 32) | sl;
+        }
+        uint32_t rank = 0u;
+        for (uint32_t m = 0; m < c_total; m++) rank += __shfl(key, (int)m) < key ? 1u : 0u;
+        if ((uint32_t)lane < c_total)
+            __hip_atomic_store(&s_out[c_lstart + rank], ((uint32_t)c << 26) | (uint32_t)key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+    }
     WGS_PROF(4)
     if (out_lds) fetch_bstart();
     WGS_PROF(5)
@@ -699,6 +825,7 @@ __device__ __forceinline__ void regroup_block(const Dev &d, int side, uint32_t e
     d.cell_cursor[idx] = bstart + lstart + total;
     d.act_cells[(size_t)aidx * NPB + lane] = make_uint2(bstart + lstart, bstart + lstart + total);   // (the same, where P2G finds it without the block id)
     if (head != 0u) d.cell_head[idx] = 0u;
+    if (lane == 0 && narr != 0u) d.blk_narr[id] = 0u;
     if (d.n_rigid != 0u) {             // mesh-collider cdf accumulators of this substep (k_p2g_cdf)
         d.mesh_min[idx] = ~0ull;
         d.mesh_aff[idx] = 0u;

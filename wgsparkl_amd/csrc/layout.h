@@ -25,6 +25,7 @@ namespace wgs {
 constexpr uint32_t NONE = 0xffffffffu;
 constexpr uint32_t PID_DEAD = 0xffffffffu;  // sharded runs: slot of a particle that now lives on a neighbouring rank
 constexpr int NPB = 64;  // nodes (= cells) per block: 4^3 or 8^2, grid.wgsl:43
+constexpr uint32_t BLK_ARR = 64;  // arrivals from other blocks a block records as an array (Dev::blk_arr)
 
 template <int D> struct Dim;
 template <> struct Dim<3> {
@@ -170,6 +171,11 @@ struct Dev {
     uint32_t *block_stamp; // cap: epoch of the last substep in which the block was active
     uint32_t *links_epoch; // cap: epoch at which nbr_plus / nbr_minus of the block were last written
     uint32_t *block_acc;   // cap: particle counter being accumulated by k_bin / k_rebin (zero at rest)
+    uint32_t *blk_narr;    // cap: particles that came into the block from OTHER blocks in this substep (zero outside the sort) ...
+    uint32_t *blk_arr;     // cap*BLK_ARR: ... and the slots of the first BLK_ARR of them, in arrival order (arbitrary); the others are on
+                           // their cell's list (cell_head). One coalesced load for the wave that regroups the block, no pointer chasing
+    uint32_t *block_dirty; // cap: epoch of the last substep for which some particle of the block's previous run is no longer in its cell
+                           // (it moved to another cell, left the block or was dropped); a block that is not dirty and has no arrivals keeps its runs
     uint32_t *block_count; // cap: particles whose associated cell is in the block (num_particles)
     uint32_t *block_start; // cap: exclusive scan of block_count over the active list (first_particle)
     uint32_t *active;      // cap: physical ids of the blocks active in this substep, [0, num_active_blocks)
@@ -180,7 +186,9 @@ struct Dev {
     uint32_t *act_src;     // cap*8, by ACTIVE-LIST index: the b - {0,1}^D neighbours that hold particles (the slabs a node of b is
                            // gathered from), NONE otherwise — what the grid update reads instead of links + counts
     uint32_t *nbr_known;   // cap*16: the same 16 neighbours' ids if they are in the table at all (active or not), NONE if absent
-    uint32_t *cell_head;   // cap*64: head of the cell's list of movers of this substep (slot + 1; zero outside the sort)
+    uint32_t *cell_head;   // cap*64: head of the cell's list of arrivals that did not fit blk_arr, and of every particle on a table-rebuild
+                           // substep (slot + 1; zero outside the sort). A particle that changed cell inside its block is on no list: the wave that regroups the block meets
+                           // it in the block's previous run and hands it to its new cell through LDS (kernels_sort.h regroup_block)
     uint32_t *cell_start;  // cap*64
     uint32_t *cell_cursor; // cap*64: end of the cell's range in perm
     unsigned long long *chunk_a, *chunk_b;  // cap / 4096: (epoch << 32 | active blocks), (epoch << 32 | particles) of a scan chunk
