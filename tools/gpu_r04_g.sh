@@ -1,5 +1,7 @@
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-D=gpurun_out/r04_g; mkdir -p $D
-for sc in stirred; do
-LIBDIR=tools/tmp_prof LIB=ablate CMD="python tools/gpu_sort_prof.py $sc" bash tools/gpu_with_lib.sh 2>&1 | grep -v amdgpu.ids | tee $D/sort_prof_$sc.log
+for i in 1 2; do
+for bits in 0 1048576; do
+WGS_DEBUG=$bits timeout 200 python bench.py --steps 60 --warmup 10 --no-cpu-baseline --no-extra --allow-debug-switches --no-floor 2>/dev/null | python3 -c "
+import sys,json; d=json.loads(sys.stdin.read()); print('nofloor dbg=$bits', round(d['ms_per_step']*1e3,1), {a:round(b*1e3,1) for a,b in d['pass_ms_per_step'].items() if b>0.006})"
+done
 done

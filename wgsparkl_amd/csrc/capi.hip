@@ -192,6 +192,7 @@ wgs_status alloc_grid(wgs_data *d) {
     GRID_ALLOC(&dev.block_acc, cap);
     GRID_ALLOC(&dev.block_dirty, cap);
     GRID_ALLOC(&dev.blk_narr, cap);
+    GRID_ALLOC(&dev.block_ident, cap);
     GRID_ALLOC(&dev.blk_arr, cap * BLK_ARR);
     GRID_ALLOC(&dev.active, cap);
     GRID_ALLOC(&dev.block_start, cap);
@@ -260,7 +261,7 @@ wgs_status grow_grid(wgs_data *d, uint32_t new_cap) {
         hipGetLastError();  // (the failed hipMalloc is not this call's error)
         return WGS_OK;
     }
-    void *old_ptrs[] = {old.hkeys, old.hvals, old.block_key, old.block_count, old.block_stamp, old.links_epoch, old.block_acc, old.block_dirty, old.blk_narr, old.blk_arr, old.active,
+    void *old_ptrs[] = {old.hkeys, old.hvals, old.block_key, old.block_count, old.block_stamp, old.links_epoch, old.block_acc, old.block_dirty, old.blk_narr, old.blk_arr, old.block_ident, old.active,
                         old.block_start, old.act_info, old.act_cells, old.nbr_plus, old.nbr_minus, old.nbr_known, old.act_src, old.cell_head, old.chunk_a, old.chunk_b, old.group_a, old.group_b,
                         old.cell_start, old.cell_cursor, old.nodes, old.node_cdf, old.slab, old.slab_epoch, old.block_cdf_gen, old.block_cpic, old.cpic_list, old.visit_list, old.halo_list,
                         old.imp_slab, old.mesh_min, old.mesh_aff};
@@ -610,8 +611,10 @@ wgs_status fetch_counters(wgs_data *d) {
     d->last_ncpic = std::min(d->last_ncpic, d->dev.cap);
     d->last_nvisit = 0;  // the longest of the eight lists
     for (uint32_t k = 0; k < 8; k++) d->last_nvisit = std::max(d->last_nvisit, std::min(host[ctr_nvisit(k, last_epoch)], d->dev.visit_cap));
-    d->movers_total += (uint32_t)(host[CTR_MOVERS] - d->last_movers);   // (modulo 2^32 on the device)
-    d->last_movers = host[CTR_MOVERS];
+    uint32_t movers = 0u;   // (16 partial counts, each modulo 2^32: so is their sum)
+    for (int k = 0; k < 16; k++) movers += host[CTR_MOVERS + 32 * k];
+    d->movers_total += (uint32_t)(movers - d->last_movers);
+    d->last_movers = movers;
     d->sticky_errors |= host[CTR_ERRORS];
     if (host[CTR_NBLOCKS] > d->dev.cap) d->sticky_errors |= ERRBIT_OVERFLOW;
     if (host[CTR_NPHYS] > d->dev.cap / 4u * 3u) d->force_rehash = true;

@@ -262,7 +262,7 @@ template <int D> __device__ __forceinline__ void rebin_body(const Dev &d, int si
         }
         if (in_range[k]) {  // (a vacated slot gets NONE: k_regroup skips it)
             const uint32_t cid = myid == NONE ? NONE : myid * NPB + local;
-            d.cellid[idx[k]] = cid;
+            d.cellid[idx[k]] = (cid != NONE && old[k] != NONE && cid != old[k]) ? (cid | CELL_MOVED) : cid;
             if (old[k] != NONE && cid != old[k]) d.block_dirty[old[k] >> 6] = epoch;   // its previous block's run changes
             // (on a list only when it came from another block — or from a neighbouring rank: no previous cell;
             // a particle that changed cell inside its block is met by the wave that regroups the block)
@@ -436,8 +436,9 @@ __device__ inline void block_prefix(const Dev &d, uint32_t epoch, uint32_t id, i
 // `have_old`: the buffer is the sorted output of the previous substep (cell_start / cell_cursor of a block whose
 // links are one epoch old describe its previous runs: that is where the stayers are); otherwise every particle is
 // on a list.
+// Returns the number of particles of the block's new run that changed cell in the last step (statistics, wave-uniform).
 template <int D, bool CDF, bool SHARD>
-__device__ __forceinline__ void regroup_block(const Dev &d, int side, uint32_t epoch, uint32_t id, uint32_t nphys, bool have_old, bool no_new_blocks,
+__device__ __forceinline__ uint32_t regroup_block(const Dev &d, int side, uint32_t epoch, uint32_t id, uint32_t nphys, bool have_old, bool no_new_blocks,
                                               uint32_t *s_in, uint32_t *s_out, uint32_t *s_pid) {
     constexpr int NN = Dim<D>::NNBR;
     const int lane = threadIdx.x & 63;
@@ -452,6 +453,7 @@ __device__ __forceinline__ void regroup_block(const Dev &d, int side, uint32_t e
     const uint32_t head = d.cell_head[idx];
     const uint32_t bkey = d.block_key[id];
     const uint32_t dirty_at = d.block_dirty[id];
+    const uint32_t bstart_old = d.block_start[id], ident = d.block_ident[id];
     const uint32_t narr = d.blk_narr[id];                                 // arrivals from other blocks ...
     uint32_t a_ent = NONE;                                                // ... lane's entry of their array (fetched when there are any)
     uint32_t cdf_seen = 0u, cdf_class = 0u;
@@ -462,7 +464,7 @@ __device__ __forceinline__ void regroup_block(const Dev &d, int side, uint32_t e
     uint32_t link = NONE;
     if (lane < 16) link = d.nbr_known[id * 16u + lane];
     const GroupLoads grp = block_prefix_loads(d, id, lane);
-    if (stamp != epoch) return;  // wave-uniform: not active in this substep
+    if (stamp != epoch) return 0u;  // wave-uniform: not active in this substep
     const bool old_ok = have_old && le == epoch - 1u;
     if (!old_ok) {
         cs_old = ce_old = 0u;
@@ -486,7 +488,7 @@ __device__ __forceinline__ void regroup_block(const Dev &d, int side, uint32_t e
     uint32_t a_cell = NONE, a_epid = 0u;                  // the array arrival of this lane: its new cell and its id
     if ((uint32_t)lane < narr_in) {
         a_ent = d.blk_arr[(size_t)id * BLK_ARR + (uint32_t)lane];
-        a_cell = d.cellid[a_ent];
+        a_cell = cell_of(d.cellid[a_ent]);
         a_epid = ldpid<D>(in, d.npad, a_ent);
         if ((a_cell >> 6) != id) a_cell = NONE;           // (never: the particle named this block)
     } else {
@@ -497,8 +499,17 @@ __device__ __forceinline__ void regroup_block(const Dev &d, int side, uint32_t e
     // of the run has to be looked at — unless particles arrive, whose ids are merged with the stayers'.
     const bool clean = !SHARD && dirty_at != epoch;
     const bool need_ids = !clean || any_arr;
-    if (in_lds && !clean)
-        for (uint32_t t = lane; t < runlen; t += 64) s_in[t] = d.cellid[run0 + t];
+    // The block's new run is built by the whole wave at once (below: a counting sort by new cell, then every cell orders its own
+    // few particles by id) when something changed, the previous run and what arrives fit the LDS stages, and nobody is on a
+    // cell's list (lists: table-rebuild substeps, and arrivals beyond a block's array); lane by lane, cell by cell, otherwise.
+    uint32_t n_moved = 0u;   // (wave-uniform) statistics: particles of this block's new run that changed cell
+    const bool par = old_ok && need_ids && in_lds && __ballot(head != 0u) == 0ull && runlen + narr_in <= (uint32_t)RUNCAP;   // (wave-uniform)
+    if (in_lds && (!clean || par))
+        for (uint32_t t = lane; t < runlen; t += 64) {
+            const uint32_t e = d.cellid[run0 + t];
+            s_in[t] = cell_of(e);
+            n_moved += (uint32_t)__popcll(__ballot(e != NONE && (e & CELL_MOVED) != 0u && (cell_of(e) >> 6) == id));   // (came from another cell of this block)
+        }
     if (in_lds && need_ids)
         for (uint32_t t = lane; t < runlen; t += 64) s_pid[t] = ldpid<D>(in, d.npad, run0 + t);
     // ---- neighbour links (replaces the per-thread hash lookups of p2g.wgsl:238-275 / g2p.wgsl:72-132)
@@ -529,7 +540,7 @@ __device__ __forceinline__ void regroup_block(const Dev &d, int side, uint32_t e
     // (single wave: LDS accesses of a wave execute in order, the relaxed wavefront-scope atomics below keep the
     // compiler from reordering or forwarding across lanes)
     auto new_cell_of = [&](uint32_t i) {
-        return in_lds ? __hip_atomic_load(&s_in[i - run0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT) : d.cellid[i];
+        return in_lds ? __hip_atomic_load(&s_in[i - run0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT) : cell_of(d.cellid[i]);
     };
     // (a particle of this cell's previous run that is still in the cell)
     auto stays_here = [&](uint32_t i) { return clean || new_cell_of(i) == idx; };
@@ -537,88 +548,16 @@ __device__ __forceinline__ void regroup_block(const Dev &d, int side, uint32_t e
         return in_lds ? __hip_atomic_load(&s_pid[i - run0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT) : ldpid<D>(in, d.npad, i);
     };
     WGS_PROF(1)
-    // ---- pass 1: members of the new run = stayers of the previous run + arrivals. Arrivals from OTHER blocks are on the
-    // cell's list (sort.wgsl:129-137, for them only); a particle that changed cell INSIDE the block is on no list: the lane of
-    // its old cell meets it here, in its own range of the previous run, and hands it to its new cell through LDS (a
-    // counter and ARRC slots per cell; LDS atomics: the order of the slots is arbitrary, they are sorted by id below).
-    // The first ARRC arrivals of a cell are kept in registers with their ids.
-    constexpr int ARRC = 4;
-    uint32_t a_slot[ARRC], a_pid[ARRC];
-#pragma unroll
-    for (int k = 0; k < ARRC; k++) { a_slot[k] = NONE; a_pid[k] = NONE; }
-    uint32_t n_stay = ce_old - cs_old, n_arr = 0, n_in = 0;
-    static_assert(RUNCAP >= 64 + 2 * 64 * ARRC, "the hand-over arrays alias the output stage");
-    uint32_t *s_acnt = s_out, *s_aslot = s_out + 64, *s_apid = s_out + 64 + 64 * ARRC;   // (aliases: read into registers before pass 2 writes s_out)
-    auto hand_over = [&](uint32_t c, uint32_t slot, uint32_t pid) {   // to cell c of this block
-        const uint32_t k = __hip_atomic_fetch_add(&s_acnt[c & 63u], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-        if (k < (uint32_t)ARRC) {
-            __hip_atomic_store(&s_aslot[(c & 63u) * ARRC + k], slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-            __hip_atomic_store(&s_apid[(c & 63u) * ARRC + k], pid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-        }
-    };
-    if (!clean || narr_in != 0u) {
-        __hip_atomic_store(&s_acnt[lane], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-        if (!clean) {
-            n_stay = 0;
-            for (uint32_t i = cs_old; i < ce_old; i++) {
-                const uint32_t c = new_cell_of(i);
-                if (c == idx) n_stay++;
-                else if ((c >> 6) == id) hand_over(c, i, pid_of_old(i));   // (NONE, a particle left out of the sort, is nobody's)
-            }
-        }
-        if (a_cell != NONE) hand_over(a_cell, a_ent, a_epid);   // the arrivals from other blocks, from the block's array
-        n_in = __hip_atomic_load(&s_acnt[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);   // (the wave ran all of the above in every lane)
-#pragma unroll
-        for (int k = 0; k < ARRC; k++)
-            if ((uint32_t)k < n_in) {
-                a_slot[k] = __hip_atomic_load(&s_aslot[lane * ARRC + k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-                a_pid[k] = __hip_atomic_load(&s_apid[lane * ARRC + k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-            }
-        n_arr = n_in;
-    }
-    for (uint32_t a = head; a != 0u;) {
-        const uint32_t nxt = d.mv_next[a - 1u], p = ldpid<D>(in, d.npad, a - 1u);
-#pragma unroll
-        for (int k = 0; k < ARRC; k++)
-            if (n_arr == (uint32_t)k) { a_slot[k] = a - 1u; a_pid[k] = p; }
-        n_arr++;
-        a = nxt;
-    }
-    if (n_arr > 1u && n_arr <= (uint32_t)ARRC) {  // ascending id (empty entries hold NONE = the largest value)
-#pragma unroll
-        for (int pass = 0; pass < ARRC; pass++)
-#pragma unroll
-            for (int k = pass & 1; k + 1 < ARRC; k += 2)
-                if (a_pid[k] > a_pid[k + 1]) {
-                    const uint32_t tp = a_pid[k], ts = a_slot[k];
-                    a_pid[k] = a_pid[k + 1]; a_slot[k] = a_slot[k + 1];
-                    a_pid[k + 1] = tp; a_slot[k + 1] = ts;
-                }
-    }
-    if (have_old) {  // statistics: cell-changers of this substep (wgs_stats.cell_changers; every particle is on a list otherwise)
-        uint32_t na = n_arr;
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) na += __shfl_xor(na, off);
-        if (lane == 0 && na != 0u) atomicAdd(&d.counters[CTR_MOVERS], na);
-    }
-    const uint32_t total = n_stay + n_arr;
-    uint32_t inc = total;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        const uint32_t t = __shfl_up(inc, off);
-        if (lane >= off) inc += t;
-    }
-    const uint32_t btotal = __shfl(inc, 63);
-    const uint32_t lstart = inc - total;  // start of this cell's run inside the block
+    // (the block's particle total is known before its runs are: launch 1's count, or the count kept up to date by the fused G2P)
+    const uint32_t bcount = __shfl(grp.acc, (int)(id & (uint32_t)(SCAN_ITEMS - 1)));
     uint32_t pc_flag = 0u;  // CELL_LISTED for the perm_cell entries of a block near a collider
     bool listed = false;  // near a collider and holding particles: on the lists of the CPIC bodies of P2G / G2P
-    WGS_PROF(2)
     // ---- node cdf tile + block class (independent of the scan: placed before the wait for it)
     // Colliders that do not move (Dev::cdf_gen != 0): a block keeps its physical id, i.e. its place in space, so the node cdfs
     // and the class computed for it one substep ago still hold — nothing below needs to run again for a block that holds
     // particles (then all its "+" neighbours are active, which is what the class depends on besides position) and was
     // computed under the current generation (bumped by every table rebuild, growth and pose upload).
-    const bool cdf_cached = CDF && d.cdf_gen != 0u && btotal > 0u && cdf_seen == d.cdf_gen;
+    const bool cdf_cached = CDF && d.cdf_gen != 0u && bcount > 0u && cdf_seen == d.cdf_gen;
     if (cdf_cached) {
         const bool any = cdf_class != 0u;
         if (lane == 0 && any) d.cpic_list[(size_t)(id & 7u) * d.cap + atomicAdd(&d.counters[ctr_ncpic(id & 7u, epoch)], 1u)] = id;
@@ -670,13 +609,107 @@ __device__ __forceinline__ void regroup_block(const Dev &d, int side, uint32_t e
         const bool any = __ballot(mine != 0u) != 0ull;
         if (lane == 0) {
             d.block_cpic[id] = any ? 1u : 0u;
-            if (d.cdf_gen != 0u && btotal > 0u) d.block_cdf_gen[id] = d.cdf_gen;
-            if (any && btotal > 0u) d.cpic_list[(size_t)(id & 7u) * d.cap + atomicAdd(&d.counters[ctr_ncpic(id & 7u, epoch)], 1u)] = id;
+            if (d.cdf_gen != 0u && bcount > 0u) d.block_cdf_gen[id] = d.cdf_gen;
+            if (any && bcount > 0u) d.cpic_list[(size_t)(id & 7u) * d.cap + atomicAdd(&d.counters[ctr_ncpic(id & 7u, epoch)], 1u)] = id;
         }
-        listed = any && btotal > 0u;
+        listed = any && bcount > 0u;
         pc_flag = any ? CELL_LISTED : 0u;
     }
     WGS_PROF(3)
+    // ---- pass 1: members of the new run = stayers of the previous run + arrivals. Arrivals from OTHER blocks are on the
+    // cell's list (sort.wgsl:129-137, for them only); a particle that changed cell INSIDE the block is on no list: the lane of
+    // its old cell meets it here, in its own range of the previous run, and hands it to its new cell through LDS (a
+    // counter and ARRC slots per cell; LDS atomics: the order of the slots is arbitrary, they are sorted by id below).
+    // The first ARRC arrivals of a cell are kept in registers with their ids.
+    constexpr int ARRC = 4;
+    uint32_t a_slot[ARRC], a_pid[ARRC];
+#pragma unroll
+    for (int k = 0; k < ARRC; k++) { a_slot[k] = NONE; a_pid[k] = NONE; }
+    uint32_t n_stay = ce_old - cs_old, n_arr = 0, n_in = 0;
+    // -- the wave-parallel form: lane = entry of the previous run (strided). Every particle that names a cell of this block takes a
+    // place in that cell (an LDS counter per cell: the order of arrival is arbitrary, the ids are put in order further down).
+    constexpr int PAR_R = (RUNCAP + 63) / 64;
+    static_assert(PAR_R % 2 == 0 && RUNCAP <= 1023, "two 16-bit (cell | place << 6) per register; 0xffff = none");
+    uint32_t ckp[PAR_R / 2];  // per entry t = lane + 64 r: new cell | place in it << 6 in half r & 1 of word r / 2, 0xffff = not this block's
+    uint32_t a_ck = NONE;     // ... of the lane's entry of the array of arrivals from other blocks
+    uint32_t *s_cnt = s_out + RUNCAP - 64;   // (the output stage is not written before the counters are consumed)
+    if (par) {
+        __hip_atomic_store(&s_cnt[lane], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+#pragma unroll
+        for (int r = 0; r < PAR_R; r++) {
+            const uint32_t t = (uint32_t)lane + 64u * (uint32_t)r;
+            uint32_t ck = 0xffffu;
+            if (t < runlen) {
+                const uint32_t c = __hip_atomic_load(&s_in[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                if ((c >> 6) == id)   // (NONE, a particle left out of the sort, is nobody's)
+                    ck = (c & 63u) | (__hip_atomic_fetch_add(&s_cnt[c & 63u], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT) << 6);
+            }
+            if (r & 1) ckp[r / 2] |= ck << 16;
+            else ckp[r / 2] = ck;
+        }
+        if (a_cell != NONE) a_ck = (a_cell & 63u) | (__hip_atomic_fetch_add(&s_cnt[a_cell & 63u], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT) << 6);
+        n_stay = __hip_atomic_load(&s_cnt[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);   // (all members of the cell's new run)
+        n_arr = 0;
+    } else {
+        static_assert(RUNCAP >= 64 + 2 * 64 * ARRC, "the hand-over arrays alias the output stage");
+        uint32_t *s_acnt = s_out, *s_aslot = s_out + 64, *s_apid = s_out + 64 + 64 * ARRC;   // (aliases: read into registers before pass 2 writes s_out)
+        auto hand_over = [&](uint32_t c, uint32_t slot, uint32_t pid) {   // to cell c of this block
+            const uint32_t k = __hip_atomic_fetch_add(&s_acnt[c & 63u], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+            if (k < (uint32_t)ARRC) {
+                __hip_atomic_store(&s_aslot[(c & 63u) * ARRC + k], slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                __hip_atomic_store(&s_apid[(c & 63u) * ARRC + k], pid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+            }
+        };
+        if (!clean || narr_in != 0u) {
+            __hip_atomic_store(&s_acnt[lane], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+            if (!clean) {
+                n_stay = 0;
+                for (uint32_t i = cs_old; i < ce_old; i++) {
+                    const uint32_t c = new_cell_of(i);
+                    if (c == idx) n_stay++;
+                    else if ((c >> 6) == id) hand_over(c, i, pid_of_old(i));   // (NONE, a particle left out of the sort, is nobody's)
+                }
+            }
+            if (a_cell != NONE) hand_over(a_cell, a_ent, a_epid);   // the arrivals from other blocks, from the block's array
+            n_in = __hip_atomic_load(&s_acnt[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);   // (the wave ran all of the above in every lane)
+#pragma unroll
+            for (int k = 0; k < ARRC; k++)
+                if ((uint32_t)k < n_in) {
+                    a_slot[k] = __hip_atomic_load(&s_aslot[lane * ARRC + k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                    a_pid[k] = __hip_atomic_load(&s_apid[lane * ARRC + k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                }
+            n_arr = n_in;
+        }
+        for (uint32_t a = head; a != 0u;) {
+            const uint32_t nxt = d.mv_next[a - 1u], p = ldpid<D>(in, d.npad, a - 1u);
+#pragma unroll
+            for (int k = 0; k < ARRC; k++)
+                if (n_arr == (uint32_t)k) { a_slot[k] = a - 1u; a_pid[k] = p; }
+            n_arr++;
+            a = nxt;
+        }
+    }   // (!par)
+    if (n_arr > 1u && n_arr <= (uint32_t)ARRC) {  // ascending id (empty entries hold NONE = the largest value)
+#pragma unroll
+        for (int pass = 0; pass < ARRC; pass++)
+#pragma unroll
+            for (int k = pass & 1; k + 1 < ARRC; k += 2)
+                if (a_pid[k] > a_pid[k + 1]) {
+                    const uint32_t tp = a_pid[k], ts = a_slot[k];
+                    a_pid[k] = a_pid[k + 1]; a_slot[k] = a_slot[k + 1];
+                    a_pid[k + 1] = tp; a_slot[k + 1] = ts;
+                }
+    }
+    const uint32_t total = n_stay + n_arr;
+    uint32_t inc = total;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t t = __shfl_up(inc, off);
+        if (lane >= off) inc += t;
+    }
+    const uint32_t btotal = __shfl(inc, 63);
+    const uint32_t lstart = inc - total;  // start of this cell's run inside the block
+    WGS_PROF(2)
     // ---- pass 2: merge in ascending particle id. Stayers are in id order already; the next arrival is selected
     // from the (short) list: smallest id above the last one taken.
     const bool out_lds = btotal <= (uint32_t)RUNCAP;
@@ -685,6 +718,52 @@ __device__ __forceinline__ void regroup_block(const Dev &d, int side, uint32_t e
     uint32_t bstart = 0, aidx = 0;
     auto fetch_bstart = [&]() { block_prefix(d, epoch, id, lane, grp, nphys, bstart, aidx); };
     if (!out_lds) fetch_bstart();
+    // Nothing moved, nothing arrived and the block's run starts where it started one substep ago, when the same was found: the
+    // block's part of perm is the identity and its part of perm_cell what it was — both are left alone (the first such substep
+    // writes them, the following ones only renew the note).
+    const bool fast_clean = old_ok && clean && !any_arr;
+    bool keep_perm = false;
+    if (fast_clean) {
+        if (out_lds) fetch_bstart();
+        keep_perm = bstart == bstart_old && ident == (((epoch - 1u) << 1) | (pc_flag != 0u ? 1u : 0u));
+    }
+    uint32_t *s_lst = s_in, *s_av = s_in + 64;   // (wave-parallel form: the staged cell ids are consumed by now)
+    if (par) {
+        // (places) the cell's start + the place taken in it; an entry of the output stage = cell << 26 | index v into the ids:
+        // v < runlen: entry v of the previous run, else entry v - runlen of the array of arrivals
+        __hip_atomic_store(&s_lst[lane], lstart, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+        if (a_ck != NONE) {
+            __hip_atomic_store(&s_av[lane], a_ent, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+            __hip_atomic_store(&s_pid[runlen + (uint32_t)lane], a_epid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+        }
+#pragma unroll
+        for (int r = 0; r < PAR_R; r++) {
+            const uint32_t ck = (ckp[r / 2] >> (16 * (r & 1))) & 0xffffu;
+            if (ck != 0xffffu) {
+                const uint32_t pos = __hip_atomic_load(&s_lst[ck & 63u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT) + (ck >> 6);
+                __hip_atomic_store(&s_out[pos], ((ck & 63u) << 26) | ((uint32_t)lane + 64u * (uint32_t)r), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+            }
+        }
+        if (a_ck != NONE) {
+            const uint32_t pos = __hip_atomic_load(&s_lst[a_ck & 63u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT) + (a_ck >> 6);
+            __hip_atomic_store(&s_out[pos], ((a_ck & 63u) << 26) | (runlen + (uint32_t)lane), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+        }
+        // (order) lane = cell: its members by ascending (id, v) — an insertion sort over a handful of entries that are nearly in
+        // order already (the stayers took their places in the order of the previous run)
+        for (uint32_t m = 1; m < total; m++) {
+            const uint32_t e = __hip_atomic_load(&s_out[lstart + m], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+            const uint32_t ve = e & 0x03ffffffu, ke = __hip_atomic_load(&s_pid[ve], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+            uint32_t j = m;
+            while (j > 0u) {
+                const uint32_t q = __hip_atomic_load(&s_out[lstart + j - 1u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                const uint32_t vq = q & 0x03ffffffu, kq = __hip_atomic_load(&s_pid[vq], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                if (kq < ke || (kq == ke && vq < ve)) break;
+                __hip_atomic_store(&s_out[lstart + j], q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                j--;
+            }
+            if (j != m) __hip_atomic_store(&s_out[lstart + j], e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+        }
+    }
     uint32_t out = lstart;
     auto emit = [&](uint32_t src) {
         if (out_lds) {
@@ -702,7 +781,7 @@ __device__ __forceinline__ void regroup_block(const Dev &d, int side, uint32_t e
     // A cell with more arrivals than fit the registers (rare in a steady flow) is sorted by the WHOLE wave further down when the
     // block fits the LDS stages and the cell holds at most 64 particles; its lane sits the merge out.
     const bool coop_ok = in_lds && out_lds;   // (wave-uniform)
-    const bool coop_me = !cached && coop_ok && total <= 64u;
+    const bool coop_me = !par && !cached && coop_ok && total <= 64u;
     auto next_arrival = [&]() {
         arr_slot = NONE;
         if (cached) {  // k-th entry of the sorted register copy
@@ -733,7 +812,7 @@ __device__ __forceinline__ void regroup_block(const Dev &d, int side, uint32_t e
                 }
             for (uint32_t t = 0; t < narr_in; t++) {   // (the block's array of arrivals from other blocks)
                 const uint32_t sl = d.blk_arr[(size_t)id * BLK_ARR + t];
-                if (d.cellid[sl] != idx) continue;
+                if (cell_of(d.cellid[sl]) != idx) continue;
                 const unsigned long long key = ((unsigned long long)ldpid<D>(in, d.npad, sl) << 32) | sl;
                 if (have_last && key <= last_key) continue;
                 if (key < best) best = key;
@@ -745,7 +824,7 @@ __device__ __forceinline__ void regroup_block(const Dev &d, int side, uint32_t e
         }
     };
     if (n_arr && !coop_me) next_arrival();
-    for (uint32_t i = cs_old; i < (coop_me ? cs_old : ce_old); i++) {
+    for (uint32_t i = cs_old; i < ((coop_me || par || keep_perm) ? cs_old : ce_old); i++) {
         if (!stays_here(i)) continue;
         if (arr_slot != NONE) {
             const uint32_t ps = pid_of_old(i);
@@ -812,12 +891,14 @@ __device__ __forceinline__ void regroup_block(const Dev &d, int side, uint32_t e
             __hip_atomic_store(&s_out[c_lstart + rank], ((uint32_t)c << 26) | (uint32_t)key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
     }
     WGS_PROF(4)
-    if (out_lds) fetch_bstart();
+    if (out_lds && !fast_clean) fetch_bstart();
     WGS_PROF(5)
-    if (out_lds)
+    if (out_lds && !keep_perm)
         for (uint32_t t = lane; t < btotal; t += 64) {
             const uint32_t v = __hip_atomic_load(&s_out[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-            d.perm[bstart + t] = v & 0x03ffffffu;
+            uint32_t src = v & 0x03ffffffu;
+            if (par) src = src < runlen ? run0 + src : __hip_atomic_load(&s_av[src - runlen], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+            d.perm[bstart + t] = src;
             d.perm_cell[bstart + t] = (id * NPB + (v >> 26)) | pc_flag;
         }
     // ---- new runs, reset of what this substep consumed
@@ -838,6 +919,7 @@ __device__ __forceinline__ void regroup_block(const Dev &d, int side, uint32_t e
         d.block_start[id] = bstart;    // first_particle
         d.block_count[id] = btotal;    // snapshot used by P2G / grid update / G2P
         d.links_epoch[id] = epoch;     // the neighbour links and cell runs written above are those of this substep
+        d.block_ident[id] = (fast_clean && bstart == bstart_old) ? ((epoch << 1) | (pc_flag != 0u ? 1u : 0u)) : 0u;
         // (block_acc is cleared by the grid update: the waves of this group read it)
     }
     if (listed) append_visits(d, id, bstart, btotal, lane, epoch);
@@ -857,6 +939,17 @@ __device__ __forceinline__ void regroup_block(const Dev &d, int side, uint32_t e
     }
     WGS_PROF(6)
     WGS_PROF_END()
+    uint32_t movers = 0u;
+    if (have_old) {   // (every particle is an arrival on a table-rebuild substep)
+        if (par) {
+            movers = (uint32_t)__builtin_amdgcn_readfirstlane((int)n_moved) + narr_in;   // (lane 0 ran every round of the staging loop)
+        } else {
+            movers = n_arr;
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) movers += __shfl_xor(movers, off);
+        }
+    }
+    return movers;
 }
 
 // Launch 2: the first `nscan` workgroups scan, the others regroup (one wave per active block, strided over the
@@ -882,8 +975,16 @@ template <int D, bool CDF, bool SHARD = false> __global__ __launch_bounds__(SORT
     // no block id was handed out since launch 2 of the previous substep? Then a neighbour that was not in the table is
     // still not in it (rim of the active region: the lookups with the longest probe sequences, every substep)
     const bool no_new_blocks = d.counters[CTR_NPHYS] == d.counters[CTR_NPHYS_SEEN + ((epoch - 1u) & 1u)];
+    uint32_t movers = 0u;
     for (uint32_t id = wave; id < nphys; id += nwaves)
-        regroup_block<D, CDF, SHARD>(d, side, epoch, id, nphys, have_old != 0, no_new_blocks, s_in[w], s_out[w], s_pid[w]);
+        movers += regroup_block<D, CDF, SHARD>(d, side, epoch, id, nphys, have_old != 0, no_new_blocks, s_in[w], s_out[w], s_pid[w]);
+    // statistics (wgs_stats.cell_changers): one add per workgroup, the partial counts in cache lines of their own
+    if ((threadIdx.x & 63u) == 0u) s_wave[w] = movers;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned long long m = s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
+        if (m != 0ull) atomicAdd(&d.counters[CTR_MOVERS + 32u * (blockIdx.x & 15u)], (uint32_t)m);
+    }
 }
 
 // Test hook (wgs_debug_scan): the scan workgroups, and workgroups that finish it per block exactly like the

@@ -117,8 +117,9 @@ enum { CTR_NBLOCKS = 0, CTR_ERRORS = 1, CTR_NPHYS = 2,
        CTR_NVISIT = 64,  // [64 + 32 k], k = 0..7: length of the visit list of XCD k (Dev::visit_list), one cache line each
        CTR_NCPIC = 320,  // [320 + 32 k], k = 0..7: length of list k of the near-collider blocks (Dev::cpic_list), one cache line each
        CTR_NHALO = 576,  // sharded runs: length of the list of active blocks in the interface layers (Dev::halo_list)
-       CTR_MOVERS = 608,  // particles pushed on a mover list since creation (modulo 2^32; wgs_get_stats: cell-changers per substep)
-       CTR_COUNT = 640 };
+       CTR_MOVERS = 640,  // [640 + 32 k], k = 0..15: particles that changed their associated cell since creation, 16 partial counts in cache lines of
+                          // their own (modulo 2^32 each; one add per workgroup of launch 2 of the sort; wgs_get_stats sums them)
+       CTR_COUNT = 1152 };
 // The three list counters exist TWICE, 16 words apart (same cache line of their own): launch 2 of the sort of substep `epoch`
 // appends to set epoch & 1 — which P2G, the fused G2P and the pack waves of that substep read — and its scan workgroup
 // zeroes the other set for the next substep. No launch has to run in front of the sort just to reset them (the binning of a
@@ -132,6 +133,10 @@ enum { ERRBIT_OVERFLOW = 1u, ERRBIT_KEYRANGE = 2u, ERRBIT_SHARD = 4u, ERRBIT_MAT
 // sort when it computes the block classes itself; the fused G2P then knows which body a particle belongs to from the sort
 // entry it loads anyway, instead of a dependent block_cpic lookup in the middle of every chunk.
 constexpr uint32_t CELL_LISTED = 0x80000000u;
+// Bit 31 of a Dev::cellid entry: the particle changed cell in the step that wrote the entry (NONE stays NONE). Launch 2 of the sort tells
+// the stayers of a run from the particles that came from another cell of the block by it, and counts the cell-changers.
+constexpr uint32_t CELL_MOVED = 0x80000000u;
+__device__ inline uint32_t cell_of(uint32_t entry) { return entry == NONE ? NONE : (entry & ~CELL_MOVED); }
 constexpr uint32_t HALO_ENT = 12;  // words per Dev::halo_list entry: block id, key, 8 source slabs, 2 spare
 
 // Message buffers of a slab (kernels_shard.h): [0] lower, [1] upper neighbour; null = no neighbour on that side.
@@ -171,6 +176,9 @@ struct Dev {
     uint32_t *block_stamp; // cap: epoch of the last substep in which the block was active
     uint32_t *links_epoch; // cap: epoch at which nbr_plus / nbr_minus of the block were last written
     uint32_t *block_acc;   // cap: particle counter being accumulated by k_bin / k_rebin (zero at rest)
+    uint32_t *block_ident; // cap: (epoch << 1 | near a collider) of the last substep that found the block's part of perm / perm_cell to be the
+                           // identity (nobody moved, nobody arrived, the block's run starts where it started): a substep that finds the
+                           // same again, right after, leaves the two arrays alone
     uint32_t *blk_narr;    // cap: particles that came into the block from OTHER blocks in this substep (zero outside the sort) ...
     uint32_t *blk_arr;     // cap*BLK_ARR: ... and the slots of the first BLK_ARR of them, in arrival order (arbitrary); the others are on
                            // their cell's list (cell_head). One coalesced load for the wave that regroups the block, no pointer chasing
