@@ -1239,11 +1239,18 @@ def test_sharded_substep_with_pack_and_interior_grid_update_inside_the_p2g_launc
     monkeypatch.setenv("WGS_DEBUG", "262144")
     b = run()
     monkeypatch.delenv("WGS_DEBUG")
-    for x, y in zip(a, b):
-        ox, oy = np.argsort(x["ids"]), np.argsort(y["ids"])    # (the storage order of a slab follows the arrival order of its guests)
-        assert np.array_equal(x["ids"][ox], y["ids"][oy])
-        for f in ("pos", "vel", "def_grad", "affine"):
-            assert np.array_equal(x[f][ox], y[f][oy]), f
+    # wgs_sharded_step with neighbours splits P2G: the two block layers at each cut first (their slabs are what the messages
+    # are gathered from: they run beside the exchange on a stream of their own), every other block and the interior's grid
+    # update in a second launch. WGS_DEBUG = 4194304 splits the lockstep slabs the same way (on their one stream): same bits.
+    monkeypatch.setenv("WGS_DEBUG", "4194304")
+    c = run()
+    monkeypatch.delenv("WGS_DEBUG")
+    for other in (b, c):
+        for x, y in zip(a, other):
+            ox, oy = np.argsort(x["ids"]), np.argsort(y["ids"])    # (the storage order of a slab follows the arrival order of its guests)
+            assert np.array_equal(x["ids"][ox], y["ids"][oy])
+            for f in ("pos", "vel", "def_grad", "affine"):
+                assert np.array_equal(x[f][ox], y[f][oy]), f
 
 
 @pytest.mark.parametrize("world,dim", [(2, 3), (3, 3), (4, 3), (2, 2)])

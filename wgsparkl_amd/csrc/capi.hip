@@ -91,6 +91,8 @@ struct wgs_data {
     wgs_pipeline *pipeline = nullptr;
     hipStream_t stream = nullptr;
     bool owns_stream = true;
+    hipStream_t stream2 = nullptr;   // wgs_sharded_step: the boundary layers' P2G and the exchange run here, beside the interior's P2G (capi_sharded.inc)
+    hipEvent_t ev_sorted = nullptr, ev_exchanged = nullptr;
     Dev dev{};
     int side = 0;
     bool plastic = false;
@@ -326,7 +328,7 @@ void fill_collider(ColliderDev &c, const wgs_collider &in) {
     for (int k = 0; k < 3; k++) c.com[k] = in.com[k];
 }
 
-constexpr uint32_t WGS_LAUNCH_SHAPE_SWITCHES = 128u | 1024u | 4096u | 8192u | 16384u | 32768u | 65536u | 131072u | 262144u | 524288u | 1048576u;  // WGS_DEBUG bits the shipped library honours
+constexpr uint32_t WGS_LAUNCH_SHAPE_SWITCHES = 128u | 1024u | 4096u | 8192u | 16384u | 32768u | 65536u | 131072u | 262144u | 524288u | 1048576u | 4194304u | 8388608u;  // WGS_DEBUG bits the shipped library honours
 constexpr uint32_t P2G_SMALL_BUDGET_MIN_PARTICLES = 600000;  // one-way CPIC P2G body at 168 VGPRs from this size on
 #ifndef WGS_REGROUP_ROUNDS
 #define WGS_REGROUP_ROUNDS 4u
@@ -662,9 +664,12 @@ void resolve_timings(wgs_data *d) {
 // One substep = pipeline.rs:201-280 (MPM passes), enqueued on the data's stream.
 // part 0 = the whole substep (single GPU, or a slab stepped without its neighbours); the sharded step splits it around
 // its one neighbour exchange: part 1 = sort .. P2G, part 2 = grid update + fused G2P (+ the arrivals' G2P) + bodies.
-template <bool TS> wgs_status enqueue_substep(wgs_data *d, int ts_slot, int part) {
+// `p2g_sel` splits part 1 further (wgs_sharded_step with neighbours): 0 = all of it; 1 = the sort only; 2 = P2G of the boundary
+// layers with the pack waves behind it, on the data's SECOND stream; 3 = P2G of all other blocks with the interior's grid update.
+template <bool TS> wgs_status enqueue_substep(wgs_data *d, int ts_slot, int part, int p2g_sel = 0) {
     Dev &dev = d->dev;
-    hipStream_t s = d->stream;
+    hipStream_t s = (p2g_sel == 2 && d->stream2) ? d->stream2 : d->stream;
+    const bool first = part != 2 && p2g_sel <= 1;   // the first call of this substep
     const int side = d->side;
     const uint32_t n = dev.n;
     const int pgrid = (int)((n + SORT_THREADS - 1) / SORT_THREADS);
@@ -678,7 +683,7 @@ template <bool TS> wgs_status enqueue_substep(wgs_data *d, int ts_slot, int part
     };
     const uint32_t epoch = (uint32_t)(d->substeps + 1);
     d->gu_fused = false;
-    if (part != 2) d->shard_fused = false;   // (part 2 of a sharded substep consumes what its part 1 decided)
+    if (first) d->shard_fused = false;   // (part 2 of a sharded substep consumes what its part 1 decided)
     dev.ctr_set = (uint32_t)(d->substeps & 1u);  // sharded runs: the set of particle counters this substep reads (layout.h)
     // chunks of 64 sorted particles per wave of the fused G2P (kernels_transfer.h); the sort files the visit list by it
     // (2D: the body keeps no state of the chunk after the next one — at most two chunks per wave)
@@ -689,36 +694,36 @@ template <bool TS> wgs_status enqueue_substep(wgs_data *d, int ts_slot, int part
     // (perm_cell) and neighbour links are still valid, so the particles are re-binned RELATIVE to their old
     // block (k_rebin: no hash lookups except for the few particles that changed block). The full k_bin runs
     // on the first substep, on table-rebuild substeps and in sharded runs (particles arrive from neighbours).
-    const bool rehash = d->substeps % d->rehash_period == 0 || (d->force_rehash && part != 2);
-    if (rehash && part != 2) {
+    const bool rehash = d->substeps % d->rehash_period == 0 || (d->force_rehash && first);
+    if (rehash && first) {
         d->force_rehash = false;
         d->cdf_generation++;   // block ids are handed out anew
     }
     // node cdfs / block classes are reused from one substep to the next while no collider can move
     dev.cdf_gen = (d->cpic && !d->bodies_move) ? d->cdf_generation : 0u;
     const bool fused_cdf = d->cpic && dev.n_rigid == 0 && !(dev.dbg & 1024u);  // (mesh cdfs are only complete after k_p2g_cdf)
-    if (part != 2) dev.listed_in_perm = fused_cdf ? 1u : 0u;  // (part 2 of a sharded substep consumes what its part 1 wrote)
+    if (first) dev.listed_in_perm = fused_cdf ? 1u : 0u;  // (part 2 of a sharded substep consumes what its part 1 wrote)
     const bool use_rebin = d->prev_sorted && !rehash && !(dev.dbg & 128u);
     // Single-domain data: the fused G2P of this substep also bins its output for the next one (g2p_body.inc, Dev::bin_next), unless
     // that substep rebuilds the table anyway (dbg bit 20 brings launch 1 of the sort, k_rebin, back: same results, tested).
     // `prebinned`: the previous substep's G2P did so for this one.
     const bool binned = use_rebin && d->prebinned && part == 0;
-    if (part != 2 && d->prebinned && !binned) {
+    if (first && d->prebinned && !binned) {
         // (a table rebuild nobody could foresee — ids three quarters handed out, seen by the host in between: what the G2P
         // accumulated for the old ids is dropped; the stamps it left mean nothing once the ids are handed out anew)
         HIP_TRY(hipMemsetAsync(dev.block_acc, 0, sizeof(uint32_t) * (size_t)dev.cap, s));
         HIP_TRY(hipMemsetAsync(dev.cell_head, 0, sizeof(uint32_t) * (size_t)dev.cap * NPB, s));
         HIP_TRY(hipMemsetAsync(dev.blk_narr, 0, sizeof(uint32_t) * (size_t)dev.cap, s));
     }
-    if (part != 2) d->prebinned = false;
+    if (first) d->prebinned = false;
     dev.bin_next = (part == 0 && !dev.sharded && !(dev.dbg & (128u | 1048576u)) && (d->substeps + 1) % d->rehash_period != 0) ? 1u : 0u;
     // the fused G2P drops the guests only inside the sharded step (kernels_shard.h); wgs_step on a slab advances what it holds
     dev.skip_guests = (d->in_sharded_step && dev.sharded) ? 1u : 0u;
-    if (dev.sharded && d->needs_compact && part != 2) {
+    if (dev.sharded && d->needs_compact && first) {
         hipLaunchKernelGGL(k_shard_compacted, dim3(1), dim3(64), 0, s, dev);
         d->needs_compact = false;
     }
-    if (part != 2) {
+    if (first) {
         if (TS) {  // two adjacent marks: their distance is what every interval below pays for its closing mark
             mark(9);
             mark(10);
@@ -772,6 +777,9 @@ template <bool TS> wgs_status enqueue_substep(wgs_data *d, int ts_slot, int part
             hipLaunchKernelGGL(k_cdf<D>, dim3(grid_for(d, 16)), dim3(CDF_THREADS), 0, s, dev, side, epoch);
         mark(2);
         mark(3);
+    }
+    if (part != 2 && p2g_sel != 1) {
+        const uint32_t layer_sel = p2g_sel == 2 ? 1u : p2g_sel == 3 ? 2u : 0u;   // (kernels_transfer.h: boundary layers / the others)
         if (n > 0) {
             // ---- "p2g"
             // Workgroups per body: about one per two entries of the block list (as the host last saw it), between 8 and
@@ -797,11 +805,11 @@ template <bool TS> wgs_status enqueue_substep(wgs_data *d, int ts_slot, int part
             const int gum = fuse_gu ? 2 : fuse_shard ? 3 : 0;   // what rides in the LAST P2G launch of this substep
             const uint32_t NW = (uint32_t)P2GCfg<D>::NW;
             // (8, 16, 32 or 64 workgroups per CU at most: the same times at C2 / C3 / C5)
-            const uint32_t gu_wgs = gum == 0 ? 0u : std::min((uint32_t)grid_for(d, 8), std::max((uint32_t)grid_for(d, 1), ((d->seen_nblocks + NW - 1u) / NW + 7u) & ~7u));
+            const uint32_t gu_wgs = (gum == 0 || p2g_sel == 2) ? 0u : std::min((uint32_t)grid_for(d, 8), std::max((uint32_t)grid_for(d, 1), ((d->seen_nblocks + NW - 1u) / NW + 7u) & ~7u));
             // pack waves: one per interface block as the host last saw the grid (a face holds a fraction of the active
             // blocks), plus a few for the guests
             uint32_t npack = 0u, npack_blk = 0u;
-            if (fuse_shard && (d->link->has_lower || d->link->has_upper)) {
+            if (fuse_shard && (d->link->has_lower || d->link->has_upper) && p2g_sel != 3) {   // (they ride behind the boundary layers' P2G)
                 npack_blk = std::max(64u, std::min(2048u, d->seen_nblocks ? d->seen_nblocks : 2048u));
                 const uint32_t nmig = std::max(1u, std::min(64u, (2u * d->link->mig_cap + 63u) / 64u));
                 npack = (npack_blk + nmig + NW - 1u) / NW;
@@ -816,16 +824,16 @@ template <bool TS> wgs_status enqueue_substep(wgs_data *d, int ts_slot, int part
 #define WGS_P2G_PAIR(TW, WPE)                                                                                                          \
     do {                                                                                                                               \
         const dim3 pg(2u * p2g_wgs + ride);                                                                                            \
-        if (gum == 2) hipLaunchKernelGGL((k_p2g_pair<D, TW, WPE, 2>), pg, p2g_block, 0, s, dev, side, epoch, p2g_wgs, npack, npack_blk);      \
-        else if (gum == 3) hipLaunchKernelGGL((k_p2g_pair<D, TW, WPE, 3>), pg, p2g_block, 0, s, dev, side, epoch, p2g_wgs, npack, npack_blk); \
-        else hipLaunchKernelGGL((k_p2g_pair<D, TW, WPE, 0>), pg, p2g_block, 0, s, dev, side, epoch, p2g_wgs, npack, npack_blk);               \
+        if (gum == 2) hipLaunchKernelGGL((k_p2g_pair<D, TW, WPE, 2>), pg, p2g_block, 0, s, dev, side, epoch, p2g_wgs, npack, npack_blk, layer_sel);      \
+        else if (gum == 3) hipLaunchKernelGGL((k_p2g_pair<D, TW, WPE, 3>), pg, p2g_block, 0, s, dev, side, epoch, p2g_wgs, npack, npack_blk, layer_sel); \
+        else hipLaunchKernelGGL((k_p2g_pair<D, TW, WPE, 0>), pg, p2g_block, 0, s, dev, side, epoch, p2g_wgs, npack, npack_blk, layer_sel);               \
     } while (0)
 #define WGS_P2G_LAST(CP, TW, PC, FILTER)                                                                                                        \
     do {                                                                                                                                        \
         const dim3 lg(p2g_wgs + ride);                                                                                                          \
-        if (gum == 2) hipLaunchKernelGGL((k_p2g<D, CP, TW, PC, 2>), lg, p2g_block, 0, s, dev, side, FILTER, epoch, p2g_wgs, npack, npack_blk);        \
-        else if (gum == 3) hipLaunchKernelGGL((k_p2g<D, CP, TW, PC, 3>), lg, p2g_block, 0, s, dev, side, FILTER, epoch, p2g_wgs, npack, npack_blk);   \
-        else hipLaunchKernelGGL((k_p2g<D, CP, TW, PC, 0>), lg, p2g_block, 0, s, dev, side, FILTER, epoch, p2g_wgs, npack, npack_blk);                 \
+        if (gum == 2) hipLaunchKernelGGL((k_p2g<D, CP, TW, PC, 2>), lg, p2g_block, 0, s, dev, side, FILTER, epoch, p2g_wgs, npack, npack_blk, layer_sel);        \
+        else if (gum == 3) hipLaunchKernelGGL((k_p2g<D, CP, TW, PC, 3>), lg, p2g_block, 0, s, dev, side, FILTER, epoch, p2g_wgs, npack, npack_blk, layer_sel);   \
+        else hipLaunchKernelGGL((k_p2g<D, CP, TW, PC, 0>), lg, p2g_block, 0, s, dev, side, FILTER, epoch, p2g_wgs, npack, npack_blk, layer_sel);                 \
     } while (0)
             if (d->cpic && !big_two_way && (big_one_way || (d->last_ncpic != UINT32_MAX && d->last_ncpic >= P2G_PAIR_MIN_BLOCKS)) && !(dev.dbg & 8192u)) {
                 // many blocks near colliders (as of the last wgs_sync): both bodies in one launch (k_p2g_pair)
@@ -834,8 +842,8 @@ template <bool TS> wgs_status enqueue_substep(wgs_data *d, int ts_slot, int part
                 else WGS_P2G_PAIR(false, 1);
             } else if (d->cpic) {
                 // (the first of the two launches hands its slabs over like the last one when anything rides in that one)
-                if (gum != 0) hipLaunchKernelGGL((k_p2g<D, false, false, false, 1>), p2g_grid, p2g_block, 0, s, dev, side, 1, epoch, p2g_wgs, 0u, 0u);
-                else hipLaunchKernelGGL((k_p2g<D, false>), p2g_grid, p2g_block, 0, s, dev, side, 1, epoch, p2g_wgs, 0u, 0u);
+                if (gum != 0) hipLaunchKernelGGL((k_p2g<D, false, false, false, 1>), p2g_grid, p2g_block, 0, s, dev, side, 1, epoch, p2g_wgs, 0u, 0u, layer_sel);
+                else hipLaunchKernelGGL((k_p2g<D, false>), p2g_grid, p2g_block, 0, s, dev, side, 1, epoch, p2g_wgs, 0u, 0u, layer_sel);
                 // near-collider list: particle cdf in the prologue (the node cdfs are complete: k_setup_scatter<CDF>, or
                 // k_cdf after k_p2g_cdf with mesh colliders), then the CPIC transfer
                 if (d->two_way) WGS_P2G_LAST(true, true, true, 2);
@@ -1269,6 +1277,12 @@ wgs_status wgs_shard_export(wgs_data *d, void *device_buf, uint32_t capacity_rec
 void wgs_data_destroy(wgs_data *d) {
     if (!d) return;
     if (d->stream) hipStreamSynchronize(d->stream);
+    if (d->stream2) {
+        hipStreamSynchronize(d->stream2);
+        hipStreamDestroy(d->stream2);
+        hipEventDestroy(d->ev_sorted);
+        hipEventDestroy(d->ev_exchanged);
+    }
     if (d->events.created)
         for (int s = 0; s < Events::MAX_SUBSTEPS; s++)
             for (int m = 0; m < Events::MARKS; m++) hipEventDestroy(d->events.ev[s][m]);

@@ -77,6 +77,11 @@ template <int D> __device__ inline IfaceMasks iface_masks(const Dev &d, int bx) 
     }
     return m;
 }
+// The block layers whose P2G slabs feed an outgoing message: what travels to the upper neighbour is gathered from the slabs of
+// layers hi - 1 (its rim) and hi (the guests), what travels to the lower one from lo - 1 (guests) and lo.
+__device__ inline bool shard_boundary_layer(const Dev &d, int bx) {
+    return (d.shard_has_lo && (bx == d.shard_lo - 1 || bx == d.shard_lo)) || (d.shard_has_hi && (bx == d.shard_hi - 1 || bx == d.shard_hi));
+}
 // the inbound message that can hold pairs of layer bx (layers lo, lo + 1 come from below, hi - 1, hi from above: a slab
 // with two neighbours is at least 3 blocks wide)
 __device__ inline int iface_recv_face(const Dev &d, int bx) { return (d.shard_has_hi && bx >= d.shard_hi - 1) ? 1 : 0; }

@@ -191,12 +191,15 @@ template <int D, bool TWOWAY = false, bool INTERIOR = false> __device__ __forcei
 // block's word in slab_epoch); 2 = also, the workgroups from index `nblk` on are not P2G workgroups but run the grid
 // update (gu_waves below) — they are dispatched after every P2G workgroup and gather a node as soon as the slabs that
 // cover it are complete: no grid-update launch.
+// `layer_sel` (one slab of a decomposition; 0 = every block): 1 = only the blocks of the BOUNDARY layers — the two block layers at each
+// cut whose slabs hold what travels to a neighbour (kernels_shard.h shard_boundary_layer) —, 2 = all the others. wgs_sharded_step
+// launches the boundary first, on a stream of its own together with the exchange, and the interior meanwhile (capi_sharded.inc).
 // GU = 3 (one slab of a decomposition, inside wgs_sharded_step): behind the P2G workgroups first `npack` workgroups whose
 // waves pack the outgoing messages (kernels_shard.h pack_face_body; `npack_blk` of their waves walk the interface-block
 // list, the others copy the guests), then the grid update of the INTERIOR blocks; the interface layers are updated after
 // the exchange (k_grid_update<D, 3> with iface_only).
 template <int D, bool CPIC, bool TWOWAY = false, bool PCDF = false, int GU = 0>
-__global__ __launch_bounds__(P2GCfg<D>::NW * 64) void k_p2g(Dev d, int side, int filter, uint32_t epoch, uint32_t nblk, uint32_t npack, uint32_t npack_blk) {
+__global__ __launch_bounds__(P2GCfg<D>::NW * 64) void k_p2g(Dev d, int side, int filter, uint32_t epoch, uint32_t nblk, uint32_t npack, uint32_t npack_blk, uint32_t layer_sel) {
     using Cfg = P2GCfg<D>;
     if constexpr (GU == 2) {
         if (blockIdx.x >= nblk) {
@@ -264,7 +267,7 @@ __global__ __launch_bounds__(P2GCfg<D>::NW * 64) void k_p2g(Dev d, int side, int
 // offered the small budget.
 // (GU: as for k_p2g; the grid is `half` CPIC + `half` plain workgroups, then the grid-update workgroups)
 template <int D, bool TWOWAY, int WPE = 1, int GU = 0>
-__global__ __launch_bounds__(P2GCfg<D>::NW * 64, WPE) void k_p2g_pair(Dev d, int side, uint32_t epoch, uint32_t half, uint32_t npack, uint32_t npack_blk) {
+__global__ __launch_bounds__(P2GCfg<D>::NW * 64, WPE) void k_p2g_pair(Dev d, int side, uint32_t epoch, uint32_t half, uint32_t npack, uint32_t npack_blk, uint32_t layer_sel) {
     using Cfg = P2GCfg<D>;
     if constexpr (GU == 2) {
         if (blockIdx.x >= 2u * half) {
