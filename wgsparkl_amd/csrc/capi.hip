@@ -125,6 +125,7 @@ struct wgs_data {
     std::vector<ColliderDev> host_colliders;  // what the host last wrote (poses / velocities move on the device)
     std::vector<BodyDev> host_bodies;
     bool bodies_move = false;   // some body has a velocity or a mass: integrate_bodies runs every substep
+    uint32_t moving_mask = 0;   // ... which ones (bit per collider; sticky like bodies_move): the blocks out of their reach keep their node cdfs
     bool two_way = false;       // P2G accumulates the bodies' impulses: whenever a body can move (a kinematic body uses
                                 // them too: the velocity caps of rigid_impulses.wgsl:112-125 apply once it is pushed)
     SimParamsDev host_sp{};
@@ -700,7 +701,8 @@ template <bool TS> wgs_status enqueue_substep(wgs_data *d, int ts_slot, int part
         d->cdf_generation++;   // block ids are handed out anew
     }
     // node cdfs / block classes are reused from one substep to the next while no collider can move
-    dev.cdf_gen = (d->cpic && !d->bodies_move) ? d->cdf_generation : 0u;
+    dev.cdf_gen = d->cpic ? d->cdf_generation : 0u;
+    dev.cdf_moving = d->moving_mask;
     const bool fused_cdf = d->cpic && dev.n_rigid == 0 && !(dev.dbg & 1024u);  // (mesh cdfs are only complete after k_p2g_cdf)
     if (first) dev.listed_in_perm = fused_cdf ? 1u : 0u;  // (part 2 of a sharded substep consumes what its part 1 wrote)
     const bool use_rebin = d->prev_sorted && !rehash && !(dev.dbg & 128u);
@@ -1208,7 +1210,10 @@ static wgs_status create_impl(wgs_pipeline *pipeline, const wgs_sim_params *para
     d->bodies_move = false;
     for (size_t i = 0; i < num_colliders; i++)
         for (int k = 0; k < 3; k++)
-            d->bodies_move = d->bodies_move || colliders[i].velocity.linear[k] != 0.f || colliders[i].velocity.angular[k] != 0.f;
+            if (colliders[i].velocity.linear[k] != 0.f || colliders[i].velocity.angular[k] != 0.f) {
+                d->bodies_move = true;
+                d->moving_mask |= 1u << i;
+            }
     if (num_colliders)  // local centres of mass from the world ones (update_world_mass_properties' inverse)
         hipLaunchKernelGGL(k_bodies_refresh<D>, dim3(1), dim3(16), 0, d->stream, dev, 0xffffu);
     if (d->bodies_move && enable_impulses(d) != WGS_OK) return bail(fail(WGS_ERR_HIP, "out of device memory for the impulse accumulators"));
@@ -1425,7 +1430,11 @@ wgs_status wgs_set_body_velocities(wgs_data *d, const wgs_velocity *vels, size_t
         ColliderDev &c = d->host_colliders[i];
         for (int k = 0; k < 3; k++) c.linvel[k] = vels[i].linear[k];
         for (int k = 0; k < 3; k++) c.angvel[k] = vels[i].angular[k];
-        for (int k = 0; k < 3; k++) d->bodies_move = d->bodies_move || c.linvel[k] != 0.f || c.angvel[k] != 0.f;
+        for (int k = 0; k < 3; k++)
+            if (c.linvel[k] != 0.f || c.angvel[k] != 0.f) {
+                d->bodies_move = true;
+                d->moving_mask |= 1u << i;
+            }
     }
     static_assert(offsetof(ColliderDev, angvel) - offsetof(ColliderDev, linvel) == 12, "linvel|angvel contiguous");
     if (d->bodies_move) {
@@ -1447,8 +1456,11 @@ wgs_status wgs_set_body_mass_properties(wgs_data *d, const wgs_mass_properties *
     }
     for (size_t i = 0; i < d->dev.n_colliders; i++) {
         const BodyDev &b = d->host_bodies[i];
-        for (int k = 0; k < 3; k++) dynamic = dynamic || b.inv_mass[k] != 0.f;
-        for (int k = 0; k < 9; k++) dynamic = dynamic || b.inv_inertia_local[k] != 0.f;
+        bool dyn = false;
+        for (int k = 0; k < 3; k++) dyn = dyn || b.inv_mass[k] != 0.f;
+        for (int k = 0; k < 9; k++) dyn = dyn || b.inv_inertia_local[k] != 0.f;
+        if (dyn) d->moving_mask |= 1u << i;
+        dynamic = dynamic || dyn;
     }
     d->bodies_move = d->bodies_move || dynamic;
     if (d->bodies_move) {

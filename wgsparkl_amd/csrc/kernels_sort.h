@@ -553,11 +553,42 @@ __device__ __forceinline__ uint32_t regroup_block(const Dev &d, int side, uint32
     uint32_t pc_flag = 0u;  // CELL_LISTED for the perm_cell entries of a block near a collider
     bool listed = false;  // near a collider and holding particles: on the lists of the CPIC bodies of P2G / G2P
     // ---- node cdf tile + block class (independent of the scan: placed before the wait for it)
-    // Colliders that do not move (Dev::cdf_gen != 0): a block keeps its physical id, i.e. its place in space, so the node cdfs
-    // and the class computed for it one substep ago still hold — nothing below needs to run again for a block that holds
-    // particles (then all its "+" neighbours are active, which is what the class depends on besides position) and was
-    // computed under the current generation (bumped by every table rebuild, growth and pose upload).
-    const bool cdf_cached = CDF && d.cdf_gen != 0u && bcount > 0u && cdf_seen == d.cdf_gen;
+    // A block keeps its physical id, i.e. its place in space, so the node cdfs and the class computed for it one substep ago
+    // still hold — nothing below needs to run again — for a block that holds particles (then all its "+" neighbours are active,
+    // which is what the class depends on besides position), was computed under the current generation (bumped by every table
+    // rebuild, growth and pose upload) with no MOVING collider in reach of its tile, and has none in reach now (the quick
+    // reject below, against the colliders of Dev::cdf_moving only: the reference's sand3 has one among six).
+    // Quick reject, wave-uniform: a collider whose boundary is farther from the tile's centre than the tile's half diagonal
+    // plus the affinity reach (1.5 h per axis) touches none of its nodes, and a centre outside the shape then means every node
+    // is outside. One projection per collider instead of (BW+2)^D.
+    auto reach_mask = [&](uint32_t which) {   // bit i: collider i (of `which`) can reach a node of this tile
+        constexpr int BW = Dim<D>::BW, TW = Dim<D>::TW;
+        uint32_t near = 0u;
+        float ctr[D];
+#pragma unroll
+        for (int k = 0; k < D; k++) ctr[k] = ((float)(b[k] * BW) + 0.5f * (float)(TW - 1)) * d.h;
+        const float reach = (0.5f * (float)(TW - 1) + 1.5f) * d.h * (D == 3 ? 1.7320508f : 1.4142136f) * 1.001f;
+        for (uint32_t i = 0; i < d.n_colliders && i < 16u; i++) {
+            if (!((which >> i) & 1u)) continue;
+            const ColliderDev &c = d.colliders[i];
+            if (c.shape_type >= 3u) continue;
+            float pl[D], projl[D], proj[D];
+            pose_to_local<D>(c, ctr, pl);
+            const bool inside = project_local_on_boundary<D>(c, pl, projl);
+            pose_to_world<D>(c, projl, proj);
+            float n2 = 0.f;
+#pragma unroll
+            for (int k = 0; k < D; k++) n2 += (proj[k] - ctr[k]) * (proj[k] - ctr[k]);
+            near |= (inside || !(n2 > reach * reach)) ? (1u << i) : 0u;
+        }
+        return near;
+    };
+    uint32_t near_moving = 0u;
+    bool cdf_cached = CDF && d.cdf_gen != 0u && bcount > 0u && cdf_seen == d.cdf_gen;
+    if (cdf_cached && d.cdf_moving != 0u) {
+        near_moving = reach_mask(d.cdf_moving);
+        cdf_cached = near_moving == 0u;
+    }
     if (cdf_cached) {
         const bool any = cdf_class != 0u;
         if (lane == 0 && any) d.cpic_list[(size_t)(id & 7u) * d.cap + atomicAdd(&d.counters[ctr_ncpic(id & 7u, epoch)], 1u)] = id;
@@ -566,28 +597,7 @@ __device__ __forceinline__ uint32_t regroup_block(const Dev &d, int side, uint32
     } else if (CDF WGS_ABLATE_AND(!(d.dbg & (1u << 21)))) {
         constexpr int BW = Dim<D>::BW, BS = Dim<D>::BSHIFT, TW = Dim<D>::TW, TILE = Dim<D>::TILE;
         uint32_t mine = 0u;
-        // Quick reject, wave-uniform: a collider whose boundary is farther from the tile's centre than the tile's
-        // half diagonal plus the affinity reach (1.5 h per axis) touches none of its nodes, and a centre outside
-        // the shape then means every node is outside. One projection per collider instead of (BW+2)^D.
-        uint32_t near = 0u;  // bit i: collider i can reach a node of this tile
-        {
-            float ctr[D];
-#pragma unroll
-            for (int k = 0; k < D; k++) ctr[k] = ((float)(b[k] * BW) + 0.5f * (float)(TW - 1)) * d.h;
-            const float reach = (0.5f * (float)(TW - 1) + 1.5f) * d.h * (D == 3 ? 1.7320508f : 1.4142136f) * 1.001f;
-            for (uint32_t i = 0; i < d.n_colliders && i < 16u; i++) {
-                const ColliderDev &c = d.colliders[i];
-                if (c.shape_type >= 3u) continue;
-                float pl[D], projl[D], proj[D];
-                pose_to_local<D>(c, ctr, pl);
-                const bool inside = project_local_on_boundary<D>(c, pl, projl);
-                pose_to_world<D>(c, projl, proj);
-                float n2 = 0.f;
-#pragma unroll
-                for (int k = 0; k < D; k++) n2 += (proj[k] - ctr[k]) * (proj[k] - ctr[k]);
-                near |= (inside || !(n2 > reach * reach)) ? (1u << i) : 0u;
-            }
-        }
+        const uint32_t near = reach_mask(0xffffu);  // bit i: collider i can reach a node of this tile
         if (near == 0u) {
             // no collider in reach of the tile (nearly every block): its own 64 nodes get the "far" cdf — lane = node —
             // and the rim, which belongs to the neighbours, is theirs to write
@@ -609,7 +619,8 @@ __device__ __forceinline__ uint32_t regroup_block(const Dev &d, int side, uint32
         const bool any = __ballot(mine != 0u) != 0ull;
         if (lane == 0) {
             d.block_cpic[id] = any ? 1u : 0u;
-            if (d.cdf_gen != 0u && bcount > 0u) d.block_cdf_gen[id] = d.cdf_gen;
+            // (kept for the coming substeps only when no collider that moves is in reach)
+            if (d.cdf_gen != 0u && bcount > 0u) d.block_cdf_gen[id] = (near & d.cdf_moving) == 0u ? d.cdf_gen : 0u;
             if (any && bcount > 0u) d.cpic_list[(size_t)(id & 7u) * d.cap + atomicAdd(&d.counters[ctr_ncpic(id & 7u, epoch)], 1u)] = id;
         }
         listed = any && bcount > 0u;

@@ -215,8 +215,9 @@ struct Dev {
                               // XCD k (g2p_body.inc); device_math.h append_visits deals the chunks to the lists
     uint32_t *halo_list;      // sharded runs, cap x HALO_ENT words: the active blocks of the layers that travel (what k_pack_face gathers and packs)
     uint32_t visit_cap;       // per list (an eighth of the chunks + 2 per block would do; a block is visited once per chunk it spans)
-    uint32_t cdf_gen;         // != 0: no collider moves — node cdfs and block classes computed under this generation stay valid
-                              // (a block keeps its id and therefore its place); 0: recompute every substep
+    uint32_t cdf_gen;         // node cdfs and block classes computed under this generation stay valid for a block (it keeps its id and
+                              // therefore its place) as long as no collider that can MOVE reaches its tile; 0: no colliders
+    uint32_t cdf_moving;      // bit i: collider i has (or had) a velocity or a mass: its pose changes from substep to substep
     uint32_t listed_in_perm;  // this substep's perm_cell entries carry CELL_LISTED (launch 2 of the sort computed the block classes)
     uint32_t g2p_npass;       // chunks per wave of the fused G2P of this substep (defines the eighths; set by the host per substep)
     uint32_t bin_next;        // single-domain data: the fused G2P of this substep also BINS its output for the next substep (new cell ids,
