@@ -1,69 +1,21 @@
-"""-m gpu parity tests: HIP path (through the C ABI) vs the CPU oracle on the same
-seeded inputs. Integer / index results are compared bit-exactly; floating-point
-fields against the fp64 oracle with the tolerance written next to each check
-(north_star: grid-velocity RMS error < 1e-5, cell indices bit-exact)."""
+"""-m gpu: the HIP path through the C ABI against the oracle (fp64 truth, fp32 twin) — single substeps, the BASELINE.json configurations at test
+size, the reference's own scenes, random scenes and API sequences, the committed golden vectors, the C ABI's error behaviour. Integer results
+(cells, blocks, membership, node bits) exact; floating point within the tolerances of tests/gpu_common.py."""
 import numpy as np
 import pytest
 
 from wgsparkl_amd import scenes
-from wgsparkl_amd.models import (MODEL_COROTATED, MODEL_NEO_HOOKEAN, DruckerPrager, ElasticCoefficients,
-                                 ParticlePhase)
+from wgsparkl_amd.models import (MODEL_COROTATED, MODEL_NEO_HOOKEAN, DruckerPrager, ElasticCoefficients, ParticlePhase)
 from wgsparkl_amd.solver import Collider, ParticleSet, SimulationParams
 
 from helpers import assert_close_to_truth, compare_cpic, compare_grids, grid_of, max_abs, rel_rms, report_margin, run_gpu, run_oracle
+from gpu_common import (CPIC_GRID_V_TOL, CPIC_PART_TOL, FUZZ_BODY_ATOL, FUZZ_NODE_MISMATCH, FUZZ_PART_MISMATCH, FUZZ_VEL_TOL, GRID_V_TOL, PART_TOL,
+                        _exploding_cube, _native_slabs, _random_scene, check_blocks, check_fields, check_grid, cloud_scene)
+import os as _os
+
+from golden_cases import CASES as _CASES
 
 pytestmark = pytest.mark.gpu
-
-GRID_V_TOL = 1e-5      # relative RMS of grid velocity vs the fp64 oracle (north_star target)
-PART_TOL = 2e-5        # relative RMS of particle x, v, F, C' vs the fp64 oracle
-# Collider (CPIC) scenes: discrete decisions (affinity / sign bits, det M > 1e-8, closest collider) sit on fp32
-# thresholds, so a handful of particles may land on the other side; the comparison runs over the particles whose
-# affinity bits agree, and the measured margins are reported (helpers.report_margin -> profiles/rNN_parity_margins.json)
-CPIC_GRID_V_TOL = 5e-5
-CPIC_PART_TOL = 5e-5
-# fuzz scenes (random colliders of every kind, some dynamic, 12 substeps, against the fp32 oracle)
-FUZZ_NODE_MISMATCH = 0.001     # measured: 0 in all 32 fuzz cases (profiles/r02_parity_margins.json)
-FUZZ_PART_MISMATCH = 0.002     # measured: 0
-FUZZ_VEL_TOL = 1e-4            # measured worst: 2.5e-5 (12 substeps of fp32 round-off growth through contact)
-FUZZ_BODY_ATOL = 1e-4          # measured worst: 9.3e-6 (fixed-point impulses: 1e-5 resolution)
-
-
-def cloud_scene(n=20000, dim=3, model=MODEL_COROTATED, seed=7, **kw):
-    ps = scenes.random_cloud(n, dim=dim, seed=seed, phase=ParticlePhase(1.0, -1.0), **kw)
-    g = (0.0, -9.81, 0.0)[:dim]
-    return dict(particles=ps, params=SimulationParams(gravity=g, dt=1.0e-3), colliders=[], cell_width=1.0,
-                grid_capacity=4096, model=model)
-
-
-def check_blocks(data, st):
-    vid, first, num, ids = data.read_blocks()
-    ovid, ofirst, onum = st.blocks()
-    assert np.array_equal(vid, ovid), "active block sets differ"
-    assert np.array_equal(num, onum), "per-block particle counts differ"
-    # sorted ids: same particles in each block (order inside a block is free in the reference)
-    osorted = st.g["sorted_ids"][:st.n]
-    of = st.g["first_particle"][:st.n_blocks]
-    on = st.g["num_particles"][:st.n_blocks]
-    ov = st.g["block_vid"][:st.n_blocks]
-    oracle_sets = {tuple(ov[b]): frozenset(osorted[of[b]:of[b] + on[b]].tolist()) for b in range(st.n_blocks)}
-    for b in range(len(vid)):
-        got = frozenset(ids[first[b]:first[b] + num[b]].tolist())
-        assert got == oracle_sets[tuple(vid[b])]
-    assert sorted(ids.tolist()) == list(range(st.n))
-
-
-def check_fields(data, st32, st64, tol=PART_TOL):
-    got = data.read_particles()
-    for name in ("pos", "vel", "def_grad", "affine"):
-        assert_close_to_truth(name, getattr(got, name), st32.arr[name], st64.arr[name], tol)
-    return got
-
-
-def check_grid(data, st32, st64, dim=3):
-    gv, ov = compare_grids(data.read_grid(), grid_of(st64))
-    o32 = grid_of(st32)[1]
-    assert_close_to_truth("grid velocity", gv[:, :dim], o32[:, :dim], ov[:, :dim], GRID_V_TOL)
-    assert_close_to_truth("grid mass", gv[:, dim], o32[:, dim], ov[:, dim], GRID_V_TOL)
 
 
 @pytest.mark.parametrize("model", [MODEL_COROTATED, MODEL_NEO_HOOKEAN])
@@ -326,189 +278,12 @@ def test_device_ptrs_view_matches_the_read_back(hip_libs):
     assert np.array_equal(quads[:, :3], pos[ids])
 
 
-def test_determinism(hip_libs):
-    sc = cloud_scene(n=30000, seed=11)
-    a = run_gpu(sc, 5).read_particles()
-    b = run_gpu(sc, 5).read_particles()
-    for name in ("pos", "vel", "def_grad", "affine"):
-        assert np.array_equal(getattr(a, name), getattr(b, name)), name
-
-
 def test_grid_overflow_is_reported(hip_libs):
     from wgsparkl_amd._ffi import WgsError
     sc = cloud_scene(n=5000)
     sc["grid_capacity"] = 8
     with pytest.raises(WgsError):
         run_gpu(sc, 1)
-
-
-def test_uniform_material_mode_is_bit_identical(hip_libs, monkeypatch):
-    """One material for all particles: the four per-particle constants (mass, V0, lambda, mu) become kernel arguments
-    and F[8] rides in their place (layout.h, Dev::uniform) — 32 bytes per particle and substep less through HBM. Same
-    arithmetic on the same values: bit-identical to the general layout (WGS_DEBUG = 65536 keeps that one), incl. the
-    CPIC passes and Drucker-Prager, and the read-back shows the caller's constants."""
-    for make in (lambda: scenes.neo_hookean_cube(n_side=20, with_floor=True), lambda: scenes.sand_column(nx=12, ny=20, nz=12, with_floor=True)):
-        def run():
-            sc = make()
-            sc["particles"].pos[:, 1] -= 5.6
-            sc["particles"].vel[:, 1] = -2.0
-            data = run_gpu(sc, 30)
-            return sc, data.read_particles(), data.read_grid()
-        sc, a, ga = run()
-        monkeypatch.setenv("WGS_DEBUG", "65536")
-        _, b, gb = run()
-        monkeypatch.delenv("WGS_DEBUG")
-        for f in ("pos", "vel", "def_grad", "affine", "mass", "init_volume", "lambda_", "mu", "cdf_affinity", "dp_state"):
-            assert np.array_equal(getattr(a, f), getattr(b, f)), f
-        assert np.array_equal(a.mass, sc["particles"].mass) and np.array_equal(a.mu, sc["particles"].mu)
-        assert np.array_equal(ga[0], gb[0]) and np.array_equal(ga[1], gb[1])
-
-
-def test_g2p_launch_shapes_are_bit_identical(hip_libs, monkeypatch):
-    """The fused G2P advances one chunk of 64 sorted particles per wave, or — from 1.5 M particles on, where the launch is
-    bound by latency x occupancy — two, with both chunks' particle state requested up front (kernels_transfer.h). The
-    large-scene shape forced on small scenes (WGS_DEBUG = 131072) must give the same bits: elastic with the floor
-    (both bodies of the paired launch), plastic, 2D."""
-    makes = (lambda: scenes.neo_hookean_cube(n_side=24, with_floor=True), lambda: scenes.sand_column(nx=12, ny=20, nz=12, with_floor=True),
-             lambda: scenes.elastic_block_2d(nx=50, ny=40))
-    for make in makes:
-        def run():
-            sc = make()
-            sc["particles"].pos[:, 1] -= 5.6 if sc["particles"].dim == 3 else 4.6
-            sc["particles"].vel[:, 0] = 1.5
-            return run_gpu(sc, 25).read_particles()
-        a = run()
-        monkeypatch.setenv("WGS_DEBUG", "131072")
-        b = run()
-        monkeypatch.delenv("WGS_DEBUG")
-        for f in ("pos", "vel", "def_grad", "affine", "cdf_affinity", "dp_state"):
-            assert np.array_equal(getattr(a, f), getattr(b, f)), f
-
-
-@pytest.mark.parametrize("seed", [1, 4, 9, 12])
-def test_binning_inside_the_fused_g2p_is_bit_identical_to_the_rebin_launch(hip_libs, seed, monkeypatch):
-    """Single-domain data: the fused G2P bins its own output for the next substep (new cell ids, block activation and totals,
-    mover lists: g2p_body.inc, Dev::bin_next), and launch 1 of that substep's sort (k_rebin) is not launched. WGS_DEBUG =
-    1048576 brings k_rebin back. The sort is only a permutation with a canonical order inside a cell, so 150 substeps — random
-    colliders, particles flying through blocks, two table rebuilds, the calls cut at odd places with a wgs_sync between them —
-    must end bit-identical, particles, grid, block set and counts; and both must have counted the same cell-changers."""
-    from helpers import pipeline
-    from wgsparkl_amd import MpmData
-    monkeypatch.setenv("WGS_REHASH_PERIOD", "64")             # (developer override, same results; the default is 1024)
-
-    def run():
-        sc = _random_scene(seed)
-        pipe = pipeline(sc["particles"].dim)
-        data = MpmData.new(pipe, sc["params"], sc["particles"], sc["colliders"], sc["cell_width"], sc["grid_capacity"], sc["model"])
-        for k in (1, 7, 63, 2, 77):
-            pipe.step(data, k)
-            data.sync()
-        return data.read_particles(), data.read_grid(), data.read_blocks(), data.stats()
-    a, ga, ka, sa = run()
-    monkeypatch.setenv("WGS_DEBUG", "1048576")
-    b, gb, kb, sb = run()
-    for f in ("pos", "vel", "def_grad", "affine", "cdf_affinity", "dp_state"):
-        assert np.array_equal(getattr(a, f), getattr(b, f)), f
-    for x, y in zip(ga, gb):
-        assert np.array_equal(x, y)
-    assert np.array_equal(ka[0], kb[0]) and np.array_equal(ka[2], kb[2])   # (block set and counts; where a block sits in memory is up to the atomics)
-    assert sa["cell_changers"] == sb["cell_changers"] and sa["cell_changers"] > 0
-    assert sa["overflow"] == 0 and sb["overflow"] == 0
-
-
-@pytest.mark.parametrize("which", ["dynamic_ball_and_polyline_2d", "cube_on_floor_3d", "sand_between_walls_3d"])
-def test_data_stepped_concurrently_on_their_own_streams_stay_bit_identical(hip_libs, which):
-    """Several wgs_data of one pipeline may run at the same time, each on its own stream (threading). The grid
-    update waits INSIDE the P2G launch for slabs of other workgroups (kernels_transfer.h gu_waves) — a wait that must make
-    progress, and hand over complete data, also while kernels of other data occupy the device. Four copies of a scene are
-    stepped interleaved, no synchronisation between the calls (their kernels overlap), and must end with the same bits as a
-    copy that ran alone; nobody may report a hand-over time-out."""
-    from helpers import pipeline
-    from wgsparkl_amd import MpmData
-
-    def make():
-        if which == "dynamic_ball_and_polyline_2d":
-            sc = _random_scene(1)          # a dynamic ball pushed to its velocity cap, a kinematic cuboid, a moving polyline
-        elif which == "cube_on_floor_3d":
-            sc = scenes.neo_hookean_cube(n_side=40, with_floor=True)
-            sc["particles"].pos[:, 1] -= 5.6
-            sc["particles"].vel[:, 0] = 1.5
-        else:
-            sc = scenes.sand_column(nx=12, ny=20, nz=12, with_floor=True)
-        pipe = pipeline(sc["particles"].dim)
-        return pipe, MpmData.new(pipe, sc["params"], sc["particles"], sc["colliders"], sc["cell_width"], sc["grid_capacity"], sc["model"])
-    pipe, alone = make()
-    for k in (3, 17, 20):
-        pipe.step(alone, k)
-    alone.sync()
-    ref = alone.read_particles()
-    copies = [make()[1] for _ in range(4)]
-    for k in (3, 17, 20):
-        for _ in range(k):
-            for c in copies:
-                pipe.step(c, 1)
-    for c in copies:
-        c.sync()                 # (raises on ERRBIT_HANDOVER)
-        got = c.read_particles()
-        for f in ("pos", "vel", "def_grad", "affine", "cdf_affinity", "dp_state"):
-            assert np.array_equal(getattr(got, f), getattr(ref, f)), f
-        assert c.stats()["overflow"] == 0
-
-
-def test_grid_update_inside_the_p2g_launch_is_bit_identical_to_its_own_launch(hip_libs, monkeypatch):
-    """Single-domain simulations run the grid update as waves of the (last) P2G launch: P2G hands its slabs over
-    inside the launch (write-through stores, one word per block), the waves gather past their XCD's L2
-    (kernels_transfer.h gu_waves). WGS_DEBUG = 262144 brings the launch of its own back: same sums in the same order, so
-    the same bits — no colliders (one P2G launch), a floor in contact (two launches, then the paired one after the
-    host has seen the list), plastic between walls, 2D; particles AND the grid (nodes, slabs' velocities feed the G2P)."""
-    makes = (lambda: scenes.neo_hookean_cube(n_side=24), lambda: scenes.neo_hookean_cube(n_side=40, with_floor=True),
-             lambda: scenes.sand_column(nx=12, ny=20, nz=12, with_floor=True), lambda: scenes.elastic_block_2d(nx=50, ny=40),
-             lambda: scenes.corotated_cube_with_paddle(n_side=32))   # (two-way coupling: node impulses gathered by the same waves)
-    for make in makes:
-        def run():
-            sc = make()
-            if sc["colliders"] and len(sc["colliders"]) == 1:
-                sc["particles"].pos[:, 1] -= 5.6 if sc["particles"].dim == 3 else 4.6
-            sc["particles"].vel[:, 0] = 1.5
-            from helpers import pipeline
-            from wgsparkl_amd import MpmData
-            pipe = pipeline(sc["particles"].dim)
-            data = MpmData.new(pipe, sc["params"], sc["particles"], sc["colliders"], sc["cell_width"], sc["grid_capacity"], sc["model"])
-            pipe.step(data, 12)
-            data.sync()          # (a long near-collider list seen here switches P2G to its paired launch)
-            pipe.step(data, 13)
-            return data.read_particles(), data.read_grid(), data.read_body_poses()
-        a, ga, ba = run()
-        monkeypatch.setenv("WGS_DEBUG", "262144")
-        b, gb, bb = run()
-        monkeypatch.delenv("WGS_DEBUG")
-        for f in ("pos", "vel", "def_grad", "affine", "cdf_affinity", "dp_state"):
-            assert np.array_equal(getattr(a, f), getattr(b, f)), f
-        for x, y in zip(ga, gb):
-            assert np.array_equal(x, y)
-        for x, y in zip(ba, bb):
-            for key in ("translation", "rotation", "linvel", "angvel"):
-                assert np.array_equal(x[key], y[key]), key
-        if len(ba) > 1:      # moving bodies: integrate_bodies rides in the next substep's first sort launch (524288: a launch of its own)
-            monkeypatch.setenv("WGS_DEBUG", "524288")
-            c, _, bc = run()
-            monkeypatch.delenv("WGS_DEBUG")
-            for f in ("pos", "vel", "def_grad", "affine", "cdf_affinity"):
-                assert np.array_equal(getattr(a, f), getattr(c, f)), f
-            for x, y in zip(ba, bc):
-                for key in ("translation", "rotation", "linvel", "angvel"):
-                    assert np.array_equal(x[key], y[key]), key
-
-
-def _exploding_cube():
-    sc = scenes.neo_hookean_cube(n_side=8)
-    ps = sc["particles"]
-    c = ps.pos.mean(0)
-    ps.vel[:] = ((ps.pos - c) * 25.0).astype(np.float32)       # radial: the cube flies apart
-    ps.lambda_[:] = 1.0                                         # (next to no stiffness: nothing holds it together)
-    ps.mu[:] = 1.0
-    sc["params"] = SimulationParams(gravity=(0.0, 0.0, 0.0), dt=sc["params"].dt)
-    return sc
 
 
 def test_grid_grows_before_it_overflows(hip_libs):
@@ -563,95 +338,6 @@ def test_fast_translation_needs_no_more_capacity_than_its_active_blocks(hip_libs
     assert np.allclose(got.vel[:, 0], 900.0, rtol=1e-5) and np.abs(got.def_grad - np.eye(3, dtype=np.float32).reshape(-1)).max() < 1e-4
 
 
-def test_bench_decomposition_eight_ranks_on_one_gpu(hip_libs):
-    """The N = 8 workload of bench.py (one elastic bar cut into 8 x-slabs, every rank generating only its own slab,
-    the floor collider, bench.py's buffer capacities) advanced as a lockstep group on one GPU — wgs_sharded_step_lockstep:
-    the per-phase code of wgs_sharded_step with device-to-device copies as the transport —: same particles as the
-    single-domain run of the whole bar, none lost."""
-    from helpers import pipeline
-    from wgsparkl_amd import MpmData
-    from wgsparkl_amd.sharded import NativeShard, native_lockstep, uniform_material_of
-    world, n_side, k = 8, 24, 40
-    pipe = pipeline(3)
-    full = scenes.neo_hookean_bar(n_side=n_side, world=world, rank=None)
-    vx = lambda gid: (8.0 + 3.0 * np.sin(0.37 * gid.astype(np.float64))).astype(np.float32)   # particles cross the faces
-    full["particles"].vel[:, 0] = vx(full["global_ids"])
-    ref_data = MpmData.new(pipe, full["params"], full["particles"], full["colliders"], full["cell_width"],
-                           full["grid_capacity"] * 4, full["model"])
-    pipe.step(ref_data, k)
-    ref = ref_data.read_particles()
-    shards, total = [], 0
-    for rank in range(world):
-        sc = scenes.neo_hookean_bar(n_side=n_side, world=world, rank=rank)
-        ps = sc["particles"]
-        ps.vel[:, 0] = vx(sc["global_ids"])
-        total += ps.n
-        lo, hi = sc["partition"].block_range(rank)
-        shards.append(NativeShard(pipe, sc["params"], ps, sc["global_ids"], sc["colliders"], sc["cell_width"],
-                                  sc["grid_capacity"], lo, hi, rank > 0, rank < world - 1,
-                                  particle_capacity=int(ps.n * 1.25) + 4096, model=sc["model"], uniform_material=uniform_material_of(ps),
-                                  halo_capacity_records=2 * ((n_side // 8 + 3) ** 2 + 32), migrant_capacity=512))
-    assert total == full["global_particles"] == full["particles"].n
-    n0 = [s.num_particles() for s in shards]
-    native_lockstep(pipe, shards, k)
-    for s in shards:
-        s.sync()                                             # would report a message / capacity overflow
-    outs = [s.export() for s in shards]
-    assert [len(o["ids"]) for o in outs] != n0, "particles must have crossed the faces"
-    ids = np.concatenate([o["ids"] for o in outs])
-    assert np.array_equal(np.sort(ids), np.sort(full["global_ids"]))
-    order = np.argsort(ids)
-    ref_order = np.argsort(full["global_ids"])
-    for f in ("pos", "vel"):
-        got = np.concatenate([o[f] for o in outs])[order]
-        err = rel_rms(got, getattr(ref, f)[ref_order])
-        report_margin(f"bench decomposition, 8 slabs, {f}", err, 1e-5)
-        assert err < 1e-5, f
-
-
-def _random_scene(seed):
-    """Seeded random configuration: dimension, material / plasticity, 0-3 colliders of random kind (ball, cuboid,
-    capsule, mesh), pose and motion, some of them dynamic."""
-    rng = np.random.default_rng(1000 + seed)
-    dim = 3 if seed % 2 == 0 else 2
-    plastic = DruckerPrager.new(1e6, 0.25) if rng.random() < 0.4 else None
-    phase = None if (plastic is not None and rng.random() < 0.5) else ParticlePhase(1.0, -1.0)
-    ps = scenes.random_cloud(1200, dim=dim, seed=100 + seed, extent=9.0, young=1e6, plasticity=plastic, phase=phase,
-                             vel_scale=1.5, perturb_F=0.02, perturb_C=0.2)
-    cols = []
-    for _ in range(int(rng.integers(0, 4))):
-        kind = int(rng.integers(0, 4))
-        pos = tuple(float(x) for x in rng.uniform(1.0, 9.0, dim))
-        vel = tuple(float(x) for x in rng.uniform(-1.0, 1.0, 3))
-        if dim == 3:
-            axis = rng.normal(size=3); axis /= np.linalg.norm(axis)
-            ang = float(rng.uniform(0, 1.5))
-            rot = tuple(float(x) for x in np.append(axis * np.sin(ang / 2), np.cos(ang / 2)))
-            angvel = tuple(float(x) for x in rng.uniform(-0.8, 0.8, 3))
-        else:
-            rot = (float(rng.uniform(0, 1.5)),)
-            angvel = (float(rng.uniform(-0.8, 0.8)),)
-        kw = dict(rotation=rot, linvel=vel, angvel=angvel)
-        if kind == 0:
-            c = Collider.ball(float(rng.uniform(0.8, 2.0)), pos, **kw)
-        elif kind == 1:
-            c = Collider.cuboid(tuple(float(x) for x in rng.uniform(0.6, 2.5, dim)), pos, **kw)
-        elif kind == 2:
-            c = Collider(2, (float(rng.uniform(0.5, 1.5)), float(rng.uniform(0.4, 1.0))), pos, **kw)   # capsule
-        elif dim == 3:
-            v = np.array([[-2.3, 0.1, -2.1], [-2.2, 0.0, 2.4], [2.1, 0.3, -2.2], [2.4, -0.2, 2.3]], np.float32)
-            c = Collider.trimesh(v, np.array([[0, 1, 2], [2, 1, 3]]), pos, **kw)
-        else:
-            v = np.array([[-3.1, 0.2], [-0.4, -0.3], [2.9, 0.4]], np.float32)
-            c = Collider.polyline(v, np.array([[0, 1], [1, 2]]), pos, **kw)
-        if kind in (0, 1) and rng.random() < 0.5:
-            c = c.with_density(float(rng.uniform(5.0, 50.0)), dim)
-        cols.append(c)
-    g = (0.0, -9.81, 0.0)[:dim]
-    return dict(particles=ps, params=SimulationParams(gravity=g, dt=8e-4), colliders=cols, cell_width=1.0,
-                grid_capacity=2048, model=int(rng.integers(0, 2)))
-
-
 @pytest.mark.parametrize("seed,chunk", [(s, 0) for s in range(24)] + [(s, 3) for s in (1, 4, 7, 10, 13, 16, 19, 22)])
 def test_random_scenes_match_oracle(hip_libs, oracle_libs, seed, chunk):
     """Fuzz-style parity: random materials and random collider sets (all shape kinds, kinematic and dynamic),
@@ -698,68 +384,6 @@ def test_random_scenes_match_oracle(hip_libs, oracle_libs, seed, chunk):
         assert worst <= FUZZ_BODY_ATOL
 
 
-@pytest.mark.parametrize("seed", range(6))
-def test_random_scenes_sharded_match_single_domain(hip_libs, seed):
-    """Fuzz-style check of the decomposition: random clouds (stretched along x so that every slab is a few blocks wide)
-    with kinematic analytic colliders, cut into 2-4 slabs, advanced as a lockstep group (wgs_sharded_step_lockstep),
-    against the single-domain run on the same GPU."""
-    from helpers import pipeline
-    from wgsparkl_amd.sharded import native_lockstep
-    rng = np.random.default_rng(500 + seed)
-    dim = 3 if seed % 2 == 0 else 2
-    world = int(rng.integers(2, 5))
-    stretch = 3.0 if dim == 3 else 5.0
-    ps = scenes.random_cloud(4000, dim=dim, seed=300 + seed, extent=22.0, young=1e6, phase=ParticlePhase(1.0, -1.0),
-                             vel_scale=2.5, perturb_F=0.02, perturb_C=0.2)
-    ps.pos[:, 0] *= np.float32(stretch)
-    ps.vel[:, 0] += np.float32(rng.uniform(-6.0, 6.0))      # a drift: particles cross the cuts
-    cols = []
-    for _ in range(int(rng.integers(0, 3))):
-        pos = [float(x) for x in rng.uniform(2.0, 20.0, dim)]
-        pos[0] *= stretch
-        kw = dict(linvel=tuple(float(x) for x in rng.uniform(-1.0, 1.0, 3)),
-                  angvel=tuple(float(x) for x in rng.uniform(-0.5, 0.5, 3 if dim == 3 else 1)))
-        cols.append(Collider.ball(float(rng.uniform(1.0, 3.0)), tuple(pos), **kw) if rng.random() < 0.5 else
-                    Collider.cuboid(tuple(float(x) for x in rng.uniform(1.0, 4.0, dim)), tuple(pos), **kw))
-    g = (0.0, -9.81, 0.0)[:dim]
-    sc = dict(particles=ps, params=SimulationParams(gravity=g, dt=8e-4), colliders=cols, cell_width=1.0,
-              grid_capacity=4096, model=int(rng.integers(0, 2)))
-    k = 30
-    ref = run_gpu(sc, k).read_particles()
-    pipe = pipeline(dim)
-    shards, part = _native_slabs(sc, world, pipe)
-    assert part.min_interior_width() >= 3
-    n0 = [s.num_particles() for s in shards]
-    native_lockstep(pipe, shards, k)
-    for s in shards:
-        s.sync()
-    outs = [s.export() for s in shards]
-    ids = np.concatenate([o["ids"] for o in outs])
-    assert np.array_equal(np.sort(ids), np.arange(ps.n, dtype=np.uint32))
-    order = np.argsort(ids)
-    for f in ("pos", "vel"):
-        got = np.concatenate([o[f] for o in outs])[order]
-        tol = 1e-5 if f == "pos" else 2e-4
-        err = rel_rms(got, getattr(ref, f))
-        report_margin(f"sharded fuzz {f}", err, tol, migrated=bool([len(o["ids"]) for o in outs] != n0))
-        assert err < tol, f
-
-
-@pytest.mark.parametrize("seed", [0, 3, 8])
-def test_steady_state_rebinning_is_bit_identical_to_full_binning(hip_libs, seed, monkeypatch):
-    """k_rebin (re-binning relative to the previous substep's blocks) against the general k_bin forced on every
-    substep (WGS_DEBUG=128, read when the data is created): the sort is only a permutation, so 150 substeps —
-    across two table rebuilds — must end bit-identical."""
-    sc = _random_scene(seed)
-    k = 150
-    monkeypatch.setenv("WGS_REHASH_PERIOD", "64")             # (developer override, same results; the default is 1024)
-    a = run_gpu(sc, k).read_particles()
-    monkeypatch.setenv("WGS_DEBUG", "128")
-    b = run_gpu(sc, k).read_particles()
-    for f in ("pos", "vel", "def_grad", "affine", "cdf_affinity", "dp_state"):
-        assert np.array_equal(getattr(a, f), getattr(b, f)), f
-
-
 def test_long_near_collider_list_paths_match_the_separate_launches_and_the_oracle(hip_libs, monkeypatch):
     """Once wgs_sync has seen a long near-collider list, P2G runs its plain and its CPIC body in one launch (k_p2g_pair)
     and G2P sizes the list half of k_g2p_pair from it. A 262 k-particle corotated cube resting on the floor under a
@@ -799,105 +423,6 @@ def test_long_near_collider_list_paths_match_the_separate_launches_and_the_oracl
     for f, tol in (("pos", 2e-6), ("vel", 2e-4)):
         err, err32 = rel_rms(getattr(pa, f)[same], st64.arr[f][same]), rel_rms(st.arr[f][same], st64.arr[f][same])
         assert err < max(tol, 10.0 * err32), (f, err, err32)
-
-
-def test_plastic_pair_register_budgets_are_bit_identical(hip_libs, monkeypatch):
-    """Drucker-Prager sand between a floor and four walls, half of the blocks near a collider: after the first wgs_sync
-    the fused G2P runs the variant compiled for 2 waves per SIMD (no spills in the CPIC body). Same source, another
-    register budget: the results must be the bits of the 3-waves variant (WGS_DEBUG = 16384 keeps that one), because
-    which of the two runs depends on when the host synchronised."""
-    from helpers import pipeline
-    from wgsparkl_amd import MpmData
-    sc = scenes.sand_column(nx=40, ny=60, nz=40, with_walls=True)
-    sc["particles"].pos[:, 1] -= 5.8
-
-    def run():
-        pipe = pipeline(3)
-        data = MpmData.new(pipe, sc["params"], sc["particles"], sc["colliders"], sc["cell_width"], sc["grid_capacity"], sc["model"])
-        pipe.step(data, 4)
-        data.sync()
-        st = data.stats()
-        assert st["num_near_collider_blocks"] * 2 >= st["num_active_blocks"]     # the switch condition of capi.hip
-        pipe.step(data, 8)
-        data.sync()
-        return data.read_particles()
-    a = run()
-    monkeypatch.setenv("WGS_DEBUG", "16384")
-    b = run()
-    for f in ("pos", "vel", "def_grad", "affine", "cdf_affinity", "dp_state"):
-        assert np.array_equal(getattr(a, f), getattr(b, f)), f
-    assert np.isfinite(a.pos).all() and len(sc["colliders"]) == 5
-    # the one-way P2G pair has two register budgets too (chosen from the particle count and the list length): force the
-    # small one by making the scene "large" is not possible at this size, so compare the large budget (this scene's
-    # choice) with the separate launches, and the small budget at a size that selects it below
-    monkeypatch.setenv("WGS_DEBUG", "8192")
-    c = run()
-    for f in ("pos", "vel", "def_grad", "affine", "cdf_affinity", "dp_state"):
-        assert np.array_equal(getattr(a, f), getattr(c, f)), f
-    for c in range(5):
-        assert ((a.cdf_affinity >> c) & 1).sum() > 100, c
-
-
-def test_large_one_way_scenes_do_not_depend_on_when_the_host_synchronised(hip_libs, monkeypatch):
-    """From 600 k particles on, one-way collider simulations always run the paired P2G launch with the CPIC body cut to
-    168 VGPRs — a budget that differs from the unconstrained one in the last bit here and there, so it must not follow
-    the near-collider list the host last saw. 640 k neo-Hookean particles lying on the floor: eight substeps in one call
-    and the same eight with a wgs_sync after the third end bit-identical; the unconstrained budget (WGS_DEBUG = 32768)
-    agrees to round-off."""
-    from helpers import pipeline
-    from wgsparkl_amd import MpmData
-    sc = scenes.neo_hookean_cube(n_side=86, with_floor=True)
-    sc["particles"].pos[:, 1] -= 5.7
-    assert sc["particles"].n >= 600_000
-
-    def run(chunks):
-        pipe = pipeline(3)
-        data = MpmData.new(pipe, sc["params"], sc["particles"], sc["colliders"], sc["cell_width"], sc["grid_capacity"], sc["model"])
-        for k in chunks:
-            pipe.step(data, k)
-            data.sync()
-        assert data.stats()["num_near_collider_blocks"] >= 8
-        return data.read_particles()
-    a, b = run((8,)), run((3, 5))
-    for f in ("pos", "vel", "def_grad", "affine", "cdf_affinity"):
-        assert np.array_equal(getattr(a, f), getattr(b, f)), f
-    monkeypatch.setenv("WGS_DEBUG", "32768")
-    c = run((3, 5))
-    assert np.array_equal(a.cdf_affinity, c.cdf_affinity)
-    for f in ("pos", "vel", "def_grad"):
-        assert rel_rms(getattr(c, f), getattr(a, f)) < 1e-6, f
-
-
-@pytest.mark.parametrize("seed", [1, 2, 6, 8])
-def test_checkpoint_restart_random_scenes(hip_libs, seed):
-    """Bit-exact restart on the fuzz scenes: dynamic and kinematic bodies, mesh colliders, plasticity."""
-    import dataclasses
-    from helpers import pipeline
-    from wgsparkl_amd import MpmData
-    sc = _random_scene(seed)
-    dim = sc["particles"].dim
-    pipe = pipeline(dim)
-    args = (sc["cell_width"], sc["grid_capacity"], sc["model"])
-    full = MpmData.new(pipe, sc["params"], sc["particles"], sc["colliders"], *args)
-    pipe.step(full, 20)
-    part = MpmData.new(pipe, sc["params"], sc["particles"], sc["colliders"], *args)
-    pipe.step(part, 9)
-    snap, bodies = part.read_particles(), part.read_body_poses()
-    def restored(c, b):
-        rot = tuple(b["rotation"]) if dim == 3 else (float(np.arctan2(b["rotation"][1], b["rotation"][0])),)
-        return dataclasses.replace(c, translation=tuple(b["translation"]), rotation=rot, linvel=tuple(b["linvel"]) + (0.0,) * (3 - dim),
-                                   angvel=tuple(b["angvel"]), com=tuple(b["com"]))
-    cols2 = [restored(c, b) for c, b in zip(sc["colliders"], bodies)]
-    rest = MpmData.new(pipe, sc["params"], snap, cols2, *args)
-    rest.set_plastic_state(snap.dp_state)
-    pipe.step(rest, 11)
-    a, b = full.read_particles(), rest.read_particles()
-    exact = dim == 3     # 2D poses are handed over as an angle: cos / sin round-trip costs an ulp
-    for f in ("pos", "vel", "def_grad", "affine", "dp_state", "cdf_affinity"):
-        if exact or not sc["colliders"]:
-            assert np.array_equal(getattr(a, f), getattr(b, f)), f
-        elif f != "cdf_affinity":
-            assert rel_rms(getattr(b, f), getattr(a, f)) < 1e-4, f
 
 
 @pytest.mark.parametrize("seed", range(6))
@@ -953,50 +478,6 @@ def test_random_api_sequences_match_oracle(hip_libs, oracle_libs, seed):
     report_margin("api sequence pos rel rms", rel_rms(got.pos[same], st.arr["pos"][same]), 2e-5)
     assert same.mean() > 0.995
     assert rel_rms(got.pos[same], st.arr["pos"][same]) < 2e-5
-
-
-def test_sharded_run_with_kinematic_collider(hip_libs):
-    """configs[3]'s decomposition on one GPU at a small size: the corotated bar on the floor, cut into 4 slabs, and the
-    kinematic rotating cuboid at its end, which every rank integrates identically; particles, CPIC state and the body
-    pose match the single-domain run (the bar slides towards the cuboid, so particles cross the cuts)."""
-    from helpers import pipeline
-    from wgsparkl_amd.sharded import NativeShard, native_lockstep, uniform_material_of
-    k, world, n = 30, 4, 24
-
-    def c4(rank):
-        sc = scenes.config_scene("c4", world, rank, "weak", n_side=n)
-        sc["particles"].vel[:, 0] = (16.0 + 2.0 * np.sin(0.37 * sc["global_ids"].astype(np.float64))).astype(np.float32)
-        return sc
-    full = c4(None)
-    single = run_gpu(full, k)
-    ref, ref_body = single.read_particles(), single.read_body_poses()
-    assert ((ref.cdf_affinity & 2) != 0).sum() > 100       # the paddle does touch the bar
-    pipe = pipeline(3)
-    shards = []
-    for r in range(world):
-        sc = c4(r)
-        lo, hi = sc["partition"].block_range(r)
-        shards.append(NativeShard(pipe, sc["params"], sc["particles"], sc["global_ids"], sc["colliders"], sc["cell_width"], sc["grid_capacity"],
-                                  lo, hi, r > 0, r < world - 1, particle_capacity=full["particles"].n, model=sc["model"],
-                                  uniform_material=uniform_material_of(sc["particles"]), halo_capacity_records=512, migrant_capacity=2048))
-    n0 = [s.num_particles() for s in shards]
-    native_lockstep(pipe, shards, k)
-    for s in shards:
-        s.sync()
-    outs = [s.export() for s in shards]
-    assert [len(o["ids"]) for o in outs] != n0
-    ids = np.concatenate([o["ids"] for o in outs])
-    assert np.array_equal(np.sort(ids), np.sort(full["global_ids"]))
-    order, ref_order = np.argsort(ids), np.argsort(full["global_ids"])
-    for f in ("pos", "vel"):
-        got = np.concatenate([o[f] for o in outs])[order]
-        err = rel_rms(got, getattr(ref, f)[ref_order])
-        report_margin(f"sharded c4 {f}", err, 1e-5)
-        assert err < 1e-5, f
-    for s in shards:                                        # every rank holds the same body state
-        b = s.read_body_poses()
-        assert np.allclose(b[1]["rotation"], ref_body[1]["rotation"], atol=1e-6)
-        assert np.allclose(b[1]["translation"], ref_body[1]["translation"], atol=1e-5)
 
 
 def test_body_setters_and_readback(hip_libs, oracle_libs):
@@ -1116,302 +597,6 @@ def test_c_abi_rejects_bad_arguments(hip_libs):
         MpmData.new(pipe, sc["params"], sc["particles"], many, sc["cell_width"], sc["grid_capacity"], sc["model"])
 
 
-def test_checkpoint_restart_is_bit_exact(hip_libs):
-    """read_particles (+ plastic state, + body poses) -> MpmData.new -> set_plastic_state continues the
-    run bit-for-bit (every reduction is in canonical particle order, whatever the storage order)."""
-    import dataclasses
-    from helpers import pipeline
-    from wgsparkl_amd import MpmData
-    ps = scenes.random_cloud(3000, dim=3, seed=5, extent=10.0, young=1e6, plasticity=DruckerPrager.new(1e6, 0.25), phase=None)
-    ps.pos[:, 1] += 3.0
-    cols = [Collider.cuboid((50.0, 1.0, 50.0), (8.0, 1.0, 8.0)),
-            Collider.ball(1.5, (8.0, 12.0, 8.0), linvel=(0.0, -1.0, 0.0), angvel=(0.0, 0.0, 0.5))]
-    params = SimulationParams((0.0, -9.81, 0.0), 5e-4)
-    pipe = pipeline(3)
-    args = (1.0, 4096, MODEL_COROTATED)
-    full = MpmData.new(pipe, params, ps, cols, *args)
-    pipe.step(full, 24)
-    part = MpmData.new(pipe, params, ps, cols, *args)
-    pipe.step(part, 12)
-    snap, bodies = part.read_particles(), part.read_body_poses()
-    assert (snap.dp_state != np.array([1.0, 1.0, 0.0], np.float32)).any(), "scene should have yielded by now"
-    cols2 = [dataclasses.replace(c, translation=tuple(b["translation"]), rotation=tuple(b["rotation"]),
-                                 linvel=tuple(b["linvel"]), angvel=tuple(b["angvel"]), com=tuple(b["com"]))
-             for c, b in zip(cols, bodies)]
-    rest = MpmData.new(pipe, params, snap, cols2, *args)
-    rest.set_plastic_state(snap.dp_state)
-    pipe.step(rest, 12)
-    a, b = full.read_particles(), rest.read_particles()
-    for f in ("pos", "vel", "def_grad", "affine", "dp_state", "phase", "cdf_affinity", "cdf_normal", "cdf_dist"):
-        assert np.array_equal(getattr(a, f), getattr(b, f)), f
-    pa, pb = full.read_body_poses(), rest.read_body_poses()
-    for x, y in zip(pa, pb):
-        for key in x:
-            assert np.array_equal(x[key], y[key]), key
-
-
-def _native_slabs(sc, world, pipe, **kw):
-    """The scene cut into `world` x-slabs balanced by particle count, each a NativeShard of a lockstep group."""
-    from wgsparkl_amd.sharded import NativeShard, SlabPartition, associated_block_x, split_scene, uniform_material_of
-    ps = sc["particles"]
-    part = SlabPartition.balanced(associated_block_x(ps.pos, sc["cell_width"], ps.dim), world)
-    shards = []
-    for r, (sub, gids) in enumerate(split_scene(ps, part, sc["cell_width"])):
-        lo, hi = part.block_range(r)
-        shards.append(NativeShard(pipe, sc["params"], sub, gids, sc["colliders"], sc["cell_width"], sc["grid_capacity"],
-                                  lo, hi, r > 0, r < world - 1, particle_capacity=ps.n, model=sc["model"],
-                                  uniform_material=uniform_material_of(ps), **kw))
-    return shards, part
-
-
-@pytest.mark.parametrize("name", ["dynamic_ball3d", "dynamic_ball2d"])
-def test_dynamic_bodies_on_sharded_data(hip_libs, name):
-    """Two-way coupling across slabs (rigid_impulses.wgsl:94-137, p2g.wgsl:142-155): every slab accumulates the
-    fixed-point impulses of its own particles, the sums are reduced over the slabs before integrate_bodies. Against
-    the single-domain run of the golden scene: the bodies to the fixed-point resolution (1e-5 per node and substep:
-    a node's impulse is truncated per slab here, once in a single domain), the particles to fp32 round-off."""
-    from helpers import pipeline
-    from wgsparkl_amd.sharded import native_lockstep
-    make, k = _CASES[name]
-    sc = make()
-    dim = sc["particles"].dim
-    ref = run_gpu(sc, k)
-    ref_p, ref_b = ref.read_particles(), ref.read_body_poses()
-    pipe = pipeline(dim)
-    shards, _ = _native_slabs(sc, 2, pipe)
-    assert min(s.num_particles() for s in shards) > 0
-    native_lockstep(pipe, shards, k)
-    for s in shards:
-        s.sync()
-    bodies = [s.read_body_poses() for s in shards]
-    for key in ("rotation", "translation", "linvel", "angvel"):
-        a = np.stack([b[key] for b in bodies[0]])
-        assert np.array_equal(a, np.stack([b[key] for b in bodies[1]])), "every slab integrates the same bodies"
-        want = np.stack([b[key] for b in ref_b])
-        err = float(np.abs(a - want).max())
-        report_margin(f"sharded body {key} abs err", err, 3e-4)
-        assert err < 3e-4, (key, a, want)
-    assert np.abs(np.stack([b["linvel"] for b in bodies[0]])[0] - np.asarray(sc["colliders"][0].linvel)[:dim]).max() > 1e-3, \
-        "the dynamic body must have been pushed"
-    outs = [s.export() for s in shards]
-    ids = np.concatenate([o["ids"] for o in outs])
-    assert np.array_equal(np.sort(ids), np.arange(sc["particles"].n, dtype=np.uint32))
-    order = np.argsort(ids)
-    for f, tol in (("pos", 1e-5), ("vel", 5e-5)):
-        got = np.concatenate([o[f] for o in outs])[order]
-        err = rel_rms(got, getattr(ref_p, f))
-        report_margin(f"sharded two-way {f}", err, tol)
-        assert err < tol, (f, err)
-
-
-@pytest.mark.parametrize("dim", [3, 2])
-def test_sharded_substep_with_pack_and_interior_grid_update_inside_the_p2g_launch_is_bit_identical(hip_libs, dim, monkeypatch):
-    """Inside wgs_sharded_step the waves that pack the outgoing messages and the grid update of the interior blocks ride in
-    the P2G launch (GU = 3: slabs handed over word by word); the interface layers are updated after the
-    exchange. WGS_DEBUG = 262144 brings the k_pack_face launch and the one grid update back: the same bits on every slab
-    (3 slabs in lockstep, a floor, particles migrating, a table rebuild inside the run)."""
-    from helpers import pipeline
-    from wgsparkl_amd.sharded import native_lockstep
-    monkeypatch.setenv("WGS_REHASH_PERIOD", "64")
-    world = 3
-
-    def run():
-        if dim == 3:
-            sc = scenes.config_scene("c2", world, None, "weak", n_side=24)
-            sc["particles"].pos[:, 1] -= 5.6                  # in contact with the floor: both P2G bodies run
-        else:
-            sc = scenes.elastic_block_2d(nx=48 * world, ny=40, with_floor=True)
-            sc["particles"].pos[:, 1] -= 4.6
-        ps = sc["particles"]
-        rng = np.random.default_rng(8)
-        ps.vel[:] = rng.normal(0.0, 2.0, ps.vel.shape).astype(np.float32)
-        ps.vel[:, 0] += 8.0
-        pipe = pipeline(dim)
-        shards, part = _native_slabs(sc, world, pipe)
-        native_lockstep(pipe, shards, 40)
-        for sh in shards:
-            sh.sync()                                          # (the near-collider lists are seen here: paired launches from now on)
-        native_lockstep(pipe, shards, 40)
-        for sh in shards:
-            sh.sync()
-        return [sh.export() for sh in shards]
-    a = run()
-    monkeypatch.setenv("WGS_DEBUG", "262144")
-    b = run()
-    monkeypatch.delenv("WGS_DEBUG")
-    # wgs_sharded_step with neighbours splits P2G: the two block layers at each cut first (their slabs are what the messages
-    # are gathered from: they run beside the exchange on a stream of their own), every other block and the interior's grid
-    # update in a second launch. WGS_DEBUG = 4194304 splits the lockstep slabs the same way (on their one stream): same bits.
-    monkeypatch.setenv("WGS_DEBUG", "4194304")
-    c = run()
-    monkeypatch.delenv("WGS_DEBUG")
-    for other in (b, c):
-        for x, y in zip(a, other):
-            ox, oy = np.argsort(x["ids"]), np.argsort(y["ids"])    # (the storage order of a slab follows the arrival order of its guests)
-            assert np.array_equal(x["ids"][ox], y["ids"][oy])
-            for f in ("pos", "vel", "def_grad", "affine"):
-                assert np.array_equal(x[f][ox], y[f][oy]), f
-
-
-@pytest.mark.parametrize("world,dim", [(2, 3), (3, 3), (4, 3), (2, 2)])
-def test_native_lockstep_matches_single_domain(hip_libs, world, dim, monkeypatch):
-    """wgs_sharded_step_lockstep — the C++ driver of the substep protocol that wgs_sharded_step runs per rank over
-    RCCL — reproduces the single-domain run (80 substeps: crosses a table rebuild; particles migrate)."""
-    from helpers import pipeline
-    from wgsparkl_amd.sharded import associated_block_x, native_lockstep
-    monkeypatch.setenv("WGS_REHASH_PERIOD", "64")             # table rebuilds inside the run (developer override, same results)
-    # a bar along x, a few blocks per slab (a slab between two neighbours must be at least 3 blocks wide)
-    if dim == 3:
-        sc = scenes.config_scene("c2", world, None, "weak", n_side=24)      # 24 * world x 24 x 24 particles
-        sc["colliders"] = []
-    else:
-        sc = scenes.elastic_block_2d(nx=48 * world, ny=40, with_floor=False)
-    ps = sc["particles"]
-    rng = np.random.default_rng(8)
-    ps.vel[:] = rng.normal(0.0, 3.0, ps.vel.shape).astype(np.float32)
-    ps.vel[:, 0] += 8.0
-    k = 80
-    ref = run_gpu(sc, k).read_particles()
-    pipe = pipeline(dim)
-    shards, part = _native_slabs(sc, world, pipe)
-    assert part.min_interior_width() >= 3
-    n0 = [s.num_particles() for s in shards]
-    native_lockstep(pipe, shards, 30)
-    native_lockstep(pipe, shards, k - 30)                  # two calls: state carried across frames
-    for s in shards:
-        s.sync()
-    outs = [s.export() for s in shards]
-    ids = np.concatenate([o["ids"] for o in outs])
-    assert np.array_equal(np.sort(ids), np.arange(ps.n, dtype=np.uint32))
-    assert [len(o["ids"]) for o in outs] != n0, "the test scene must make particles migrate"
-    order = np.argsort(ids)
-    for f, tol in (("pos", 1e-5), ("vel", 1e-5), ("def_grad", 1e-5), ("affine", 2e-4)):
-        err = rel_rms(np.concatenate([o[f] for o in outs])[order], getattr(ref, f))
-        report_margin(f"native lockstep {f}", err, tol)
-        assert err < tol, (f, err)
-    for r, o in enumerate(outs):                               # a rank holds its core range + the particles that left it in
-        lo, hi = part.block_range(r)                           # the last substep (handed over with the next message)
-        bx = associated_block_x(o["pos"], sc["cell_width"], dim)
-        assert ((bx >= lo - 1) & (bx <= hi)).all()
-
-
-@pytest.mark.parametrize("with_floor", [False, True])
-def test_particles_enter_an_empty_slab_and_leave_theirs_empty(hip_libs, with_floor):
-    """The edge of the one-exchange protocol: a cube flies from slab 0 into slab 1, which holds NO particle at the start —
-    the first arrivals find none of their blocks active on their new rank and read their nodes from the message (the old
-    owner's partial sums are then the totals; with the floor also the node cdfs, evaluated on the spot) — and keeps going
-    until slab 0 is empty. Both against the single-domain run."""
-    from helpers import pipeline
-    from wgsparkl_amd.sharded import NativeShard, SlabPartition, associated_block_x, native_lockstep, split_scene, uniform_material_of
-    sc = scenes.neo_hookean_cube(n_side=16, with_floor=with_floor)
-    ps = sc["particles"]
-    if with_floor:
-        ps.pos[:, 1] -= 5.6                                   # sliding just above the floor: CPIC state travels with the particles
-    ps.vel[:, 0] = 400.0                                      # a third of a cell per substep
-    k = 45                                                    # 15 cells: the whole cube (8 cells wide) crosses the cut
-    ref = run_gpu(sc, k).read_particles()
-    bx = associated_block_x(ps.pos, sc["cell_width"], 3)
-    part = SlabPartition([int(bx.min()), int(bx.max()) + 1, int(bx.max()) + 12])
-    pipe = pipeline(3)
-    shards = []
-    for r, (sub, gids) in enumerate(split_scene(ps, part, sc["cell_width"])):
-        lo, hi = part.block_range(r)
-        shards.append(NativeShard(pipe, sc["params"], sub, gids, sc["colliders"], sc["cell_width"], sc["grid_capacity"], lo, hi, r > 0, r < 1,
-                                  particle_capacity=ps.n, model=sc["model"], uniform_material=uniform_material_of(ps),
-                                  halo_capacity_records=256, migrant_capacity=2048))
-    assert [s.num_particles() for s in shards] == [ps.n, 0]
-    native_lockstep(pipe, shards, 20)
-    mid = [s.num_particles() for s in shards]
-    assert 0 < mid[0] < ps.n and sum(mid) == ps.n, mid         # on its way
-    native_lockstep(pipe, shards, k - 20)
-    for s in shards:
-        s.sync()
-    assert [s.num_particles() for s in shards] == [0, ps.n]
-    outs = [s.export() for s in shards]
-    ids = np.concatenate([o["ids"] for o in outs])
-    assert np.array_equal(np.sort(ids), np.arange(ps.n, dtype=np.uint32))
-    order = np.argsort(ids)
-    for f, tol in (("pos", 1e-5), ("vel", 1e-5), ("def_grad", 1e-5)):
-        err = rel_rms(np.concatenate([o[f] for o in outs])[order], getattr(ref, f))
-        report_margin(f"cube into an empty slab ({'floor' if with_floor else 'free'}) {f}", err, tol)
-        assert err < tol, (f, err)
-
-
-@pytest.mark.parametrize("name", ["mesh_floor3d", "polyline2d"])
-def test_mesh_colliders_on_sharded_data(hip_libs, name):
-    """Mesh colliders (rigid-particle samples) on slabs: every slab holds every sample, the node cdfs of the
-    nodes two slabs share are computed by both from the same inputs. Two slabs in lockstep against the single-domain run of
-    the golden scene: the same particles on the same side of the mesh, fields to fp32 round-off."""
-    from helpers import pipeline
-    from wgsparkl_amd.sharded import native_lockstep
-    make, k = _CASES[name]
-    sc = make()
-    dim = sc["particles"].dim
-    ref = run_gpu(sc, k).read_particles()
-    pipe = pipeline(dim)
-    shards, _ = _native_slabs(sc, 2, pipe)
-    assert min(s.num_particles() for s in shards) > 0
-    native_lockstep(pipe, shards, k)
-    for s in shards:
-        s.sync()
-    outs = [s.export() for s in shards]
-    ids = np.concatenate([o["ids"] for o in outs])
-    assert np.array_equal(np.sort(ids), np.arange(sc["particles"].n, dtype=np.uint32))
-    order = np.argsort(ids)
-    assert (ref.cdf_affinity != 0).sum() > 10, "the scene must feel its mesh"
-    for f, tol in (("pos", 1e-5), ("vel", 5e-5), ("def_grad", 1e-5)):
-        err = rel_rms(np.concatenate([o[f] for o in outs])[order], getattr(ref, f))
-        report_margin(f"sharded mesh {f}", err, tol)
-        assert err < tol, (f, err)
-
-
-def test_native_sharded_step_over_rccl_one_rank(hip_libs):
-    """wgs_comm_* + wgs_shard_attach + wgs_sharded_step with a real RCCL communicator. A second rank on the same GPU
-    is refused by RCCL, so: (a) world = 1 without neighbours must reproduce wgs_step on single-domain data;
-    (b) WGS_COMM_SELF_NEIGHBOURS: the rank is its own lower and upper neighbour, so every ncclSend / ncclRecv group
-    of an interior rank is issued and matched (its physics is meaningless: the slab adds its own halo to itself) —
-    the run must complete, keep its particles and report no error."""
-    import ctypes as C
-    from helpers import pipeline
-    from wgsparkl_amd import _ffi
-    from wgsparkl_amd.sharded import INT_MAX, INT_MIN, NativeComm, NativeShard
-    sc = scenes.neo_hookean_cube(n_side=24, with_floor=True)
-    ps = sc["particles"]
-    ps.vel[:, 0] = 2.0
-    pipe = pipeline(3)
-    k = 20
-    ref = run_gpu(sc, k).read_particles()
-    comm = NativeComm(pipe, None, 0, 1)
-    gids = np.arange(ps.n, dtype=np.uint32)
-    sh = NativeShard(pipe, sc["params"], ps, gids, sc["colliders"], sc["cell_width"], sc["grid_capacity"], INT_MIN, INT_MAX,
-                     False, False, ps.n, sc["model"], comm=comm, halo_capacity_records=64, migrant_capacity=64)
-    sh.step(k)
-    sh.sync()
-    out = sh.export()
-    order = np.argsort(out["ids"])
-    assert rel_rms(out["pos"][order], ref.pos) < 1e-6 and rel_rms(out["vel"][order], ref.vel) < 1e-5
-    sh.close(); comm.close()
-    # (b) self-neighbour proxy
-    comm = NativeComm(pipe, None, 0, 1, flags=1)
-    from wgsparkl_amd.sharded import associated_block_x
-    bx = associated_block_x(ps.pos, sc["cell_width"], 3)
-    sh = NativeShard(pipe, sc["params"], ps, gids, sc["colliders"], sc["cell_width"], sc["grid_capacity"], int(bx.min()), int(bx.max()) + 2,
-                     True, True, int(ps.n * 1.5), sc["model"], comm=comm, halo_capacity_records=512, migrant_capacity=1024)
-    ps.vel[:, 0] = 0.0
-    sh2 = sh
-    sh2.step(k)
-    sh2.sync()
-    assert sh2.num_particles() == ps.n
-    sh2.close(); comm.close()
-
-
-# ---------------------------------------------------------------------------------------------
-# Committed golden vectors (tests/golden/oracle_regression.npz) incl. the CPIC collider paths
-# ---------------------------------------------------------------------------------------------
-import os as _os
-
-from golden_cases import CASES as _CASES
-
 _GOLD = np.load(_os.path.join(_os.path.dirname(_os.path.abspath(__file__)), "golden", "oracle_regression.npz"))
 
 
@@ -1521,3 +706,4 @@ def test_set_sim_params_and_colliders(hip_libs, oracle_libs):
     assert same.mean() > 0.995
     assert rel_rms(got.pos[same], st.arr["pos"][same]) < 1e-5
     assert rel_rms(got.vel[same], st.arr["vel"][same]) < 1e-4
+

@@ -2,7 +2,7 @@
 fresh child processes: nothing here touches a GPU in the pytest process) against the single-domain run of the same
 scene — the elastic bar of the bench preflight, configs[3] with its kinematic rotating cuboid, a dynamic body (two-way
 coupling: the ranks' fixed-point impulses are all-reduced) and mesh colliders. One-GPU boxes skip; there the same
-protocol code runs as a lockstep group on one device (test_gpu_parity.py) and over gloo on the CPU (test_sharded_cpu.py)."""
+protocol code runs as a lockstep group on one device (test_gpu_sharded.py) and over gloo on the CPU (test_sharded_cpu.py)."""
 import json
 import os
 import socket

@@ -5,7 +5,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 os.environ["WGS_REHASH_PERIOD"] = "64"
-from test_gpu_parity import _random_scene
+from gpu_common import _random_scene
 from helpers import pipeline
 from wgsparkl_amd import MpmData
 seed, nd, reps, ksub = (int(x) for x in sys.argv[1:5])

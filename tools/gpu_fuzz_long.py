@@ -1,7 +1,7 @@
 """Developer utility: many more seeds of the fuzz parity tests than the suite runs (bug hunting on an idle GPU)."""
 import sys, traceback; sys.path.insert(0, '.'); sys.path.insert(0, 'tests')
 import numpy as np
-import test_gpu_parity as T
+import gpu_common as T
 from helpers import run_gpu, run_oracle, rel_rms
 lo, hi = int(sys.argv[1]), int(sys.argv[2])
 bad = []
