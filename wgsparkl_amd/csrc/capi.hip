@@ -718,7 +718,9 @@ template <bool TS> wgs_status enqueue_substep(wgs_data *d, int ts_slot, int part
         HIP_TRY(hipMemsetAsync(dev.blk_narr, 0, sizeof(uint32_t) * (size_t)dev.cap, s));
     }
     if (first) d->prebinned = false;
-    dev.bin_next = (part == 0 && !dev.sharded && !(dev.dbg & (128u | 1048576u)) && (d->substeps + 1) % d->rehash_period != 0) ? 1u : 0u;
+    // (not the plastic variants: their fused G2P is compiled without the binning — kernels_transfer.h: the code alone, beyond the
+    // instruction cache, cost a third of the launch — and launch 1 of the sort, k_rebin, stays)
+    dev.bin_next = (part == 0 && !dev.sharded && !d->plastic && !(dev.dbg & (128u | 1048576u)) && (d->substeps + 1) % d->rehash_period != 0) ? 1u : 0u;
     // the fused G2P drops the guests only inside the sharded step (kernels_shard.h); wgs_step on a slab advances what it holds
     dev.skip_guests = (d->in_sharded_step && dev.sharded) ? 1u : 0u;
     if (dev.sharded && d->needs_compact && first) {
@@ -887,10 +889,10 @@ template <bool TS> wgs_status enqueue_substep(wgs_data *d, int ts_slot, int part
             // (the decomposition is a template parameter of the fused G2P: kernels_transfer.h; a slab always takes the paired /
             // single-body launch shapes, the two-launch debug shape exists for single-domain data only)
 #define WGS_LAUNCH_G2P(MODEL, PL, CM, NP, SH)                                                                          \
-    hipLaunchKernelGGL((k_g2p_update<D, MODEL, PL, CM, NP, SH>), (CM) == 2 ? dim3(8 * (grid_for(d, 1) * 3 / 2)) : dim3(g), \
+    hipLaunchKernelGGL((k_g2p_update<D, MODEL, PL, CM, NP, SH, !(PL)>), (CM) == 2 ? dim3(8 * (grid_for(d, 1) * 3 / 2)) : dim3(g), \
                        dim3(G2P_THREADS), 0, s, dev, side, epoch)
 #define WGS_LAUNCH_G2P_PAIR(MODEL, PL, WPE, NP, SH)                                                                        \
-    hipLaunchKernelGGL((k_g2p_pair<D, MODEL, PL, WPE, NP, SH>), dim3((uint32_t)g + 8u * nlist), dim3(G2P_THREADS), 0, s, \
+    hipLaunchKernelGGL((k_g2p_pair<D, MODEL, PL, WPE, NP, SH, !(PL)>), dim3((uint32_t)g + 8u * nlist), dim3(G2P_THREADS), 0, s, \
                        dev, side, epoch, (uint32_t)g, nlist)
 #define WGS_LAUNCH_G2P_NP(MODEL, PL, NP)    \
     do {                                    \

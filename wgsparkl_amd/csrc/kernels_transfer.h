@@ -516,6 +516,7 @@ __device__ unsigned long long g_g2p_prof[WGS_G2P_ROWS][8];
 // chunks a block spans, and only that block's particles are processed; the launch is nearly free while no
 // particle is near a collider.
 #define G2P_DONE continue;
+#define G2P_BIN (BIN && !SHARD)
 // Chunks of 64 sorted particles per wave of the main body (template parameter NPASS, g2p_body.inc): 1 while the two particle
 // buffers fit the 256 MB Infinity Cache (the launch then runs at HBM-roofline speed for its real traffic and a longer
 // wave life only costs), 2 beyond — there the kernel is bound by latency x occupancy and twice the bytes in flight per
@@ -535,7 +536,11 @@ constexpr uint32_t G2P_TWO_PASS_MIN_PARTICLES = WGS_G2P_TWO_PASS_MIN;
 #endif
 constexpr int G2P_MANY_PASSES = WGS_G2P_MANY_PASSES;
 constexpr uint32_t G2P_MANY_PASS_MIN_PARTICLES = WGS_G2P_MANY_PASS_MIN;
-template <int D, int MODEL, bool PLASTIC, int CMODE, int NPASS = 1, bool SHARD = false>
+// BIN: the launch can also bin its output for the next substep (g2p_body.inc, Dev::bin_next; single-domain data). A template parameter:
+// the binning is some 350 instructions per body, and the plastic paired kernel — 8 000 instructions, beyond the instruction cache —
+// runs a third slower with them compiled in whether they execute or not (C3: fused G2P 320 -> 425 us); those variants leave the
+// binning to launch 1 of the sort (capi.hip).
+template <int D, int MODEL, bool PLASTIC, int CMODE, int NPASS = 1, bool SHARD = false, bool BIN = false>
 __global__ __launch_bounds__(G2P_THREADS, G2P_WAVES_PER_EU) void k_g2p_update(Dev d, int side, uint32_t epoch) {
     constexpr uint32_t npass = NPASS;  // (a template parameter: as a kernel argument the second pass's registers spilled in the one-pass launch)
     __shared__ float4 s_node[Dim<D>::TILE];
@@ -563,7 +568,7 @@ __global__ __launch_bounds__(G2P_THREADS, G2P_WAVES_PER_EU) void k_g2p_update(De
 // (With the list half as it was in the middle of round 2 — chunk lanes on XCDs, 27-term stencil for every particle —
 // a third of the blocks listed was already enough: 4 M sand between walls 16 % faster; since the visit lists and the
 // per-particle choice of the stencil that scene is 4.5 % faster with 3: 362-371 -> 346-351 us.)
-template <int D, int MODEL, bool PLASTIC, int WPE = G2P_WAVES_PER_EU, int NPASS = 1, bool SHARD = false>
+template <int D, int MODEL, bool PLASTIC, int WPE = G2P_WAVES_PER_EU, int NPASS = 1, bool SHARD = false, bool BIN = false>
 __global__ __launch_bounds__(G2P_THREADS, WPE) void k_g2p_pair(Dev d, int side, uint32_t epoch, uint32_t nmain, uint32_t nlist) {
     constexpr uint32_t npass = NPASS;
     __shared__ float4 s_node[Dim<D>::TILE];
@@ -592,5 +597,6 @@ __global__ __launch_bounds__(G2P_THREADS, WPE) void k_g2p_pair(Dev d, int side, 
     }
 }
 #undef G2P_DONE
+#undef G2P_BIN
 
 }  // namespace wgs
