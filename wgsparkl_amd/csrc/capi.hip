@@ -1076,7 +1076,10 @@ static wgs_status create_impl(wgs_pipeline *pipeline, const wgs_sim_params *para
     // spill-free variant of the plastic G2P pair, 32768 = never the small register budget of the one-way P2G pair,
     // 65536 = never the uniform-material mode (the per-particle constants always travel with the particle), 131072 = the
     // fused G2P always with two chunks per wave (the large-scene launch shape), 262144 = the grid update as a launch of its
-    // own also where it could ride in the P2G launch, 524288 = integrate_bodies as a launch of its own at the tail of every substep.
+    // own also where it could ride in the P2G launch, 524288 = integrate_bodies as a launch of its own at the tail of every substep,
+    // 1048576 = launch 1 of the sort (k_rebin) every substep instead of the binning inside the fused G2P, 4194304 = P2G of a
+    // lockstep slab split into its boundary layers and the rest (the shape wgs_sharded_step uses when it forks), 8388608 =
+    // wgs_sharded_step forks the exchange onto a second stream beside the interior's P2G (measured slower here: capi_sharded.inc).
     // The ablations that change the RESULTS (64 = G2P moves bytes only, 256 = P2G without its accumulation loop,
     // 512 = P2G without its particle loads) exist only in builds with -DWGS_ABLATE; the shipped library ignores them.
     dev.dbg = getenv("WGS_DEBUG") ? (uint32_t)strtoul(getenv("WGS_DEBUG"), nullptr, 0) : 0u;
