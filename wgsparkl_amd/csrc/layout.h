@@ -320,7 +320,12 @@ template <int D> struct SlabTileMap {
 };
 __constant__ SlabTileMap<WGS_DIM> g_slab_tile_map = SlabTileMap<WGS_DIM>();
 
-// P2G's per-wave accumulation tile in LDS (p2g_body.inc): NOT x + TW y + TW^2 z. In each of the nine (sx, sy) phases lane = cell
+// P2G's per-wave accumulation tile in LDS (p2g_body.inc). The shipped layout is the linear one, x + TW y + TW^2 z; the swizzled
+// one below is an option (-DWGS_P2G_SWIZZLE_TILE), measured in round 4 and not kept: it takes the bank conflicts of the nine-phase
+// read-add-write from 1.85 M cycles per launch to 0.10 M (3.0 -> 0.16 per LDS instruction, SQ_LDS_BANK_CONFLICT at C2) and makes
+// the launch 1-2 % SLOWER (C2 38.2 -> 38.7, C3 180 -> 184, C5 400 -> 406 us on one box): the five integer instructions per
+// phase that place a node cost more than the conflicts did — the LDS was never what this kernel waits for.
+// The swizzled layout: in each of the nine (sx, sy) phases lane = cell
 // (lx + BW ly + BW^2 lz) reads, adds to and writes back the float4 of node (lx + sx, ly + sy, lz + sz), and with the linear
 // layout the 16-lane groups of ds_read_b128 ({0-3, 12-15, 20-27}, ...: MI355X_MICROARCH.md, LDS) land three deep on the same
 // 16-byte slots (x + 6 y mod 16 for y = 0, 3 and two rows of the next z layer), the 8-lane groups of ds_write_b128 two deep:
@@ -331,7 +336,7 @@ __constant__ SlabTileMap<WGS_DIM> g_slab_tile_map = SlabTileMap<WGS_DIM>();
 // (BW / 2 + 1)^2-ish more LDS: 384 float4 per wave instead of 216 (3D), 256 instead of 100 (2D).
 template <int D> struct TileSwz {
     static constexpr int BW = Dim<D>::BW, BS = Dim<D>::BSHIFT, TW = Dim<D>::TW;
-#ifdef WGS_P2G_LINEAR_TILE   // (A/B builds only: the layout of rounds 1-3, x + TW y + TW^2 z)
+#ifndef WGS_P2G_SWIZZLE_TILE   // (the shipped layout: x + TW y + TW^2 z)
     static constexpr int SIZE = Dim<D>::TILE;
     __host__ __device__ static constexpr int fx(int x) { return x; }
     __host__ __device__ static constexpr int fy(int y) { return TW * y; }
