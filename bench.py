@@ -3,7 +3,8 @@
 
 Default workload (BASELINE.json configs[1]): wgsparkl3d neo-Hookean elastic cube, 100^3 = 1M
 particles (8 per cell) in a 128^3-cell domain, floor cuboid, fp32, synthetic lattice + jitter. One "step" = one
-substep of MpmPipeline::queue_step (sort -> P2G -> grid update -> fused G2P + particle update), inputs resident in HBM.
+substep of MpmPipeline::queue_step (sort -> P2G -> grid update -> fused G2P + particle update; three launches on a single
+domain: the grid update rides in the P2G launch and the fused G2P bins its output for the next sort), inputs resident in HBM.
 
   python bench.py --gpus N --steps K --warmup W [--config c2|c3|c4|c5] [--scaling weak|strong]
 
@@ -17,7 +18,10 @@ anything is timed the decomposition validates itself against a single-domain run
 mismatch). --scaling weak (default): N
 copies of the config side by side along x (fixed work per GPU); strong: the named size cut into N slabs (north_star's
 16M target: --config c5 --scaling strong). Without flags, the line also carries `extra` legs: the same cube after it
-landed on the floor, c3, the reference's own sand3 scene (202 k particles) and c5 (strong over the N GPUs), each with its own G2P roofline figure.
+landed on the floor, c3, the reference's own sand3 (202 k particles) and sand2 (490 k, 2D) scenes, c2_stirred (the cube
+crossing the grid and spinning: > 10 % of its particles change cell per substep), c2_frames (20 substeps per wgs_step call
+with the pose read-back between calls) and c5 (strong over the N GPUs), each with its pass times, its own G2P roofline figure
+and `mover_fraction` (particles that changed cell per substep, counted on the device).
 `python bench.py --gpus N` outside a launcher starts the N ranks itself (torch.distributed.run as a child process).
 """
 import argparse
@@ -33,7 +37,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable)
-KERNEL_ELASTIC = "k_g2p_pair (fused G2P + particle update; collider simulations run both bodies in this launch)"
+KERNEL_ELASTIC = "k_g2p_pair (fused G2P + particle update + binning for the next sort; collider simulations run both bodies in this launch)"
 
 
 def parse_args():
@@ -45,7 +49,7 @@ def parse_args():
     ap.add_argument("--scaling", choices=("weak", "strong"), default="weak")
     ap.add_argument("--n-side", type=int, default=None, help="particles per cube edge (c2: 100 -> 1M, the named config)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-extra", action="store_true", help="skip the extra legs (landed cube, c3, c5)")
+    ap.add_argument("--no-extra", action="store_true", help="skip the extra legs (landed cube, c3, sand3, sand2, stirred, frames, c5)")
     ap.add_argument("--no-floor", action="store_true", help="c2 without the floor cuboid of SURVEY 8d (no CPIC passes)")
     ap.add_argument("--no-live-pmc", action="store_true", help="roofline.traffic from the committed rocprofv3 passes instead of two child runs under rocprofv3 --pmc")
     ap.add_argument("--allow-debug-switches", action="store_true", help="run although WGS_DEBUG is set (A/B of launch shapes)")
@@ -131,7 +135,7 @@ def live_pmc_traffic():
 def g2p_roofline(timings, k_ts, mark_ms, n, n_nodes, bytes_per_particle, kernel):
     # One launch between the two marks of the "g2p" pass: the event interval IS the duration rocprofv3 reports for the
     # kernel (profiles/rNN_kernel_stats.csv; both contain the launch's dispatch gap, and the rocprofv3 durations of the
-    # four launches of a substep add up to the un-instrumented wall time per substep). Two marks recorded back to back
+    # launches of a substep add up to the un-instrumented wall time per substep). Two marks recorded back to back
     # are 3.5 us apart (event_mark_ms, informational): that spacing is what an EMPTY pass costs the instrumented run, it
     # is not a cost inside an interval that holds a kernel — earlier rounds subtracted it and overstated the rate by 10 %.
     interval = timings["g2p"] / k_ts
@@ -415,9 +419,10 @@ def main():
             "pass_ms_per_step": main_res["pass_ms_per_step"],
             "build": {"info": build_info, "WGS_DEBUG": dbg_env, "transport_note": transport_note},
             "validation_sharded": validation_sharded,
-            "notes": "the hash table of block ids is rebuilt (k_bin instead of k_rebin, ~+0.25 ms once at this size) on the first substep, every "
+            "notes": "the hash table of block ids is rebuilt (a k_bin launch in front of the sort, ~+0.25 ms once at this size) on the first substep, every "
                      "1024 substeps and whenever three quarters of the ids are handed out; none of these falls inside this timed region. "
-                     "pass_ms_per_step: on single-domain data the grid update runs as workgroups of the P2G launch (DESIGN.md 4): 'p2g' holds both, "
+                     "pass_ms_per_step: on single-domain data the grid update runs as workgroups of the P2G launch and the fused G2P bins its output for the "
+                     "next substep's sort (DESIGN.md 4): 'p2g' holds P2G + grid update, 'g2p' holds the binning, 'grid sort' is the one regroup launch, "
                      "'grid_update' is then an empty interval between two event marks (~0.004 ms, like every pass without a launch)",
         }
 
