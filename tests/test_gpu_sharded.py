@@ -235,7 +235,13 @@ def test_sharded_substep_with_pack_and_interior_grid_update_inside_the_p2g_launc
     monkeypatch.setenv("WGS_DEBUG", "4194304")
     c = run()
     monkeypatch.delenv("WGS_DEBUG")
-    for other in (b, c):
+    # A slab's fused G2P bins its residents for the next substep (the guests it drops leave their block's total) and
+    # k_g2p_arrivals the particles that arrive (Dev::bin_next); WGS_DEBUG = 1048576 brings launch 1 of the sort, k_rebin, back:
+    # the same bits, the same storage order.
+    monkeypatch.setenv("WGS_DEBUG", "1048576")
+    e = run()
+    monkeypatch.delenv("WGS_DEBUG")
+    for other in (b, c, e):
         for x, y in zip(a, other):
             ox, oy = np.argsort(x["ids"]), np.argsort(y["ids"])    # (the storage order of a slab follows the arrival order of its guests)
             assert np.array_equal(x["ids"][ox], y["ids"][oy])

@@ -709,7 +709,7 @@ template <bool TS> wgs_status enqueue_substep(wgs_data *d, int ts_slot, int part
     // Single-domain data: the fused G2P of this substep also bins its output for the next one (g2p_body.inc, Dev::bin_next), unless
     // that substep rebuilds the table anyway (dbg bit 20 brings launch 1 of the sort, k_rebin, back: same results, tested).
     // `prebinned`: the previous substep's G2P did so for this one.
-    const bool binned = use_rebin && d->prebinned && part == 0;
+    const bool binned = use_rebin && d->prebinned;
     if (first && d->prebinned && !binned) {
         // (a table rebuild nobody could foresee — ids three quarters handed out, seen by the host in between: what the G2P
         // accumulated for the old ids is dropped; the stamps it left mean nothing once the ids are handed out anew)
@@ -720,7 +720,9 @@ template <bool TS> wgs_status enqueue_substep(wgs_data *d, int ts_slot, int part
     if (first) d->prebinned = false;
     // (not the plastic variants: their fused G2P is compiled without the binning — kernels_transfer.h: the code alone, beyond the
     // instruction cache, cost a third of the launch — and launch 1 of the sort, k_rebin, stays)
-    dev.bin_next = (part == 0 && !dev.sharded && !d->plastic && !(dev.dbg & (128u | 1048576u)) && (d->substeps + 1) % d->rehash_period != 0) ? 1u : 0u;
+    // (a slab: its fused G2P bins the residents — the guests it drops leave their block's total —, k_g2p_arrivals the particles that
+    // arrive; both parts of a sharded substep see the same value)
+    dev.bin_next = (!d->plastic && !(dev.dbg & (128u | 1048576u)) && (d->substeps + 1) % d->rehash_period != 0) ? 1u : 0u;
     // the fused G2P drops the guests only inside the sharded step (kernels_shard.h); wgs_step on a slab advances what it holds
     dev.skip_guests = (d->in_sharded_step && dev.sharded) ? 1u : 0u;
     if (dev.sharded && d->needs_compact && first) {

@@ -81,6 +81,22 @@ __device__ inline uint32_t hmap_find(const Dev &d, uint32_t key, uint32_t epoch)
     return NONE;
 }
 
+// ... for a reader BEHIND the fused G2P of the substep: that launch stamps the blocks of the next substep while it bins its output
+// (Dev::bin_next), so "active in this substep" is read from the note launch 2 of this substep's sort left (links_epoch)
+__device__ inline uint32_t hmap_find_sorted(const Dev &d, uint32_t key, uint32_t epoch) {
+    uint32_t slot = hash_key(key) & d.hmask;
+    for (uint32_t probe = 0; probe <= d.hmask; ++probe) {
+        const uint32_t st = d.hkeys[slot];
+        if (st == key) {
+            const uint32_t id = d.hvals[slot];
+            return (id < d.cap && d.links_epoch[id] == epoch) ? id : NONE;
+        }
+        if (st == NONE) return NONE;
+        slot = (slot + 1u) & d.hmask;
+    }
+    return NONE;
+}
+
 // the block's physical id whether it is active or not (NONE: not in the table)
 // One visit-list entry per chunk of 64 sorted particles that holds particles of the listed block `id` (its run in the
 // sorted order is [start, start + count), count > 0). Called by one whole wave. Consecutive groups of g2p_npass chunks

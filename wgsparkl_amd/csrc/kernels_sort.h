@@ -494,10 +494,10 @@ __device__ __forceinline__ uint32_t regroup_block(const Dev &d, int side, uint32
     } else {
         a_ent = NONE;
     }
-    // Every particle of the previous run is still in its cell (nobody flagged the block for this substep; a slab cannot
-    // tell: a slot vacated by a migrated particle is not flagged by anybody it belongs to): the runs only move, nothing
+    // Every particle of the previous run is still in its cell (nobody flagged the block for this substep; on a slab a slot
+    // vacated by a migrated particle flags its block like a particle that changed cell): the runs only move, nothing
     // of the run has to be looked at — unless particles arrive, whose ids are merged with the stayers'.
-    const bool clean = !SHARD && dirty_at != epoch;
+    const bool clean = dirty_at != epoch;
     const bool need_ids = !clean || any_arr;
     // The block's new run is built by the whole wave at once (below: a counting sort by new cell, then every cell orders its own
     // few particles by id) when something changed, the previous run and what arrives fit the LDS stages, and nobody is on a

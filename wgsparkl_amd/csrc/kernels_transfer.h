@@ -516,7 +516,7 @@ __device__ unsigned long long g_g2p_prof[WGS_G2P_ROWS][8];
 // chunks a block spans, and only that block's particles are processed; the launch is nearly free while no
 // particle is near a collider.
 #define G2P_DONE continue;
-#define G2P_BIN (BIN && !SHARD)
+#define G2P_BIN BIN
 // Chunks of 64 sorted particles per wave of the main body (template parameter NPASS, g2p_body.inc): 1 while the two particle
 // buffers fit the 256 MB Infinity Cache (the launch then runs at HBM-roofline speed for its real traffic and a longer
 // wave life only costs), 2 beyond — there the kernel is bound by latency x occupancy and twice the bytes in flight per
