@@ -706,7 +706,7 @@ template <bool TS> wgs_status enqueue_substep(wgs_data *d, int ts_slot, int part
     const bool fused_cdf = d->cpic && dev.n_rigid == 0 && !(dev.dbg & 1024u);  // (mesh cdfs are only complete after k_p2g_cdf)
     if (first) dev.listed_in_perm = fused_cdf ? 1u : 0u;  // (part 2 of a sharded substep consumes what its part 1 wrote)
     const bool use_rebin = d->prev_sorted && !rehash && !(dev.dbg & 128u);
-    // Single-domain data: the fused G2P of this substep also bins its output for the next one (g2p_body.inc, Dev::bin_next), unless
+    // The fused G2P of this substep also bins its output for the next one (g2p_body.inc, Dev::bin_next; slabs too), unless
     // that substep rebuilds the table anyway (dbg bit 20 brings launch 1 of the sort, k_rebin, back: same results, tested).
     // `prebinned`: the previous substep's G2P did so for this one.
     const bool binned = use_rebin && d->prebinned;

@@ -3,8 +3,9 @@
 // the inbound messages instead of the sorted buffer: no block tile, no sort entry — every (arrival, stencil node) pair
 // looks its node up (the block's velocity if the block is active here, else the neighbour's partial sum from the
 // message, which is then the node's total), the arrival is advanced from those 3^D values and written BEHIND the
-// sorted output of the fused G2P, in slots [NPREV, N), where launch 1 of the next substep's sort (k_rebin, or k_bin on a table
-// rebuild) bins it through the hash path like a particle that changed block. A launch of its own behind the fused G2P (capi.hip);
+// sorted output of the fused G2P, in slots [NPREV, N), and binned for the next substep's sort through the hash path like a particle
+// that changed block — here (Dev::bin_next), or by launch 1 of that sort (k_rebin; k_bin on a table rebuild) when the fused G2P
+// does not bin. A launch of its own behind the fused G2P (capi.hip);
 // its last workgroup to finish does the bookkeeping of the migration round (the particle counters of the next substep).
 #pragma once
 #include "kernels_transfer.h"

@@ -221,8 +221,22 @@ template <int D, int NT> __device__ __forceinline__ void stage_node_cdf_tile(con
 // from the node cdfs of its block's tile (LDS image s_cdf, tile origin = block coordinates bc). Writes the
 // particle's cdf quads and stamps them with the substep.
 // AGENT: the quads are written through (agent scope) — a P2G launch whose pack waves copy a guest's record in the same launch
-template <int D, bool AGENT = false> __device__ inline void particle_cdf_update(const Dev &d, float *buf, uint32_t src, const NodeCdf *s_cdf, const int *bc,
-                                                            uint32_t epoch) {
+// What particle_cdf_update needs of the particle, fetched apart from it: a caller with several particles per thread requests them
+// all before it computes the first (the prologue of the CPIC P2G: one pair of dependent round trips per batch instead of one per particle)
+struct ParticleCdfIn {
+    float4 xm;
+    uint32_t prev_aff, stamp;
+};
+template <int D> __device__ __forceinline__ ParticleCdfIn particle_cdf_fetch(const Dev &d, const float *buf, uint32_t src) {
+    using P = Pl<D>;
+    ParticleCdfIn in;
+    in.xm = ldq(buf, d.npad, P::XM, src);
+    in.prev_aff = __float_as_uint(ldq(buf, d.npad, D == 3 ? (int)P::CDF1 : (int)P::CDF0, src).w);
+    in.stamp = ldstamp<D>(buf, d.npad, src);
+    return in;
+}
+template <int D, bool AGENT = false> __device__ inline void particle_cdf_update(const Dev &d, float *buf, uint32_t src, const ParticleCdfIn &pin, const NodeCdf *s_cdf,
+                                                            const int *bc, uint32_t epoch) {
     constexpr int BW = Dim<D>::BW, TW = Dim<D>::TW;
     constexpr int N = D + 1;
     using P = Pl<D>;
@@ -234,10 +248,9 @@ template <int D, bool AGENT = false> __device__ inline void particle_cdf_update(
 #pragma unroll
     for (int k = 0; k < D; k++) nrm[k] = 0.f;
     if (any) {
-        const float4 xm = ldq(buf, npad, P::XM, src);
-        const float4 cprev = ldq(buf, npad, D == 3 ? (int)P::CDF1 : (int)P::CDF0, src);
+        const float4 xm = pin.xm;
         // previous affinity (sign persistence, g2p_cdf.wgsl:183-190): only if computed last substep
-        const uint32_t prev = ldstamp<D>(buf, npad, src) == epoch - 1u ? __float_as_uint(cprev.w) : 0u;
+        const uint32_t prev = pin.stamp == epoch - 1u ? pin.prev_aff : 0u;
         float x[D], ref[D], w[D][3];
         x[0] = xm.x; x[1] = xm.y;
         if constexpr (D == 3) x[2] = xm.z;

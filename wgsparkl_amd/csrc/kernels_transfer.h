@@ -536,7 +536,7 @@ constexpr uint32_t G2P_TWO_PASS_MIN_PARTICLES = WGS_G2P_TWO_PASS_MIN;
 #endif
 constexpr int G2P_MANY_PASSES = WGS_G2P_MANY_PASSES;
 constexpr uint32_t G2P_MANY_PASS_MIN_PARTICLES = WGS_G2P_MANY_PASS_MIN;
-// BIN: the launch can also bin its output for the next substep (g2p_body.inc, Dev::bin_next; single-domain data). A template parameter:
+// BIN: the launch can also bin its output for the next substep (g2p_body.inc, Dev::bin_next; on a slab the arrivals are binned by k_g2p_arrivals). A template parameter:
 // the binning is some 350 instructions per body, and the plastic paired kernel — 8 000 instructions, beyond the instruction cache —
 // runs a third slower with them compiled in whether they execute or not (C3: fused G2P 320 -> 425 us); those variants leave the
 // binning to launch 1 of the sort (capi.hip).

@@ -220,8 +220,9 @@ struct Dev {
     uint32_t cdf_moving;      // bit i: collider i has (or had) a velocity or a mass: its pose changes from substep to substep
     uint32_t listed_in_perm;  // this substep's perm_cell entries carry CELL_LISTED (launch 2 of the sort computed the block classes)
     uint32_t g2p_npass;       // chunks per wave of the fused G2P of this substep (defines the eighths; set by the host per substep)
-    uint32_t bin_next;        // single-domain data: the fused G2P of this substep also BINS its output for the next substep (new cell ids,
-                              // block activation and totals, mover lists — launch 1 of the next sort, k_rebin, is then not launched)
+    uint32_t bin_next;        // the fused G2P of this substep also BINS its output for the next substep (new cell ids, block activation and
+                              // totals, mover lists — launch 1 of the next sort, k_rebin, is then not launched); on a slab k_g2p_arrivals
+                              // does the same for the particles that arrive. Not the plastic variants (kernels_transfer.h BIN)
     uint32_t *counters;    // CTR_COUNT
     const SimParamsDev *sp;
     ColliderDev *colliders;  // poses / velocities are integrated on the device (kernels_bodies.h)
