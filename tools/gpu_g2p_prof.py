@@ -6,6 +6,12 @@ from helpers import pipeline
 from wgsparkl_amd import MpmData, scenes
 if len(sys.argv) > 1 and sys.argv[1] in ("c2", "c3", "c5"):
     sc = scenes.config_scene(sys.argv[1], n_side=int(sys.argv[2]) if len(sys.argv) > 2 else None)
+elif len(sys.argv) > 1 and sys.argv[1] == "stirred":      # bench.py's c2_stirred leg: > 10 % of the particles change cell per substep
+    sc = scenes.neo_hookean_cube(n_side=100, with_floor=True)
+    rel = sc["particles"].pos - sc["particles"].pos.mean(0)
+    sc["particles"].vel[:, 0] = 48.0 + 1.5 * rel[:, 2]
+    sc["particles"].vel[:, 1] = 48.0
+    sc["particles"].vel[:, 2] = 48.0 - 1.5 * rel[:, 0]
 else:
     n_side = int(sys.argv[1]) if len(sys.argv) > 1 else 100
     sc = scenes.neo_hookean_cube(n_side=n_side, with_floor=True)

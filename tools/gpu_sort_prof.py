@@ -12,6 +12,10 @@ elif len(sys.argv) > 1 and sys.argv[1] == "stirred":      # bench.py's c2_stirre
     sc["particles"].vel[:, 0] = 48.0 + 1.5 * rel[:, 2]
     sc["particles"].vel[:, 1] = 48.0
     sc["particles"].vel[:, 2] = 48.0 - 1.5 * rel[:, 0]
+elif len(sys.argv) > 1 and sys.argv[1] == "landed":       # bench.py's c2_landed leg
+    sc = scenes.neo_hookean_cube(n_side=100, with_floor=True)
+    sc["particles"].pos[:, 1] -= 5.7
+    sc["particles"].vel[:, 1] = -3.0
 elif len(sys.argv) > 1 and sys.argv[1] in ("c2", "c3", "c5"):
     sc = scenes.config_scene(sys.argv[1])
 else:
@@ -21,7 +25,7 @@ pipe = pipeline(3)
 data = MpmData.new(pipe, sc["params"], sc["particles"], sc["colliders"], sc["cell_width"], sc["grid_capacity"], sc["model"])
 ROWS = 8192
 buf = (C.c_ulonglong * (ROWS * 8))()
-pipe.step(data, 20); data.sync()
+pipe.step(data, 200 if len(sys.argv) > 1 and sys.argv[1] == 'landed' else 20); data.sync()
 names = ["links", "staged", "pass1", "cdf", "pass2", "bstart", "end"]
 for rep in range(2):
     pipe.lib.wgs_debug_prof(buf)          # reset

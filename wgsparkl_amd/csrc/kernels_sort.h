@@ -502,16 +502,40 @@ __device__ __forceinline__ uint32_t regroup_block(const Dev &d, int side, uint32
     // The block's new run is built by the whole wave at once (below: a counting sort by new cell, then every cell orders its own
     // few particles by id) when something changed, the previous run and what arrives fit the LDS stages, and nobody is on a
     // cell's list (lists: table-rebuild substeps, and arrivals beyond a block's array); lane by lane, cell by cell, otherwise.
-    uint32_t n_moved = 0u;   // (wave-uniform) statistics: particles of this block's new run that changed cell
+    uint32_t n_moved = 0u;   // (per lane, summed at the end) statistics: particles of this block's new run that changed cell
     const bool par = old_ok && need_ids && in_lds && __ballot(head != 0u) == 0ull && runlen + narr_in <= (uint32_t)RUNCAP;   // (wave-uniform)
-    if (in_lds && (!clean || par))
-        for (uint32_t t = lane; t < runlen; t += 64) {
-            const uint32_t e = d.cellid[run0 + t];
-            s_in[t] = cell_of(e);
-            n_moved += (uint32_t)__popcll(__ballot(e != NONE && (e & CELL_MOVED) != 0u && (cell_of(e) >> 6) == id));   // (came from another cell of this block)
+    // (two batches of PAR_R / 2 rounds, every load of a batch in flight before the first LDS store: a round at a time — one wait per
+    // round — the staging of a full block was six to eight dependent round trips, 5 us of a dirty block's 16)
+    constexpr int PAR_R = (RUNCAP + 63) / 64;
+    if (in_lds && need_ids) {
+        const bool want_cells = !clean || par;   // (wave-uniform)
+#pragma unroll
+        for (int half = 0; half < 2; half++) {
+            if (half == 1 && runlen <= 64u * (uint32_t)(PAR_R / 2)) break;
+            uint32_t ce[PAR_R / 2], pe[PAR_R / 2];
+#pragma unroll
+            for (int r = 0; r < PAR_R / 2; r++) {
+                const uint32_t t = (uint32_t)lane + 64u * (uint32_t)(half * (PAR_R / 2) + r);
+                ce[r] = NONE;
+                pe[r] = 0u;
+                if (t < runlen) {
+                    if (want_cells) ce[r] = d.cellid[run0 + t];
+                    pe[r] = ldpid<D>(in, d.npad, run0 + t);
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < PAR_R / 2; r++) {
+                const uint32_t t = (uint32_t)lane + 64u * (uint32_t)(half * (PAR_R / 2) + r);
+                if (t < runlen) {
+                    if (want_cells) {
+                        s_in[t] = ce[r];   // (the raw entry: bit 31 tells the wave-parallel form below who changed cell)
+                        n_moved += (ce[r] != NONE && (ce[r] & CELL_MOVED) != 0u && (cell_of(ce[r]) >> 6) == id) ? 1u : 0u;   // (came from another cell of this block)
+                    }
+                    s_pid[t] = pe[r];
+                }
+            }
         }
-    if (in_lds && need_ids)
-        for (uint32_t t = lane; t < runlen; t += 64) s_pid[t] = ldpid<D>(in, d.npad, run0 + t);
+    }
     // ---- neighbour links (replaces the per-thread hash lookups of p2g.wgsl:238-275 / g2p.wgsl:72-132)
     uint32_t res = NONE;
     int b[3] = {0, 0, 0};
@@ -540,7 +564,7 @@ __device__ __forceinline__ uint32_t regroup_block(const Dev &d, int side, uint32
     // (single wave: LDS accesses of a wave execute in order, the relaxed wavefront-scope atomics below keep the
     // compiler from reordering or forwarding across lanes)
     auto new_cell_of = [&](uint32_t i) {
-        return in_lds ? __hip_atomic_load(&s_in[i - run0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT) : cell_of(d.cellid[i]);
+        return cell_of(in_lds ? __hip_atomic_load(&s_in[i - run0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT) : d.cellid[i]);
     };
     // (a particle of this cell's previous run that is still in the cell)
     auto stays_here = [&](uint32_t i) { return clean || new_cell_of(i) == idx; };
@@ -639,27 +663,36 @@ __device__ __forceinline__ uint32_t regroup_block(const Dev &d, int side, uint32
     uint32_t n_stay = ce_old - cs_old, n_arr = 0, n_in = 0;
     // -- the wave-parallel form: lane = entry of the previous run (strided). Every particle that names a cell of this block takes a
     // place in that cell (an LDS counter per cell: the order of arrival is arbitrary, the ids are put in order further down).
-    constexpr int PAR_R = (RUNCAP + 63) / 64;
     static_assert(PAR_R % 2 == 0 && RUNCAP <= 1023, "two 16-bit (cell | place << 6) per register; 0xffff = none");
     uint32_t ckp[PAR_R / 2];  // per entry t = lane + 64 r: new cell | place in it << 6 in half r & 1 of word r / 2, 0xffff = not this block's
     uint32_t a_ck = NONE;     // ... of the lane's entry of the array of arrivals from other blocks
-    uint32_t *s_cnt = s_out + RUNCAP - 64;   // (the output stage is not written before the counters are consumed)
+    // (two counters per cell: the particles that did NOT change cell — they come in the order of the cell's previous run, ascending ids —
+    // take the first places, the others the places behind them: the ordering pass below then only has the newcomers to move)
+    uint32_t *s_cnt = s_out + RUNCAP - 64, *s_cnt2 = s_out + RUNCAP - 128;   // (the output stage is not written before the counters are consumed)
+    uint32_t par_new = 0u;    // bit r: entry lane + 64 r changed cell (its place counts from behind the stayers of its new cell)
+    uint32_t par_nst = 0u;    // lane = cell: members of the new run that stayed
     if (par) {
         __hip_atomic_store(&s_cnt[lane], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+        __hip_atomic_store(&s_cnt2[lane], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
 #pragma unroll
         for (int r = 0; r < PAR_R; r++) {
             const uint32_t t = (uint32_t)lane + 64u * (uint32_t)r;
             uint32_t ck = 0xffffu;
             if (t < runlen) {
-                const uint32_t c = __hip_atomic_load(&s_in[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-                if ((c >> 6) == id)   // (NONE, a particle left out of the sort, is nobody's)
-                    ck = (c & 63u) | (__hip_atomic_fetch_add(&s_cnt[c & 63u], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT) << 6);
+                const uint32_t e = __hip_atomic_load(&s_in[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                const uint32_t c = cell_of(e);
+                if ((c >> 6) == id) {   // (NONE, a particle left out of the sort, is nobody's)
+                    const bool came = (e & CELL_MOVED) != 0u;
+                    ck = (c & 63u) | (__hip_atomic_fetch_add(came ? &s_cnt2[c & 63u] : &s_cnt[c & 63u], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT) << 6);
+                    par_new |= came ? (1u << r) : 0u;
+                }
             }
             if (r & 1) ckp[r / 2] |= ck << 16;
             else ckp[r / 2] = ck;
         }
-        if (a_cell != NONE) a_ck = (a_cell & 63u) | (__hip_atomic_fetch_add(&s_cnt[a_cell & 63u], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT) << 6);
-        n_stay = __hip_atomic_load(&s_cnt[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);   // (all members of the cell's new run)
+        if (a_cell != NONE) a_ck = (a_cell & 63u) | (__hip_atomic_fetch_add(&s_cnt2[a_cell & 63u], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT) << 6);
+        par_nst = __hip_atomic_load(&s_cnt[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+        n_stay = par_nst + __hip_atomic_load(&s_cnt2[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);   // (all members of the cell's new run)
         n_arr = 0;
     } else {
         static_assert(RUNCAP >= 64 + 2 * 64 * ARRC, "the hand-over arrays alias the output stage");
@@ -738,11 +771,12 @@ __device__ __forceinline__ uint32_t regroup_block(const Dev &d, int side, uint32
         if (out_lds) fetch_bstart();
         keep_perm = bstart == bstart_old && ident == (((epoch - 1u) << 1) | (pc_flag != 0u ? 1u : 0u));
     }
-    uint32_t *s_lst = s_in, *s_av = s_in + 64;   // (wave-parallel form: the staged cell ids are consumed by now)
+    uint32_t *s_lst = s_in, *s_av = s_in + 64, *s_new = s_in + 128;   // (wave-parallel form: the staged cell ids are consumed by now)
     if (par) {
-        // (places) the cell's start + the place taken in it; an entry of the output stage = cell << 26 | index v into the ids:
-        // v < runlen: entry v of the previous run, else entry v - runlen of the array of arrivals
+        // (places) the cell's start + the place taken in it — behind the cell's stayers for a newcomer; an entry of the output stage =
+        // cell << 26 | index v into the ids: v < runlen: entry v of the previous run, else entry v - runlen of the array of arrivals
         __hip_atomic_store(&s_lst[lane], lstart, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+        __hip_atomic_store(&s_new[lane], lstart + par_nst, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
         if (a_ck != NONE) {
             __hip_atomic_store(&s_av[lane], a_ent, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
             __hip_atomic_store(&s_pid[runlen + (uint32_t)lane], a_epid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
@@ -751,19 +785,31 @@ __device__ __forceinline__ uint32_t regroup_block(const Dev &d, int side, uint32
         for (int r = 0; r < PAR_R; r++) {
             const uint32_t ck = (ckp[r / 2] >> (16 * (r & 1))) & 0xffffu;
             if (ck != 0xffffu) {
-                const uint32_t pos = __hip_atomic_load(&s_lst[ck & 63u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT) + (ck >> 6);
+                const uint32_t pos = __hip_atomic_load(((par_new >> r) & 1u) ? &s_new[ck & 63u] : &s_lst[ck & 63u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT) + (ck >> 6);
                 __hip_atomic_store(&s_out[pos], ((ck & 63u) << 26) | ((uint32_t)lane + 64u * (uint32_t)r), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
             }
         }
         if (a_ck != NONE) {
-            const uint32_t pos = __hip_atomic_load(&s_lst[a_ck & 63u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT) + (a_ck >> 6);
+            const uint32_t pos = __hip_atomic_load(&s_new[a_ck & 63u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT) + (a_ck >> 6);
             __hip_atomic_store(&s_out[pos], ((a_ck & 63u) << 26) | (runlen + (uint32_t)lane), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
         }
-        // (order) lane = cell: its members by ascending (id, v) — an insertion sort over a handful of entries that are nearly in
-        // order already (the stayers took their places in the order of the previous run)
+        // (order) lane = cell: its members by ascending (id, v) — an insertion sort that is correct for any order of the places and
+        // cheap for the one they are taken in: the stayers first, in the order of the previous run (ascending ids: one comparison
+        // each, against the key of the member before, kept in registers), then the few newcomers, each moved down to its place
+        uint32_t kprev = 0u, vprev = 0u;
+        if (total > 1u) {
+            vprev = __hip_atomic_load(&s_out[lstart], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT) & 0x03ffffffu;
+            kprev = __hip_atomic_load(&s_pid[vprev], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+        }
         for (uint32_t m = 1; m < total; m++) {
             const uint32_t e = __hip_atomic_load(&s_out[lstart + m], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
             const uint32_t ve = e & 0x03ffffffu, ke = __hip_atomic_load(&s_pid[ve], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+            if (kprev < ke || (kprev == ke && vprev < ve)) {   // in order behind the member before it (which stays the last one so far)
+                kprev = ke;
+                vprev = ve;
+                continue;
+            }
+            // (moved down: the member before it ends up at place m, so the key kept in the registers is still that of the last place)
             uint32_t j = m;
             while (j > 0u) {
                 const uint32_t q = __hip_atomic_load(&s_out[lstart + j - 1u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
@@ -953,7 +999,10 @@ __device__ __forceinline__ uint32_t regroup_block(const Dev &d, int side, uint32
     uint32_t movers = 0u;
     if (have_old) {   // (every particle is an arrival on a table-rebuild substep)
         if (par) {
-            movers = (uint32_t)__builtin_amdgcn_readfirstlane((int)n_moved) + narr_in;   // (lane 0 ran every round of the staging loop)
+            movers = n_moved;
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) movers += __shfl_xor(movers, off);
+            movers += narr_in;
         } else {
             movers = n_arr;
 #pragma unroll
