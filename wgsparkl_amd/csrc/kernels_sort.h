@@ -793,15 +793,97 @@ __device__ __forceinline__ uint32_t regroup_block(const Dev &d, int side, uint32
             const uint32_t pos = __hip_atomic_load(&s_new[a_ck & 63u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT) + (a_ck >> 6);
             __hip_atomic_store(&s_out[pos], ((a_ck & 63u) << 26) | (runlen + (uint32_t)lane), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
         }
-        // (order) lane = cell: its members by ascending (id, v) — an insertion sort that is correct for any order of the places and
-        // cheap for the one they are taken in: the stayers first, in the order of the previous run (ascending ids: one comparison
-        // each, against the key of the member before, kept in registers), then the few newcomers, each moved down to its place
+        // (order) lane = cell: its members by ascending (id, v). The stayers hold the first places in the order of the previous run —
+        // ascending ids, checked in one pipelined pass —, the newcomers the places behind them. With up to NEWC newcomers (nearly
+        // every cell) those are sorted in registers, each finds its rank among the stayers by bisection (the searches of a lane
+        // advance together: their loads are independent), the stayers above the lowest rank move up by the number of newcomers
+        // below them, and the newcomers drop into the gaps: about a dozen dependent LDS accesses per cell, where inserting
+        // newcomer after newcomer cost the wave the longest insertion of its 64 cells at every step (the stirred cube: 10 of a dirty
+        // block's 26 us). Any other case — more newcomers, stayers not in order — takes the insertion sort below, which is correct
+        // for any order of the places.
+        constexpr int NEWC = 4;
+        constexpr uint32_t VM = 0x03ffffffu;
+        // (plain LDS accesses in this pass: a lane touches the range of its own cell only — what other lanes wrote there, they wrote with
+        // the atomic stores above, which a load of a possibly aliasing address is not moved across —, so the loads of a batch can
+        // be issued together)
+        auto lds = [&](const uint32_t *ptr) { return *ptr; };
+        bool ordered = true;
+        {
+            uint32_t pk = 0u, pv = 0u;
+#pragma unroll 4
+            for (uint32_t m = 0; m < par_nst; m++) {
+                const uint32_t v = lds(&s_out[lstart + m]) & VM, k = lds(&s_pid[v]);
+                ordered = ordered && (m == 0u || pk < k || (pk == k && pv < v));
+                pk = k;
+                pv = v;
+            }
+        }
+        const bool quick = ordered;
+        // (batches of NEWC newcomers: the members merged so far are the sorted prefix of the next batch)
+        for (uint32_t base = par_nst; quick && base < total; base += (uint32_t)NEWC) {
+            const uint32_t par_nst = base, n_new = min((uint32_t)NEWC, total - base);   // (this batch: `par_nst` sorted members, `n_new` newcomers)
+            uint32_t nk[NEWC], nv[NEWC], rk[NEWC];
+#pragma unroll
+            for (int k = 0; k < NEWC; k++) {
+                nk[k] = nv[k] = NONE;   // (empty entries sort last)
+                if ((uint32_t)k < n_new) {
+                    nv[k] = lds(&s_out[lstart + par_nst + (uint32_t)k]) & VM;
+                    nk[k] = lds(&s_pid[nv[k]]);
+                }
+            }
+#pragma unroll
+            for (int pass = 0; pass < NEWC; pass++)
+#pragma unroll
+                for (int k = pass & 1; k + 1 < NEWC; k += 2)
+                    if (nk[k] > nk[k + 1] || (nk[k] == nk[k + 1] && nv[k] > nv[k + 1])) {
+                        const uint32_t tk = nk[k], tv = nv[k];
+                        nk[k] = nk[k + 1]; nv[k] = nv[k + 1];
+                        nk[k + 1] = tk; nv[k + 1] = tv;
+                    }
+            // rank of each newcomer = number of stayers with a smaller key
+            uint32_t lo[NEWC], hi[NEWC];
+#pragma unroll
+            for (int k = 0; k < NEWC; k++) { lo[k] = 0u; hi[k] = (uint32_t)k < n_new ? par_nst : 0u; }
+            for (;;) {
+                bool more = false;
+                uint32_t mid[NEWC], mv[NEWC], mk[NEWC];
+#pragma unroll
+                for (int k = 0; k < NEWC; k++) {
+                    mid[k] = (lo[k] + hi[k]) >> 1;
+                    mv[k] = lo[k] < hi[k] ? (lds(&s_out[lstart + mid[k]]) & VM) : 0u;
+                }
+#pragma unroll
+                for (int k = 0; k < NEWC; k++) mk[k] = lo[k] < hi[k] ? lds(&s_pid[mv[k]]) : 0u;
+#pragma unroll
+                for (int k = 0; k < NEWC; k++)
+                    if (lo[k] < hi[k]) {
+                        if (mk[k] < nk[k] || (mk[k] == nk[k] && mv[k] < nv[k])) lo[k] = mid[k] + 1u;
+                        else hi[k] = mid[k];
+                        more = more || lo[k] < hi[k];
+                    }
+                if (!more) break;
+            }
+#pragma unroll
+            for (int k = 0; k < NEWC; k++) rk[k] = lo[k];
+            // the stayers from the top down to the lowest rank move up by the number of newcomers that rank at or below them
+            for (uint32_t t = par_nst; t > rk[0]; t--) {
+                const uint32_t at = t - 1u;
+                uint32_t up = 0u;
+#pragma unroll
+                for (int k = 0; k < NEWC; k++) up += ((uint32_t)k < n_new && rk[k] <= at) ? 1u : 0u;
+                s_out[lstart + at + up] = lds(&s_out[lstart + at]);
+            }
+#pragma unroll
+            for (int k = 0; k < NEWC; k++)
+                if ((uint32_t)k < n_new)
+                    s_out[lstart + rk[k] + (uint32_t)k] = ((uint32_t)lane << 26) | nv[k];
+        }
         uint32_t kprev = 0u, vprev = 0u;
-        if (total > 1u) {
+        if (!quick && total > 1u) {
             vprev = __hip_atomic_load(&s_out[lstart], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT) & 0x03ffffffu;
             kprev = __hip_atomic_load(&s_pid[vprev], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
         }
-        for (uint32_t m = 1; m < total; m++) {
+        for (uint32_t m = 1; m < (quick ? 0u : total); m++) {   // (the insertion sort: cells the quick form above does not cover)
             const uint32_t e = __hip_atomic_load(&s_out[lstart + m], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
             const uint32_t ve = e & 0x03ffffffu, ke = __hip_atomic_load(&s_pid[ve], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
             if (kprev < ke || (kprev == ke && vprev < ve)) {   // in order behind the member before it (which stays the last one so far)
