@@ -6,6 +6,10 @@ from helpers import pipeline
 from wgsparkl_amd import MpmData, scenes
 if len(sys.argv) > 1 and sys.argv[1] == "sand3":
     sc = scenes.reference_sand3()
+elif len(sys.argv) > 1 and sys.argv[1] == "landed":       # bench.py's c2_landed leg
+    sc = scenes.neo_hookean_cube(n_side=100, with_floor=True)
+    sc["particles"].pos[:, 1] -= 5.7
+    sc["particles"].vel[:, 1] = -3.0
 elif len(sys.argv) > 1 and sys.argv[1] in ("c2", "c3", "c5"):
     sc = scenes.config_scene(sys.argv[1], n_side=int(sys.argv[2]) if len(sys.argv) > 2 else None)
 else:
@@ -15,7 +19,7 @@ pipe = pipeline(3)
 data = MpmData.new(pipe, sc["params"], sc["particles"], sc["colliders"], sc["cell_width"], sc["grid_capacity"], sc["model"])
 ROWS = 8192
 buf = (C.c_ulonglong * (ROWS * 8))()
-pipe.step(data, 20); data.sync()
+pipe.step(data, 200 if len(sys.argv) > 1 and sys.argv[1] == 'landed' else 20); data.sync()
 names = ["meta (count, key, cell ranges)", "round-0 fetch issued", "round-0 in LDS", "accumulated", "slab stored"]
 for rep in range(2):
     pipe.lib.wgs_debug_p2g_prof(buf)
