@@ -818,7 +818,7 @@ __device__ __forceinline__ uint32_t regroup_block(const Dev &d, int side, uint32
                 pv = v;
             }
         }
-        const bool quick = ordered;
+        const bool quick = ordered && !(d.dbg & 16777216u);   // (WGS_DEBUG bit 24: the insertion sort below for every cell — same order, tested)
         // (batches of NEWC newcomers: the members merged so far are the sorted prefix of the next batch)
         for (uint32_t base = par_nst; quick && base < total; base += (uint32_t)NEWC) {
             const uint32_t par_nst = base, n_new = min((uint32_t)NEWC, total - base);   // (this batch: `par_nst` sorted members, `n_new` newcomers)
