@@ -607,17 +607,26 @@ __device__ __forceinline__ uint32_t regroup_block(const Dev &d, int side, uint32
         }
         return near;
     };
+    // A block WITHOUT particles (the rim of a body: active as somebody's "+" neighbour) is asked for its own 64 nodes only — they
+    // are the rim of its "-" neighbours' tiles; nobody asks for its class, which would depend on which of ITS "+" neighbours
+    // happen to be active —, and those too keep (the note then lacks CDF_FULL: the class is computed when particles arrive).
+    // (The rim blocks within reach of the floor were the slowest waves of this launch at C2: 10 us, every substep.)
+    constexpr uint32_t CDF_FULL = 0x80000000u;
     uint32_t near_moving = 0u;
-    bool cdf_cached = CDF && d.cdf_gen != 0u && bcount > 0u && cdf_seen == d.cdf_gen;
-    if (cdf_cached && d.cdf_moving != 0u) {
+    bool cdf_cached = CDF && d.cdf_gen != 0u && bcount > 0u && cdf_seen == (d.cdf_gen | CDF_FULL);
+    bool own_cached = CDF && d.cdf_gen != 0u && bcount == 0u && (cdf_seen & ~CDF_FULL) == d.cdf_gen;
+    if ((cdf_cached || own_cached) && d.cdf_moving != 0u) {
         near_moving = reach_mask(d.cdf_moving);
-        cdf_cached = near_moving == 0u;
+        cdf_cached = cdf_cached && near_moving == 0u;
+        own_cached = own_cached && near_moving == 0u;
     }
     if (cdf_cached) {
         const bool any = cdf_class != 0u;
         if (lane == 0 && any) d.cpic_list[(size_t)(id & 7u) * d.cap + atomicAdd(&d.counters[ctr_ncpic(id & 7u, epoch)], 1u)] = id;
         listed = any;
         pc_flag = any ? CELL_LISTED : 0u;
+    } else if (own_cached) {
+        // (nothing to do: its nodes are what they were, it holds no particle)
     } else if (CDF WGS_ABLATE_AND(!(d.dbg & (1u << 21)))) {
         constexpr int BW = Dim<D>::BW, BS = Dim<D>::BSHIFT, TW = Dim<D>::TW, TILE = Dim<D>::TILE;
         uint32_t mine = 0u;
@@ -626,6 +635,14 @@ __device__ __forceinline__ uint32_t regroup_block(const Dev &d, int side, uint32
             // no collider in reach of the tile (nearly every block): its own 64 nodes get the "far" cdf — lane = node —
             // and the rim, which belongs to the neighbours, is theirs to write
             d.node_cdf[(size_t)id * NPB + (uint32_t)lane] = NodeCdf{1.0e10f, 0u, NONE, 0u};
+        } else if (bcount == 0u) {   // (no particles: its own nodes, lane = node)
+            float pt[D];
+            int t[3] = {lane & (BW - 1), (lane >> BS) & (BW - 1), D == 3 ? (lane >> (2 * BS)) : 0};
+#pragma unroll
+            for (int k = 0; k < D; k++) pt[k] = (float)(b[k] * BW + t[k]) * d.h;
+            const NodeCdf c = node_cdf_eval<D>(d, pt, near);
+            d.node_cdf[(size_t)id * NPB + (uint32_t)lane] = c;
+            mine |= c.affinities;
         } else
         for (int n = lane; n < ((TILE + 63) / 64) * 64; n += 64) {
             int t[3] = {n % TW, (n / TW) % TW, D == 3 ? n / (TW * TW) : 0};
@@ -644,7 +661,7 @@ __device__ __forceinline__ uint32_t regroup_block(const Dev &d, int side, uint32
         if (lane == 0) {
             d.block_cpic[id] = any ? 1u : 0u;
             // (kept for the coming substeps only when no collider that moves is in reach)
-            if (d.cdf_gen != 0u && bcount > 0u) d.block_cdf_gen[id] = (near & d.cdf_moving) == 0u ? d.cdf_gen : 0u;
+            if (d.cdf_gen != 0u) d.block_cdf_gen[id] = (near & d.cdf_moving) == 0u ? (d.cdf_gen | (bcount > 0u ? CDF_FULL : 0u)) : 0u;
             if (any && bcount > 0u) d.cpic_list[(size_t)(id & 7u) * d.cap + atomicAdd(&d.counters[ctr_ncpic(id & 7u, epoch)], 1u)] = id;
         }
         listed = any && bcount > 0u;
