@@ -6,6 +6,10 @@ from helpers import pipeline
 from wgsparkl_amd import MpmData, scenes
 if len(sys.argv) > 1 and sys.argv[1] in ("c2", "c3", "c5"):
     sc = scenes.config_scene(sys.argv[1], n_side=int(sys.argv[2]) if len(sys.argv) > 2 else None)
+elif len(sys.argv) > 1 and sys.argv[1] == "landed":       # bench.py's c2_landed leg
+    sc = scenes.neo_hookean_cube(n_side=100, with_floor=True)
+    sc["particles"].pos[:, 1] -= 5.7
+    sc["particles"].vel[:, 1] = -3.0
 elif len(sys.argv) > 1 and sys.argv[1] == "stirred":      # bench.py's c2_stirred leg: > 10 % of the particles change cell per substep
     sc = scenes.neo_hookean_cube(n_side=100, with_floor=True)
     rel = sc["particles"].pos - sc["particles"].pos.mean(0)
@@ -19,7 +23,7 @@ pipe = pipeline(3)
 data = MpmData.new(pipe, sc["params"], sc["particles"], sc["colliders"], sc["cell_width"], sc["grid_capacity"], sc["model"])
 ROWS = 16384
 buf = (C.c_ulonglong * (ROWS * 8))()
-pipe.step(data, 20); data.sync()
+pipe.step(data, 200 if len(sys.argv) > 1 and sys.argv[1] == 'landed' else 20); data.sync()
 names = ["sort entries + state requested", "state + tile in", "stencil done", "update + stress done", "stores issued (end)", "plastic: parameters in", "plastic: SVD done"]
 for rep in range(2):
     pipe.lib.wgs_debug_g2p_prof(buf)
