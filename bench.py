@@ -209,9 +209,9 @@ class Leg:
         env["barrier"]()
         t0 = time.perf_counter()
         self.run(steps)                      # exactly K substeps
-        self.data.sync()
-        env["barrier"]()
+        env["barrier"]()                     # torch.cuda.synchronize() (+ the process group's barrier): every stream of the device, the data's included
         elapsed = time.perf_counter() - t0
+        self.data.sync()                     # (device-side errors of the timed substeps surface here: wgs_sync)
         # particles that changed their associated cell per substep of the timed region (device counter, wgs_stats.cell_changers)
         self.mover_fraction = None if movers0 is None else (self.data.stats()["cell_changers"] - movers0) / max(1, self.n * steps)
         if dist is not None:
