@@ -106,6 +106,18 @@ template <int D> __device__ inline void bodies_integrate_one(const Dev &d, uint3
         if (anorm > ang_limit)
             for (int k = 0; k < ANG; k++) na[k] = na[k] * (ang_limit / anorm);
     }
+    // A body at rest that nothing pushes — no velocity, no impulse, no gravity on a dynamic axis — keeps the very bits of its
+    // pose: the integration below is the identity in exact arithmetic, but in fp32 it renormalises the quaternion and
+    // recomposes the translation about the centre of mass, which rewrites the pose of a ROTATED fixed collider by an ulp for
+    // some substeps (a fifth of the rotations on the first, a few never settle). The node cdfs of blocks out of reach of the
+    // colliders that move are cached (Dev::cdf_moving, kernels_sort.h): a fixed collider must be bit-static for that cache —
+    // and for a bit-exact restart — whatever else moves in the scene.
+    {
+        bool rest = true;
+        for (int k = 0; k < D; k++) rest = rest && nl[k] == 0.f && (b.inv_mass[k] == 0.f || d.sp->gravity[k] == 0.f);
+        for (int k = 0; k < ANG; k++) rest = rest && na[k] == 0.f;
+        if (rest) return;
+    }
     // Body::integrateVelocity: rotate about the world centre of mass by exp(angvel dt), translate by linvel dt
     float comw[3] = {0.f, 0.f, 0.f}, arm[3] = {0.f, 0.f, 0.f}, rarm[3] = {0.f, 0.f, 0.f};
     pose_to_world<D>(c, b.local_com, comw);

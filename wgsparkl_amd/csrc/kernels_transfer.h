@@ -225,7 +225,7 @@ __global__ __launch_bounds__(P2GCfg<D>::NW * 64) void k_p2g(Dev d, int side, int
     constexpr int NQ = Cfg::NQ;
     __shared__ float4 s_q[NQ][P2G_J * ROW];
     __shared__ uint32_t s_aff[CPIC ? P2G_J * ROW : 1];
-    __shared__ float4 s_tile[Cfg::NW][TileSwz<D>::SIZE];   // (swizzled: layout.h TileSwz)
+    __shared__ float4 s_tile[Cfg::NW][TILE];
     __shared__ uint32_t s_cs[NPB], s_cn[NPB];
     constexpr int IMPQ = D == 3 ? 2 : 1;  // impulse quads per node: (lin, 0), (ang, 0) | (lin.xy, ang, 0)
     __shared__ float4 s_nrm[TWOWAY ? P2G_J * ROW : 1];
@@ -292,7 +292,7 @@ __global__ __launch_bounds__(P2GCfg<D>::NW * 64, WPE) void k_p2g_pair(Dev d, int
     constexpr int NQ = Cfg::NQ;
     __shared__ float4 s_q[NQ][P2G_J * ROW];
     __shared__ uint32_t s_aff[P2G_J * ROW];
-    __shared__ float4 s_tile[Cfg::NW][TileSwz<D>::SIZE];   // (swizzled: layout.h TileSwz)
+    __shared__ float4 s_tile[Cfg::NW][TILE];
     __shared__ uint32_t s_cs[NPB], s_cn[NPB];
     constexpr int IMPQ = D == 3 ? 2 : 1;
     __shared__ float4 s_nrm[TWOWAY ? P2G_J * ROW : 1];
