@@ -205,7 +205,8 @@ class Leg:
         torch, dist = env["torch"], env["dist"]
         self.run(warmup)
         self.data.sync()
-        movers0 = None if self.sharded else self.data.stats()["cell_changers"]
+        st0 = None if self.sharded else self.data.stats()
+        movers0 = None if st0 is None else st0["cell_changers"]
         env["barrier"]()
         t0 = time.perf_counter()
         self.run(steps)                      # exactly K substeps
@@ -213,7 +214,10 @@ class Leg:
         elapsed = time.perf_counter() - t0
         self.data.sync()                     # (device-side errors of the timed substeps surface here: wgs_sync)
         # particles that changed their associated cell per substep of the timed region (device counter, wgs_stats.cell_changers)
-        self.mover_fraction = None if movers0 is None else (self.data.stats()["cell_changers"] - movers0) / max(1, self.n * steps)
+        st1 = None if st0 is None else self.data.stats()
+        self.mover_fraction = None if movers0 is None else (st1["cell_changers"] - movers0) / max(1, self.n * steps)
+        # fixed-cost events INSIDE the timed region: substeps that rebuilt the table of block ids, growths of the grid (wgs_stats)
+        self.events = None if st0 is None else {"table_rebuilds": st1["table_rebuilds"] - st0["table_rebuilds"], "grid_growths": st1["grid_growths"] - st0["grid_growths"]}
         if dist is not None:
             t = torch.tensor([elapsed], device=env["device"], dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -241,7 +245,7 @@ class Leg:
         nblocks = int(st.num_active_blocks)
         return {"value": self.n_total * steps / elapsed, "ms_per_step": elapsed / steps * 1e3, "steps": steps,
                 "global_particles": self.n_total, "active_blocks_rank0": nblocks, "near_collider_blocks_rank0": int(st.num_near_collider_blocks),
-                "mover_fraction": self.mover_fraction,
+                "mover_fraction": self.mover_fraction, "events_in_timed_region": getattr(self, "events", None),
                 "parallelism": self.parallelism,
                 "roofline": g2p_roofline(timings, k_ts, float(ovh.value), self.n, nblocks * 64, self.bytes_per_particle, kernel_name),
                 "pass_ms_per_step": {k: v / k_ts for k, v in timings.items()}}
@@ -417,6 +421,7 @@ def main():
                        "parallelism": main_res["parallelism"]},
             "roofline": rl,
             "pass_ms_per_step": main_res["pass_ms_per_step"],
+            "events_in_timed_region": main_res["events_in_timed_region"], "mover_fraction": main_res["mover_fraction"],
             "build": {"info": build_info, "WGS_DEBUG": dbg_env, "transport_note": transport_note},
             "validation_sharded": validation_sharded,
             "notes": "the hash table of block ids is rebuilt (a k_bin launch in front of the sort, ~+0.25 ms once at this size) on the first substep, every "
@@ -462,6 +467,7 @@ def main():
         slim = lambda r, name: {"workload": name, "value": r["value"], "unit": "particle-steps/s", "ms_per_step": r["ms_per_step"],
                                 "global_particles": r["global_particles"], "active_blocks_rank0": r["active_blocks_rank0"],
                                 "near_collider_blocks_rank0": r["near_collider_blocks_rank0"], "steps": r["steps"], "mover_fraction": r["mover_fraction"],
+                                "events_in_timed_region": r["events_in_timed_region"],
                                 "roofline_g2p": {x: r["roofline"][x] for x in ("achieved", "frac", "avg_launch_ms", "algorithmic_bytes_per_launch")},
                                 "pass_ms_per_step": r["pass_ms_per_step"], "parallelism": r["parallelism"]}
         if not sharded_path:
@@ -469,7 +475,8 @@ def main():
             sc["particles"].pos[:, 1] -= 5.7          # lowered onto the floor, impact at -3 cells/s: contact state after 200 substeps
             sc["particles"].vel[:, 1] = -3.0
             sc["bytes_per_particle"] = 160.0
-            extra["c2_landed"] = slim(measure(env, sc, 1, 0, k, w, KERNEL_ELASTIC, settle=200 - w),
+            km = max(k, 200)   # scenes in motion: a timed region of 20 substeps swings by 15 % with one table rebuild inside it
+            extra["c2_landed"] = slim(measure(env, sc, 1, 0, km, w, KERNEL_ELASTIC, settle=200 - w),
                                       "the C2 cube after it landed: lowered onto the floor with a -3 cells/s impact, 200 substeps before the timed region")
             sc = scenes.config_scene("c3")
             extra["c3"] = slim(measure(env, sc, 1, 0, k, w, "k_g2p_pair<plastic>"), sc["name"])
@@ -489,7 +496,7 @@ def main():
             sc["particles"].vel[:, 1] = 48.0
             sc["particles"].vel[:, 2] = 48.0 - 1.5 * rel[:, 0]
             sc["bytes_per_particle"] = 160.0
-            extra["c2_stirred"] = slim(measure(env, sc, 1, 0, k, w, KERNEL_ELASTIC),
+            extra["c2_stirred"] = slim(measure(env, sc, 1, 0, km, w, KERNEL_ELASTIC),
                                        "the C2 cube flying through the grid at (48, 48, 48) cells/s and spinning at 1.5 rad/s: particles change cells in every substep")
             # the caller's frame loop: 20 substeps per wgs_step call, the blocking pose read-back between the calls
             # (src_testbed/step.rs:122-132,175-176; sand3.rs runs 20 substeps per frame)

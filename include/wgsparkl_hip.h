@@ -168,6 +168,9 @@ typedef struct {
     uint32_t grid_growths;        /* times the block capacity was doubled (wgs_set_grid_growth) */
     uint64_t cell_changers;       /* particles that changed their associated cell since creation (they are what the sort has to move:
                                      the difference of two reads / (particles x substeps) is the mover fraction per substep) */
+    uint64_t table_rebuilds;      /* substeps that rebuilt the table of block ids (a full binning pass in front of the sort: the first substep,
+                                     every 1024th, after a growth of the grid, when the ids ran out) — with grid_growths, the fixed-cost events
+                                     inside a timed region */
 } wgs_stats;
 
 typedef struct wgs_pipeline wgs_pipeline;

@@ -130,6 +130,7 @@ pub struct wgs_stats {
     pub num_near_collider_blocks: u32,
     pub grid_growths: u32,
     pub cell_changers: u64,
+    pub table_rebuilds: u64,
 }
 
 /// Optional interop view of the particle state on the device (`wgs_get_device_ptrs`).

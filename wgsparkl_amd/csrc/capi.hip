@@ -110,6 +110,7 @@ struct wgs_data {
     uint32_t last_nvisit = UINT32_MAX; // visit-list length at the last wgs_sync (sizes the list half of k_g2p_pair)
     uint32_t last_movers = 0;          // CTR_MOVERS at the last wgs_sync (cumulative, modulo 2^32)
     uint64_t movers_total = 0;         // the same, accumulated in 64 bits over the host's looks
+    uint64_t table_rebuilds = 0;       // substeps that rebuilt the table of block ids (wgs_stats)
     bool prebinned = false;            // the last fused G2P binned its output for the coming substep (Dev::bin_next): no k_rebin launch then
     uint32_t capacity = 0;      // particle slots allocated
     uint32_t *shard_counts = nullptr;  // device scratch for pack kernels
@@ -697,6 +698,7 @@ template <bool TS> wgs_status enqueue_substep(wgs_data *d, int ts_slot, int part
     // on the first substep, on table-rebuild substeps and in sharded runs (particles arrive from neighbours).
     const bool rehash = d->substeps % d->rehash_period == 0 || (d->force_rehash && first);
     if (rehash && first) {
+        d->table_rebuilds++;
         d->force_rehash = false;
         d->cdf_generation++;   // block ids are handed out anew
     }
@@ -1847,6 +1849,7 @@ wgs_status wgs_get_stats(wgs_data *d, wgs_stats *out) {
     out->num_near_collider_blocks = d->cpic && d->last_ncpic != UINT32_MAX ? d->last_ncpic : 0u;
     out->grid_growths = d->grid_grown;
     out->cell_changers = d->movers_total;
+    out->table_rebuilds = d->table_rebuilds;
     return WGS_OK;
 }
 

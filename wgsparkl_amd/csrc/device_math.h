@@ -557,7 +557,8 @@ __device__ inline bool affinities_are_compatible(uint32_t a1, uint32_t a2) {
 }
 
 // wgrapier Body::velocity_at_point (call sites p2g.wgsl:208, g2p.wgsl:191,224)
-template <int D> __device__ inline void velocity_at_point(const ColliderDev &c, const float *pt, float *out) {
+// (C: ColliderDev, or the copy of its motion a wave keeps in LDS — ColliderMotion, layout.h)
+template <int D, class C> __device__ inline void velocity_at_point(const C &c, const float *pt, float *out) {
     if constexpr (D == 2) {
         float dx = pt[0] - c.com[0], dy = pt[1] - c.com[1];
         out[0] = c.linvel[0] - c.angvel[0] * dy;

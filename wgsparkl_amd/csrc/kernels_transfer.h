@@ -546,6 +546,7 @@ __global__ __launch_bounds__(G2P_THREADS, G2P_WAVES_PER_EU) void k_g2p_update(De
     __shared__ float4 s_node[Dim<D>::TILE];
     __shared__ uint32_t s_nbr[16];   // Dev::bin_next: ids of the staged block's 2^D "+" and 2^D "-" neighbours (nbr_known)
     __shared__ NodeCdf s_cdf[CMODE == 2 ? Dim<D>::TILE : 1];
+    __shared__ ColliderMotion s_col[CMODE == 2 ? 16 : 1];   // (CPIC body: the colliders' velocities and centres of mass)
 #define G2P_CMODE CMODE
 #define G2P_BX blockIdx.x
 #define G2P_GX gridDim.x
@@ -574,6 +575,7 @@ __global__ __launch_bounds__(G2P_THREADS, WPE) void k_g2p_pair(Dev d, int side, 
     __shared__ float4 s_node[Dim<D>::TILE];
     __shared__ uint32_t s_nbr[16];   // Dev::bin_next: ids of the staged block's 2^D "+" and 2^D "-" neighbours (nbr_known)
     __shared__ NodeCdf s_cdf[Dim<D>::TILE];
+    __shared__ ColliderMotion s_col[16];   // (CPIC body: the colliders' velocities and centres of mass)
     if (blockIdx.x >= 8u * nlist) {
         const uint32_t widx = blockIdx.x - 8u * nlist;
 #define G2P_CMODE 1

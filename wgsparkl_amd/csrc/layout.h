@@ -90,6 +90,14 @@ struct ColliderDev {    // wgs_collider, device copy
     float com[3];
 };
 
+// What velocity_at_point needs of a collider (the three fields are consecutive in ColliderDev): the CPIC body of the fused G2P keeps
+// the colliders' copies in LDS (g2p_body.inc).
+struct ColliderMotion {
+    float linvel[3];
+    float angvel[3];
+    float com[3];
+};
+
 struct BodyDev {        // mass properties of the body behind a collider (rigid_impulses.wgsl:81-84)
     float inv_mass[3];
     float inv_inertia_local[9];   // 3D: column-major, body frame; 2D: [0]
