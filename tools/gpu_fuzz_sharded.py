@@ -28,22 +28,29 @@ for seed in range(lo, hi):
             cols.append(Collider.ball(float(rng.uniform(1.0, 3.0)), tuple(pos), **kw) if rng.random() < 0.5 else
                         Collider.cuboid(tuple(float(x) for x in rng.uniform(1.0, 4.0, dim)), tuple(pos), **kw))
         sc = dict(particles=ps, params=SimulationParams(gravity=(0.0, -9.81, 0.0)[:dim], dt=8e-4), colliders=cols, cell_width=1.0, grid_capacity=4096, model=int(rng.integers(0, 2)))
-        ref = run_gpu(sc, k).read_particles()
-        pipe = pipeline(dim)
-        shards, part = _native_slabs(sc, world, pipe)
-        if part.min_interior_width() < 3:
-            skipped += 1
-            continue
-        native_lockstep(pipe, shards, k)
-        for s in shards: s.sync()
-        outs = [s.export() for s in shards]
-        ids = np.concatenate([o["ids"] for o in outs])
-        assert np.array_equal(np.sort(ids), np.arange(ps.n, dtype=np.uint32)), "ids"
-        order = np.argsort(ids)
-        for f, tol in (("pos", 1e-5), ("vel", 2e-4)):
-            err = rel_rms(np.concatenate([o[f] for o in outs])[order], getattr(ref, f))
-            assert err < tol, (f, err)
-        for s in shards: s.close()
+        ref_data, shards = None, []
+        try:
+            ref_data = run_gpu(sc, k)
+            ref = ref_data.read_particles()
+            pipe = pipeline(dim)
+            shards, part = _native_slabs(sc, world, pipe)
+            if part.min_interior_width() < 3:
+                skipped += 1
+                continue
+            native_lockstep(pipe, shards, k)
+            for s in shards: s.sync()
+            outs = [s.export() for s in shards]
+            ids = np.concatenate([o["ids"] for o in outs])
+            assert np.array_equal(np.sort(ids), np.arange(ps.n, dtype=np.uint32)), "ids"
+            order = np.argsort(ids)
+            for f, tol in (("pos", 1e-5), ("vel", 2e-4)):
+                err = rel_rms(np.concatenate([o[f] for o in outs])[order], getattr(ref, f))
+                assert err < tol, (f, err)
+        finally:   # (device memory of every seed is released whatever happened: a long range must not fail on leaked memory)
+            for s in shards: s.close()
+            if ref_data is not None: ref_data.close()
     except Exception as e:  # noqa: BLE001
-        bad.append((seed, repr(e)[:120]))
+        import traceback
+        traceback.print_exc()
+        bad.append((seed, repr(e)))
 print(f"sharded fuzz seeds {lo}..{hi}: failures {bad}, skipped (slab too narrow) {skipped}")

@@ -13,7 +13,14 @@ for line in open(f"gpurun_out/{tag}/margins.jsonl"):
     e["count"] += 1
     if r["value"] / max(r["bound"], 1e-300) > e["worst_value"] / max(e["bound"], 1e-300) or e["count"] == 1:
         e.update(worst_value=r["value"], bound=r["bound"], worst_test=r["test"])
-out = dict(note="measured parity margins of the -m gpu suite on MI355X (tests/helpers.py report_margin): per check name, the worst value "
+import os, re, subprocess
+suite = ""
+try:
+    suite = [l.strip() for l in open(f"gpurun_out/{tag}/pytest.log") if re.search(r"\d+ passed", l)][-1]
+except Exception:
+    pass
+head = subprocess.run(["git", "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip()
+out = dict(round=rnd, suite=suite, git_head_when_summarised=head, note="measured parity margins of the -m gpu suite on MI355X (tests/helpers.py report_margin): per check name, the worst value "
                 "over all tests against its bound; values are relative RMS vs the fp64 oracle unless the name says otherwise",
            comparisons=total, comparisons_that_used_the_affine_escape=escapes, checks=list(by.values()))
 json.dump(out, open(f"profiles/{rnd}_parity_margins.json", "w"), indent=1)

@@ -330,7 +330,7 @@ void fill_collider(ColliderDev &c, const wgs_collider &in) {
     for (int k = 0; k < 3; k++) c.com[k] = in.com[k];
 }
 
-constexpr uint32_t WGS_LAUNCH_SHAPE_SWITCHES = 128u | 1024u | 4096u | 8192u | 16384u | 32768u | 65536u | 131072u | 262144u | 524288u | 1048576u | 4194304u | 8388608u | 16777216u;  // WGS_DEBUG bits the shipped library honours
+constexpr uint32_t WGS_LAUNCH_SHAPE_SWITCHES = 128u | 4096u | 8192u | 16384u | 32768u | 65536u | 131072u | 262144u | 524288u | 1048576u | 4194304u | 8388608u | 16777216u;  // WGS_DEBUG bits the shipped library honours
 constexpr uint32_t P2G_SMALL_BUDGET_MIN_PARTICLES = 600000;  // one-way CPIC P2G body at 168 VGPRs from this size on
 #ifndef WGS_REGROUP_ROUNDS
 #define WGS_REGROUP_ROUNDS 4u
@@ -705,7 +705,7 @@ template <bool TS> wgs_status enqueue_substep(wgs_data *d, int ts_slot, int part
     // node cdfs / block classes are reused from one substep to the next while no collider can move
     dev.cdf_gen = d->cpic ? d->cdf_generation : 0u;
     dev.cdf_moving = d->moving_mask;
-    const bool fused_cdf = d->cpic && dev.n_rigid == 0 && !(dev.dbg & 1024u);  // (mesh cdfs are only complete after k_p2g_cdf)
+    const bool fused_cdf = d->cpic && dev.n_rigid == 0;  // (mesh cdfs are only complete after k_p2g_cdf)
     if (first) dev.listed_in_perm = fused_cdf ? 1u : 0u;  // (part 2 of a sharded substep consumes what its part 1 wrote)
     const bool use_rebin = d->prev_sorted && !rehash && !(dev.dbg & 128u);
     // The fused G2P of this substep also bins its output for the next one (g2p_body.inc, Dev::bin_next; slabs too), unless
@@ -1075,7 +1075,7 @@ static wgs_status create_impl(wgs_pipeline *pipeline, const wgs_sim_params *para
     }
     dev.model = WGS_MODEL_COROTATED;
     // Developer switches (read once, here; 0 in production): A/B of launch shapes, SAME results — 128 = full k_bin on
-    // every substep (no k_rebin), 1024 = node cdf in a launch of its own (k_cdf) instead of k_setup_scatter<CDF>,
+    // every substep (no k_rebin),
     // 4096 = the two G2P bodies as two launches, 8192 = the two P2G bodies always as two launches, 16384 = never the
     // spill-free variant of the plastic G2P pair, 32768 = never the small register budget of the one-way P2G pair,
     // 65536 = never the uniform-material mode (the per-particle constants always travel with the particle), 131072 = the
@@ -1295,8 +1295,8 @@ void wgs_data_destroy(wgs_data *d) {
     if (d->stream2) {
         hipStreamSynchronize(d->stream2);
         hipStreamDestroy(d->stream2);
-        hipEventDestroy(d->ev_sorted);
-        hipEventDestroy(d->ev_exchanged);
+        if (d->ev_sorted) hipEventDestroy(d->ev_sorted);
+        if (d->ev_exchanged) hipEventDestroy(d->ev_exchanged);
     }
     if (d->events.created)
         for (int s = 0; s < Events::MAX_SUBSTEPS; s++)
