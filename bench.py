@@ -424,12 +424,12 @@ def main():
             "events_in_timed_region": main_res["events_in_timed_region"], "mover_fraction": main_res["mover_fraction"],
             "build": {"info": build_info, "WGS_DEBUG": dbg_env, "transport_note": transport_note},
             "validation_sharded": validation_sharded,
-            "notes": "the hash table of block ids is rebuilt (a k_bin launch in front of the sort, ~+0.25 ms once at this size) on the first substep, every "
-                     "1024 substeps and whenever three quarters of the ids are handed out; none of these falls inside this timed region. "
+            "notes": "the table of block ids is built by the first substep (a k_bin launch in front of the sort, ~+0.25 ms once at this size); blocks "
+                     "nobody activated for 8 substeps are evicted from it and their ids reused, so it is rebuilt again only when the grid grows "
+                     "(events_in_timed_region counts such substeps per leg). "
                      "pass_ms_per_step: on single-domain data the grid update runs as workgroups of the P2G launch and the fused G2P bins its output for the "
                      "next substep's sort (DESIGN.md 4): 'p2g' holds P2G + grid update, 'g2p' holds the binning, 'grid sort' is the one regroup launch, "
-                     "'grid_update' is then an empty interval between two event marks (~0.004 ms, like every pass without a launch)",
-        }
+                     "'grid_update' is then an empty interval between two event marks (~0.004 ms, like every pass without a launch)",        }
 
     # ---- CPU baseline + validation of the HIP path on the bench data itself (rank 0, N = 1)
     if rank == 0 and not args.no_cpu_baseline and not sharded_path:

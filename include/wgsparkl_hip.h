@@ -171,6 +171,10 @@ typedef struct {
     uint64_t table_rebuilds;      /* substeps that rebuilt the table of block ids (a full binning pass in front of the sort: the first substep,
                                      every 1024th, after a growth of the grid, when the ids ran out) — with grid_growths, the fixed-cost events
                                      inside a timed region */
+    uint32_t block_ids;           /* physical block ids handed out since the last table rebuild (high-water mark; the capacity bounds it) */
+    uint32_t block_ids_free;      /* ... of them on the free list: blocks evicted from the table after 8 substeps without activity, their ids reused */
+    uint32_t table_marks;         /* table slots marked "evicted" and not yet reused by an insertion */
+    uint32_t table_refreshes;     /* times the table was cleared of those marks: the live blocks re-inserted under their own ids, no particle touched */
 } wgs_stats;
 
 typedef struct wgs_pipeline wgs_pipeline;

@@ -131,6 +131,10 @@ pub struct wgs_stats {
     pub grid_growths: u32,
     pub cell_changers: u64,
     pub table_rebuilds: u64,
+    pub block_ids: u32,
+    pub block_ids_free: u32,
+    pub table_marks: u32,
+    pub table_refreshes: u32,
 }
 
 /// Optional interop view of the particle state on the device (`wgs_get_device_ptrs`).

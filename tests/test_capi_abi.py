@@ -59,7 +59,7 @@ def test_ctypes_structs_match_the_c_header(hip_libs, dim, tmp_path):
         "wgs_sim_params": ("SimParams", ["gravity", "dt"]),
         "wgs_node_record": ("NodeRecord", ["cell", "velocity", "mass", "cdf_distance", "cdf_affinities", "cdf_closest_id"]),
         "wgs_block_record": ("BlockRecord", ["virtual_id", "first_particle", "num_particles"]),
-        "wgs_stats": ("Stats", ["num_particles", "num_active_blocks", "grid_capacity", "overflow", "substeps_done", "device_bytes", "num_near_collider_blocks", "grid_growths", "cell_changers", "table_rebuilds"]),
+        "wgs_stats": ("Stats", ["num_particles", "num_active_blocks", "grid_capacity", "overflow", "substeps_done", "device_bytes", "num_near_collider_blocks", "grid_growths", "cell_changers", "table_rebuilds", "block_ids", "block_ids_free", "table_marks", "table_refreshes"]),
     }
     lines = ['#include <stdio.h>', '#include <stddef.h>', f'#define WGS_DIM {dim}', '#include "wgsparkl_hip.h"', 'int main(void) {']
     for cname, (_, fs) in fields.items():

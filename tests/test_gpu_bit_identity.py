@@ -368,3 +368,40 @@ def test_checkpoint_restart_with_a_rotated_fixed_collider_next_to_a_moving_one(h
     ga, gb = full.read_grid(), rest.read_grid()
     for x, y in zip(ga, gb):
         assert np.array_equal(x, y)
+
+
+@pytest.mark.parametrize("plastic", [False, True])
+def test_a_body_crossing_the_grid_evicts_blocks_and_stays_bit_identical_to_the_rebuild_path(hip_libs, plastic, monkeypatch):
+    """A cube flies through the grid and spins for 2 000 substeps: it leaves a trail of blocks nobody activates any more. Launch 2 of
+    the sort evicts them (their table slots are marked, their ids reused: kernels_sort.h regroup_block) — no table rebuild but the
+    periodic ones; with WGS_DEBUG=1024 nothing is evicted and the table is rebuilt whenever three quarters of the ids are handed out.
+    The sort is only a permutation: the same bits either way, and the evicting run rebuilds less often."""
+    from helpers import pipeline
+    from wgsparkl_amd import MpmData
+    sc = scenes.neo_hookean_cube(n_side=16, with_floor=True, grid_capacity=512)   # (~125-200 blocks at a time: the grid never grows; 384 ids run out every few hundred substeps)
+    ps = sc["particles"]
+    if plastic:   # (the variants with the plasticity / fracture branch bin in launch 1 of the sort, k_rebin, not in the fused G2P; a
+        # breakable phase that never breaks selects them and leaves the cube in one piece)
+        ps = ParticleSet.uniform(sc["particles"].pos, 0.25, 2700.0, ElasticCoefficients.from_young_modulus(1.0e7, 0.2),
+                                 phase=ParticlePhase(1.0, 1.0e6))
+    rel = ps.pos - ps.pos.mean(0)
+    ps.vel[:, 0] = 40.0 + 1.5 * rel[:, 2]
+    ps.vel[:, 1] = 25.0
+    ps.vel[:, 2] = 40.0 - 1.5 * rel[:, 0]
+    sc["params"] = SimulationParams((0.0, 0.0, 0.0), 1.0 / 300.0)   # (270 cells along x and z, 170 along y in 2 000 substeps)
+    monkeypatch.setenv("WGS_REHASH_PERIOD", "100000")   # (developer override, same results: no periodic rebuild inside the run)
+    pipe = pipeline(3)
+    def run():
+        data = MpmData.new(pipe, sc["params"], ps, sc["colliders"], sc["cell_width"], sc["grid_capacity"], sc["model"])
+        for _ in range(20):
+            pipe.step(data, 100)
+            data.sync()
+        return data.read_particles(), data.stats()
+    a, sa = run()
+    monkeypatch.setenv("WGS_DEBUG", "1024")
+    b, sb = run()
+    for f in ("pos", "vel", "def_grad", "affine", "dp_state"):
+        assert np.array_equal(getattr(a, f), getattr(b, f)), f
+    assert sa["overflow"] == 0 and sb["overflow"] == 0
+    assert sa["table_rebuilds"] < sb["table_rebuilds"], (sa["table_rebuilds"], sb["table_rebuilds"])
+    assert sa["table_rebuilds"] <= 1 + sa["grid_growths"]     # the first substep (+ one per growth of the grid: none expected)

@@ -99,7 +99,8 @@ def make_types(D: int):
     class Stats(C.Structure):
         _fields_ = [("num_particles", u), ("num_active_blocks", u), ("grid_capacity", u), ("overflow", u),
                     ("substeps_done", C.c_uint64), ("device_bytes", C.c_uint64), ("num_near_collider_blocks", u), ("grid_growths", u),
-                    ("cell_changers", C.c_uint64), ("table_rebuilds", C.c_uint64)]
+                    ("cell_changers", C.c_uint64), ("table_rebuilds", C.c_uint64),
+                    ("block_ids", u), ("block_ids_free", u), ("table_marks", u), ("table_refreshes", u)]
 
     ns = dict(SimParams=SimParams, Elastic=Elastic, DruckerPrager=DruckerPrager, PlasticState=PlasticState,
               Phase=Phase, Cdf=Cdf, Dynamics=Dynamics, Particle=Particle, Pose=Pose, Velocity=Velocity,

@@ -109,6 +109,7 @@ struct wgs_data {
     uint32_t last_ncpic = UINT32_MAX;  // near-collider list length at the last wgs_sync (picks the P2G launch shape and G2P's register budget)
     uint32_t last_nvisit = UINT32_MAX; // visit-list length at the last wgs_sync (sizes the list half of k_g2p_pair)
     uint32_t last_movers = 0;          // CTR_MOVERS at the last wgs_sync (cumulative, modulo 2^32)
+    uint32_t last_nphys = 0, last_nfree = 0, last_ntomb = 0;   // id high-water mark, free list, table marks at the last wgs_sync (wgs_stats)
     uint64_t movers_total = 0;         // the same, accumulated in 64 bits over the host's looks
     uint64_t table_rebuilds = 0;       // substeps that rebuilt the table of block ids (wgs_stats)
     bool prebinned = false;            // the last fused G2P binned its output for the coming substep (Dev::bin_next): no k_rebin launch then
@@ -137,13 +138,16 @@ struct wgs_data {
     uint32_t *watch = nullptr;          // pinned host copy of the device counters as of the end of the last wgs_step call
     hipEvent_t watch_event = nullptr;
     bool watch_pending = false, force_rehash = false, auto_grow = true;
+    bool force_refresh = false;    // the marks of evicted blocks crowd the table: the next substep re-inserts the live blocks into a cleared table (k_table_refresh)
+    uint64_t table_refreshes = 0;
     bool bodies_pending = false;   // integrate_bodies of the last substep has not run yet (it rides in the next sort launch)
     bool gu_fused = false;   // this substep's grid update rode in its P2G launch
     bool shard_fused = false; // sharded substep: the pack waves and the interior blocks' grid update rode in the P2G launch
     uint32_t grid_grown = 0;            // times the block capacity was doubled
     uint32_t watch_skips = 0;
     uint32_t cdf_generation = 1;        // bumped whenever cached node cdfs / block classes become invalid (kernels_sort.h regroup_block)
-    uint32_t rehash_period = REHASH_PERIOD;  // substeps between unconditional table rebuilds (developer override: WGS_REHASH_PERIOD)
+    uint32_t rehash_period = REHASH_PERIOD;  // substeps between unconditional table rebuilds (developer override: WGS_REHASH_PERIOD); 0 = none
+                                             // but the first substep's: data whose long-inactive blocks are evicted (wgs_data_create decides)
     ShardLink *link = nullptr;          // wgs_shard_attach
     int reduce_impulses = 0;            // sharded two-way coupling: 1 = ncclAllReduce of the body impulses before
                                         // integrate_bodies, 2 = the caller sums them and integrates (lockstep group)
@@ -190,6 +194,10 @@ wgs_status alloc_grid(wgs_data *d) {
     GRID_ALLOC(&dev.hkeys, hcap);
     GRID_ALLOC(&dev.hvals, hcap);
     GRID_ALLOC(&dev.block_key, cap);
+    if (!dev.sharded && !(dev.dbg & 1024u)) {   // (eviction of blocks long inactive: single-domain data; WGS_DEBUG bit 10 = never, the table is rebuilt instead)
+        GRID_ALLOC(&dev.block_slot, cap);
+        GRID_ALLOC(&dev.free_ids, cap);
+    }
     GRID_ALLOC(&dev.block_count, cap);
     GRID_ALLOC(&dev.block_stamp, cap);
     GRID_ALLOC(&dev.links_epoch, cap);
@@ -265,7 +273,7 @@ wgs_status grow_grid(wgs_data *d, uint32_t new_cap) {
         hipGetLastError();  // (the failed hipMalloc is not this call's error)
         return WGS_OK;
     }
-    void *old_ptrs[] = {old.hkeys, old.hvals, old.block_key, old.block_count, old.block_stamp, old.links_epoch, old.block_acc, old.block_dirty, old.blk_narr, old.blk_arr, old.block_ident, old.active,
+    void *old_ptrs[] = {old.hkeys, old.hvals, old.block_key, old.block_slot, old.free_ids, old.block_count, old.block_stamp, old.links_epoch, old.block_acc, old.block_dirty, old.blk_narr, old.blk_arr, old.block_ident, old.active,
                         old.block_start, old.act_info, old.act_cells, old.nbr_plus, old.nbr_minus, old.nbr_known, old.act_src, old.cell_head, old.chunk_a, old.chunk_b, old.group_a, old.group_b,
                         old.cell_start, old.cell_cursor, old.nodes, old.node_cdf, old.slab, old.slab_epoch, old.block_cdf_gen, old.block_cpic, old.cpic_list, old.visit_list, old.halo_list,
                         old.imp_slab, old.mesh_min, old.mesh_aff};
@@ -273,6 +281,7 @@ wgs_status grow_grid(wgs_data *d, uint32_t new_cap) {
     HIP_TRY(hipMemsetAsync(dev.hkeys, 0xff, sizeof(uint32_t) * ((size_t)dev.hmask + 1), d->stream));
     HIP_TRY(hipMemsetAsync(dev.hvals, 0xff, sizeof(uint32_t) * ((size_t)dev.hmask + 1), d->stream));
     HIP_TRY(hipMemsetAsync(dev.counters + CTR_NPHYS, 0, sizeof(uint32_t), d->stream));
+    HIP_TRY(hipMemsetAsync(dev.counters + CTR_NFREE, 0, 3 * sizeof(uint32_t), d->stream));   // (free list, insertion count, marks)
     d->prev_sorted = false;      // block ids start over: the next substep bins every particle through the hash map
     d->prebinned = false;        // (what the last G2P binned went with the old arrays)
     d->cdf_generation++;
@@ -310,6 +319,7 @@ wgs_status maintain_grid(wgs_data *d) {
         return grow_grid(d, new_cap);
     }
     if (nphys > cap / 4u * 3u) d->force_rehash = true;
+    if (d->watch[CTR_NTOMB] > cap / 2u) d->force_refresh = true;   // (marks of evicted blocks: a quarter of the 2 x cap slots)
     return WGS_OK;
 }
 
@@ -330,7 +340,7 @@ void fill_collider(ColliderDev &c, const wgs_collider &in) {
     for (int k = 0; k < 3; k++) c.com[k] = in.com[k];
 }
 
-constexpr uint32_t WGS_LAUNCH_SHAPE_SWITCHES = 128u | 4096u | 8192u | 16384u | 32768u | 65536u | 131072u | 262144u | 524288u | 1048576u | 4194304u | 8388608u | 16777216u;  // WGS_DEBUG bits the shipped library honours
+constexpr uint32_t WGS_LAUNCH_SHAPE_SWITCHES = 128u | 1024u | 4096u | 8192u | 16384u | 32768u | 65536u | 131072u | 262144u | 524288u | 1048576u | 4194304u | 8388608u | 16777216u;  // WGS_DEBUG bits the shipped library honours
 constexpr uint32_t P2G_SMALL_BUDGET_MIN_PARTICLES = 600000;  // one-way CPIC P2G body at 168 VGPRs from this size on
 #ifndef WGS_REGROUP_ROUNDS
 #define WGS_REGROUP_ROUNDS 4u
@@ -619,9 +629,13 @@ wgs_status fetch_counters(wgs_data *d) {
     for (int k = 0; k < 16; k++) movers += host[CTR_MOVERS + 32 * k];
     d->movers_total += (uint32_t)(movers - d->last_movers);
     d->last_movers = movers;
+    d->last_nphys = host[CTR_NPHYS];
+    d->last_nfree = host[CTR_NFREE];
+    d->last_ntomb = host[CTR_NTOMB];
     d->sticky_errors |= host[CTR_ERRORS];
     if (host[CTR_NBLOCKS] > d->dev.cap) d->sticky_errors |= ERRBIT_OVERFLOW;
     if (host[CTR_NPHYS] > d->dev.cap / 4u * 3u) d->force_rehash = true;
+    if (host[CTR_NTOMB] > d->dev.cap / 2u) d->force_refresh = true;
     return WGS_OK;
 }
 
@@ -696,7 +710,7 @@ template <bool TS> wgs_status enqueue_substep(wgs_data *d, int ts_slot, int part
     // (perm_cell) and neighbour links are still valid, so the particles are re-binned RELATIVE to their old
     // block (k_rebin: no hash lookups except for the few particles that changed block). The full k_bin runs
     // on the first substep, on table-rebuild substeps and in sharded runs (particles arrive from neighbours).
-    const bool rehash = d->substeps % d->rehash_period == 0 || (d->force_rehash && first);
+    const bool rehash = d->substeps == 0 || (d->rehash_period != 0u && d->substeps % d->rehash_period == 0) || (d->force_rehash && first);
     if (rehash && first) {
         d->table_rebuilds++;
         d->force_rehash = false;
@@ -724,7 +738,7 @@ template <bool TS> wgs_status enqueue_substep(wgs_data *d, int ts_slot, int part
     // instruction cache, cost a third of the launch — and launch 1 of the sort, k_rebin, stays)
     // (a slab: its fused G2P bins the residents — the guests it drops leave their block's total —, k_g2p_arrivals the particles that
     // arrive; both parts of a sharded substep see the same value)
-    dev.bin_next = (!d->plastic && !(dev.dbg & (128u | 1048576u)) && (d->substeps + 1) % d->rehash_period != 0) ? 1u : 0u;
+    dev.bin_next = (!d->plastic && !(dev.dbg & (128u | 1048576u)) && (d->rehash_period == 0u || (d->substeps + 1) % d->rehash_period != 0)) ? 1u : 0u;
     // the fused G2P drops the guests only inside the sharded step (kernels_shard.h); wgs_step on a slab advances what it holds
     dev.skip_guests = (d->in_sharded_step && dev.sharded) ? 1u : 0u;
     if (dev.sharded && d->needs_compact && first) {
@@ -738,10 +752,20 @@ template <bool TS> wgs_status enqueue_substep(wgs_data *d, int ts_slot, int part
         }
         mark(0);
         // ---- "grid sort" (grid.rs:30-207)
+        if (d->force_refresh && !rehash && dev.free_ids != nullptr) {
+            // the marks of evicted blocks crowd the table (the host's last look): clear it and insert the live blocks again under
+            // their own ids — no particle is touched, the steady-state sort goes on (kernels_sort.h k_table_refresh)
+            HIP_TRY(hipMemsetAsync(dev.hkeys, 0xff, sizeof(uint32_t) * ((size_t)dev.hmask + 1), s));
+            HIP_TRY(hipMemsetAsync(dev.hvals, 0xff, sizeof(uint32_t) * ((size_t)dev.hmask + 1), s));
+            hipLaunchKernelGGL(k_table_refresh, dim3(std::max(1u, std::min((dev.cap + 255u) / 256u, (uint32_t)grid_for(d, 4)))), dim3(256), 0, s, dev);
+            d->table_refreshes++;
+        }
+        if (first) d->force_refresh = false;
         if (rehash) {  // reset_hmap, amortised (device_math.h)
             HIP_TRY(hipMemsetAsync(dev.hkeys, 0xff, sizeof(uint32_t) * ((size_t)dev.hmask + 1), s));
             HIP_TRY(hipMemsetAsync(dev.hvals, 0xff, sizeof(uint32_t) * ((size_t)dev.hmask + 1), s));
             HIP_TRY(hipMemsetAsync(dev.counters + CTR_NPHYS, 0, sizeof(uint32_t), s));
+            HIP_TRY(hipMemsetAsync(dev.counters + CTR_NFREE, 0, 3 * sizeof(uint32_t), s));   // (free list, insertion count, marks: layout.h)
         }
         // ---- "update rigid particles" (rigid_particle_update.wgsl): samples and vertices of the mesh colliders
         if (dev.n_rigid > 0)
@@ -1075,7 +1099,7 @@ static wgs_status create_impl(wgs_pipeline *pipeline, const wgs_sim_params *para
     }
     dev.model = WGS_MODEL_COROTATED;
     // Developer switches (read once, here; 0 in production): A/B of launch shapes, SAME results — 128 = full k_bin on
-    // every substep (no k_rebin),
+    // every substep (no k_rebin), 1024 = no eviction of long-inactive blocks from the table (it is rebuilt when the ids run out instead),
     // 4096 = the two G2P bodies as two launches, 8192 = the two P2G bodies always as two launches, 16384 = never the
     // spill-free variant of the plastic G2P pair, 32768 = never the small register budget of the one-way P2G pair,
     // 65536 = never the uniform-material mode (the per-particle constants always travel with the particle), 131072 = the
@@ -1109,6 +1133,9 @@ static wgs_status create_impl(wgs_pipeline *pipeline, const wgs_sim_params *para
     TRY_ALLOC(&dev.mv_next, (size_t)dev.npad);
     st = alloc_grid(d);
     if (st != WGS_OK) return bail(st);
+    // data that evicts its long-inactive blocks needs no periodic table rebuild (the marks the evictions leave are cleared by
+    // k_table_refresh, without touching a particle); slabs keep the period
+    if (dev.free_ids != nullptr && !getenv("WGS_REHASH_PERIOD")) d->rehash_period = 0u;
     TRY_ALLOC(&dev.counters, (size_t)CTR_COUNT);
     TRY_ALLOC(&d->sp, (size_t)1);
     TRY_ALLOC(&d->colliders, (size_t)WGS_MAX_COLLIDERS);
@@ -1850,6 +1877,10 @@ wgs_status wgs_get_stats(wgs_data *d, wgs_stats *out) {
     out->grid_growths = d->grid_grown;
     out->cell_changers = d->movers_total;
     out->table_rebuilds = d->table_rebuilds;
+    out->block_ids = d->last_nphys;
+    out->block_ids_free = d->last_nfree;
+    out->table_marks = d->last_ntomb;
+    out->table_refreshes = (uint32_t)d->table_refreshes;
     return WGS_OK;
 }
 

@@ -31,10 +31,11 @@ template <int D> __host__ __device__ inline void unpack_key(uint32_t key, int *b
 
 template <int D> __host__ __device__ inline bool block_in_key_range(const int *b) {
     if constexpr (D == 2) {
-        return b[0] >= -0x7fff && b[0] <= 0x8000 && b[1] >= -0x7fff && b[1] <= 0x8000 && !(b[0] == 0x8000 && b[1] == 0x8000);
+        // (the corner that packs to NONE, quirk B5 — and the block next to it along x, whose key is KEY_TOMB, the mark of an evicted table slot)
+        return b[0] >= -0x7fff && b[0] <= 0x8000 && b[1] >= -0x7fff && b[1] <= 0x8000 && !(b[0] >= 0x7fff && b[1] == 0x8000);
     } else {
         bool in = b[0] >= -0x3ff && b[0] <= 0x400 && b[1] >= -0x1ff && b[1] <= 0x200 && b[2] >= -0x3ff && b[2] <= 0x400;
-        return in && !(b[0] == 0x400 && b[1] == 0x200 && b[2] == 0x400);  // that corner packs to NONE (quirk B5)
+        return in && !(b[0] >= 0x3ff && b[1] == 0x200 && b[2] == 0x400);  // that corner packs to NONE (quirk B5); its x-neighbour to KEY_TOMB
     }
 }
 
@@ -65,6 +66,11 @@ __device__ inline int assoc_cell(float x, float h, float inv_h, bool h_pow2) {
 // handed out, capi.hip maintain_grid, which is what bounds the table in practice)
 constexpr uint32_t REHASH_PERIOD = 1024;
 constexpr uint32_t ID_OVERFLOW = 0xfffffffeu;
+// The key of a table slot whose block was EVICTED (kernels_sort.h regroup_block): look-ups walk past it; an insertion whose key is not
+// in the table takes the first marked slot on its probe sequence (activate_block). No block packs to it (block_in_key_range).
+constexpr uint32_t KEY_TOMB = 0xfffffffeu;
+// substeps a block must have been inactive before launch 2 of the sort may evict it (its id goes on the free list, its table slot is marked)
+constexpr uint32_t EVICT_AGE = 8;
 
 // grid/grid.wgsl:167-184 find_block_header_id (active blocks only)
 __device__ inline uint32_t hmap_find(const Dev &d, uint32_t key, uint32_t epoch) {
@@ -169,24 +175,51 @@ template <int K> __device__ inline void hmap_find_many(const Dev &d, const uint3
 // grid/grid.wgsl:121-164 insertion_index + :323-334 mark_block_as_active: make sure `key`
 // is in the table, stamp its block active for `epoch` and return the block's physical id.
 __device__ inline uint32_t activate_block(const Dev &d, uint32_t key, uint32_t epoch) {
-    uint32_t slot = hash_key(key) & d.hmask;
+    const uint32_t home = hash_key(key) & d.hmask;
+    uint32_t slot = home;
+    uint32_t first_mark = NONE;   // the first KEY_TOMB slot on the key's probe sequence: where the key goes if it is not in the table
     uint32_t result = NONE;
     bool done = false;
+    bool coherent = false;   // after a lost claim: read the table past this CU's cache (a stale mark would be tried again and again)
     for (uint32_t probe = 0; probe <= d.hmask && !done; ++probe) {
-        uint32_t cur = d.hkeys[slot];  // plain load: a stale NONE only costs one extra CAS below
+        // plain load: a stale NONE only costs one extra CAS below
+        uint32_t cur = coherent ? __hip_atomic_load(&d.hkeys[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : d.hkeys[slot];
         bool won = false;
+        if (cur == KEY_TOMB && first_mark == NONE) first_mark = slot;
         if (cur == NONE) {
-            cur = atomicCAS(&d.hkeys[slot], NONE, key);
-            won = cur == NONE;
-            if (won) cur = key;
+            // the key is not in the table (its sequence ends here): it takes the first marked slot it passed, else this empty one. Every
+            // wave that inserts the same key walks the same sequence and tries the same slot; if ANOTHER key took it meanwhile, start over.
+            const uint32_t target = first_mark != NONE ? first_mark : slot;
+            const uint32_t expect = first_mark != NONE ? KEY_TOMB : NONE;
+            const uint32_t old = atomicCAS(&d.hkeys[target], expect, key);
+            if (old == expect || old == key) {
+                won = old == expect;
+                slot = target;
+                cur = key;
+            } else {
+                slot = home;
+                first_mark = NONE;
+                coherent = true;
+                continue;
+            }
         }
         // Winners first, in program order and WITHOUT leaving the divergent region: lanes of the
         // same wave that lost the race for this very slot wait below for hvals, and would spin
         // forever if the winner's branch were scheduled after their loop.
         if (won) {  // slot claimed: hand out a physical id (rare: new block)
-            uint32_t id = atomicAdd(&d.counters[CTR_NPHYS], 1u);
+            // an id from the free list of evicted blocks (pushed by launch 2 of the sort, never while anybody inserts), else a new one
+            uint32_t id = NONE;
+            if (d.free_ids != nullptr && __hip_atomic_load(&d.counters[CTR_NFREE], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - 1u < d.cap) {
+                const uint32_t nf = atomicSub(&d.counters[CTR_NFREE], 1u);
+                if (nf - 1u < d.cap) id = d.free_ids[nf - 1u];
+                else atomicAdd(&d.counters[CTR_NFREE], 1u);   // (somebody else took the last one)
+            }
+            if (id == NONE) id = atomicAdd(&d.counters[CTR_NPHYS], 1u);
+            atomicAdd(&d.counters[CTR_NINSERT], 1u);   // (what "no block was inserted since" is read from: ids are reused)
+            if (first_mark != NONE && slot == first_mark) atomicSub(&d.counters[CTR_NTOMB], 1u);   // (a marked slot is a key's again)
             if (id < d.cap) {
                 d.block_key[id] = key;
+                if (d.block_slot != nullptr) d.block_slot[id] = slot;
             } else {
                 atomicOr(&d.counters[CTR_ERRORS], ERRBIT_OVERFLOW);
                 id = ID_OVERFLOW;
@@ -196,6 +229,7 @@ __device__ inline uint32_t activate_block(const Dev &d, uint32_t key, uint32_t e
         if (cur == key) {
             uint32_t id = d.hvals[slot];
             // a thread of ANOTHER wave may still be between its CAS and its hvals store: bounded wait
+            // (the value of a marked slot is NONE, like an empty slot's: the eviction cleared it)
             for (int spin = 0; id == NONE && spin < (1 << 16); spin++) {
                 __builtin_amdgcn_s_sleep(1);
                 id = __hip_atomic_load(&d.hvals[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

@@ -390,7 +390,7 @@ __device__ __forceinline__ void scan_chunk(const Dev &d, uint32_t epoch, uint32_
 #ifdef WGS_ABLATE
     if (tid == 0) g_prof[WGS_PROF_ROWS - 1][0] = wall_clock64();
 #endif
-    if (k == 0 && tid == 0) d.counters[CTR_NPHYS_SEEN + (epoch & 1u)] = d.counters[CTR_NPHYS];
+    if (k == 0 && tid == 0) d.counters[CTR_NPHYS_SEEN + (epoch & 1u)] = d.counters[CTR_NINSERT];
     // the list counters of the NEXT substep (the other set: nothing of this substep reads or appends to it; layout.h)
     if (k == 0 && tid < 16) d.counters[tid < 8 ? ctr_ncpic((uint32_t)tid, epoch + 1u) : ctr_nvisit((uint32_t)tid - 8u, epoch + 1u)] = 0u;
     if (k == 0 && tid == 16) d.counters[ctr_nhalo(epoch + 1u)] = 0u;
@@ -464,7 +464,26 @@ __device__ __forceinline__ uint32_t regroup_block(const Dev &d, int side, uint32
     uint32_t link = NONE;
     if (lane < 16) link = d.nbr_known[id * 16u + lane];
     const GroupLoads grp = block_prefix_loads(d, id, lane);
-    if (stamp != epoch) return 0u;  // wave-uniform: not active in this substep
+    if (stamp != epoch) {  // wave-uniform: not active in this substep
+        // EVICTION (single-domain data): a block nobody activated for EVICT_AGE substeps leaves the table — its slot is marked KEY_TOMB,
+        // its id goes on the free list the next insertion takes from. The table and the ids then live as long as the simulation moves
+        // slowly enough for the marks not to crowd the table (the host watches CTR_NTOMB), instead of being rebuilt from every particle —
+        // a k_bin launch and a regrouping of everything, ~0.65 ms at 1 M particles — whenever three quarters of the ids were handed out
+        // (a body crossing the grid: every few hundred substeps). Whoever still holds the id as "a neighbour that is in the table"
+        // (nbr_known) compares the key before trusting it: block_key of an evicted id is NONE until the id is handed out again.
+        if constexpr (!SHARD) {
+            if (d.free_ids != nullptr && lane == 0 && stamp != 0u && epoch - stamp > EVICT_AGE && bkey != NONE) {
+                const uint32_t hs = d.block_slot[id];
+                d.hkeys[hs] = KEY_TOMB;
+                d.hvals[hs] = NONE;   // (like an empty slot's: an insertion that takes the slot publishes its id here)
+                d.block_key[id] = NONE;
+                if constexpr (CDF) d.block_cdf_gen[id] = 0u;
+                d.free_ids[atomicAdd(&d.counters[CTR_NFREE], 1u)] = id;
+                atomicAdd(&d.counters[CTR_NTOMB], 1u);
+            }
+        }
+        return 0u;
+    }
     const bool old_ok = have_old && le == epoch - 1u;
     if (!old_ok) {
         cs_old = ce_old = 0u;
@@ -472,10 +491,11 @@ __device__ __forceinline__ uint32_t regroup_block(const Dev &d, int side, uint32
     }
     // a neighbour that was in the table one substep ago keeps its physical id: it only has to be active now (one round
     // trip instead of the three of a hash lookup)
-    uint32_t link_stamp = 0u, link_cnt = 0u;
+    uint32_t link_stamp = 0u, link_cnt = 0u, link_key = NONE;
     if (link != NONE) {
         link_stamp = d.block_stamp[link];
         link_cnt = d.block_acc[link];  // particles of that neighbour in this substep (launch 1's total)
+        link_key = d.block_key[link];  // (an id that was evicted since — and maybe handed out again, to another block — is not this neighbour)
     }
     const bool links_valid = old_ok;
     // ---- stage the new cell ids of the block's previous run (contiguous: cells are consecutive runs); with movers
@@ -545,12 +565,13 @@ __device__ __forceinline__ uint32_t regroup_block(const Dev &d, int side, uint32
         const bool minus = lane >= 8;
         uint32_t known = NONE;
         if ((int)o < NN) {
+            const int sgn = minus ? -1 : 1;
+            int nb[3] = {b[0] + sgn * (int)(o & 1u), b[1] + sgn * (int)((o >> 1) & 1u), b[2] + sgn * (int)((o >> 2) & 1u)};
+            if (link != NONE && link_key != pack_key<D>(nb)) link = NONE;   // (evicted: no longer in the table under that id)
             if (link != NONE) {
                 known = link;
                 res = link_stamp == epoch ? link : NONE;
             } else if (!(links_valid && no_new_blocks)) {  // unknown, or the table has grown: look it up
-                const int sgn = minus ? -1 : 1;
-                int nb[3] = {b[0] + sgn * (int)(o & 1u), b[1] + sgn * (int)((o >> 1) & 1u), b[2] + sgn * (int)((o >> 2) & 1u)};
                 if (block_in_key_range<D>(nb)) known = hmap_lookup(d, pack_key<D>(nb));
                 if (known != NONE && d.block_stamp[known] == epoch) res = known;
                 if (res != NONE) link_cnt = d.block_acc[res];
@@ -1133,7 +1154,7 @@ template <int D, bool CDF, bool SHARD = false> __global__ __launch_bounds__(SORT
     const int w = threadIdx.x >> 6;
     // no block id was handed out since launch 2 of the previous substep? Then a neighbour that was not in the table is
     // still not in it (rim of the active region: the lookups with the longest probe sequences, every substep)
-    const bool no_new_blocks = d.counters[CTR_NPHYS] == d.counters[CTR_NPHYS_SEEN + ((epoch - 1u) & 1u)];
+    const bool no_new_blocks = d.counters[CTR_NINSERT] == d.counters[CTR_NPHYS_SEEN + ((epoch - 1u) & 1u)];
     uint32_t movers = 0u;
     for (uint32_t id = wave; id < nphys; id += nwaves)
         movers += regroup_block<D, CDF, SHARD>(d, side, epoch, id, nphys, have_old != 0, no_new_blocks, s_in[w], s_out[w], s_pid[w]);
@@ -1143,6 +1164,29 @@ template <int D, bool CDF, bool SHARD = false> __global__ __launch_bounds__(SORT
     if (threadIdx.x == 0) {
         const unsigned long long m = s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
         if (m != 0ull) atomicAdd(&d.counters[CTR_MOVERS + 32u * (blockIdx.x & 15u)], (uint32_t)m);
+    }
+}
+
+// The table without its marks (capi.hip, when the marks of evicted blocks crowd it): the two arrays were cleared, every block that is
+// still in the table — block_key is NONE for an evicted id — is inserted again UNDER ITS OWN ID. Nothing else changes: ids, cell ids,
+// links and the particles' order stay what they are, the steady-state sort goes on. (A full rebuild bins every particle again through
+// the table and regroups everything: ~0.65 ms at 1 M particles against a few microseconds here.) Alone on the stream: nobody else
+// looks at the table meanwhile.
+__global__ __launch_bounds__(256) void k_table_refresh(Dev d) {
+    const uint32_t nphys = min(d.counters[CTR_NPHYS], d.cap);
+    if (blockIdx.x == 0 && threadIdx.x == 0) d.counters[CTR_NTOMB] = 0u;
+    for (uint32_t id = blockIdx.x * 256u + threadIdx.x; id < nphys; id += gridDim.x * 256u) {
+        const uint32_t key = d.block_key[id];
+        if (key == NONE) continue;   // (on the free list)
+        uint32_t slot = hash_key(key) & d.hmask;
+        for (uint32_t probe = 0; probe <= d.hmask; ++probe) {
+            if (atomicCAS(&d.hkeys[slot], NONE, key) == NONE) {
+                d.hvals[slot] = id;
+                d.block_slot[id] = slot;
+                break;
+            }
+            slot = (slot + 1u) & d.hmask;
+        }
     }
 }
 

@@ -121,7 +121,10 @@ enum { CTR_NBLOCKS = 0, CTR_ERRORS = 1, CTR_NPHYS = 2,
        CTR_NPREV = 6,  // sharded runs: slots [0, NPREV) are the sorted output of the last substep, [NPREV, N) arrivals
        CTR_NLEAVE = 7,  // sharded runs: particles the last fused G2P launches found outside the core range (Dev::leavers): next substep's guests
        CTR_TICKET = 10,  // sharded runs: workgroups of k_g2p_arrivals that are done (the last one does the bookkeeping)
-       CTR_NPHYS_SEEN = 8,  // [8], [9]: the id counter as launch 2 of an even / odd substep saw it (kernels_sort.h regroup_block)
+       CTR_NFREE = 11,   // ids on the free list (Dev::free_ids): blocks launch 2 of the sort evicted from the table
+       CTR_NINSERT = 12, // insertions into the table since its last rebuild (never decreases: ids are reused, so the id counter does not say)
+       CTR_NTOMB = 13,   // table slots marked KEY_TOMB since the last rebuild (the host rebuilds the table before they crowd it)
+       CTR_NPHYS_SEEN = 8,  // [8], [9]: the insertion counter (CTR_NINSERT) as launch 2 of an even / odd substep saw it (kernels_sort.h regroup_block)
        CTR_NVISIT = 64,  // [64 + 32 k], k = 0..7: length of the visit list of XCD k (Dev::visit_list), one cache line each
        CTR_NCPIC = 320,  // [320 + 32 k], k = 0..7: length of list k of the near-collider blocks (Dev::cpic_list), one cache line each
        CTR_NHALO = 576,  // sharded runs: length of the list of active blocks in the interface layers (Dev::halo_list)
@@ -180,7 +183,9 @@ struct Dev {
     uint32_t hmask;      // hcap - 1
     uint32_t cap;        // block capacity
     // per physical block id (ids persist while the block stays in the hash map)
-    uint32_t *block_key;   // cap: packed virtual id
+    uint32_t *block_key;   // cap: packed virtual id (NONE: the id is on the free list — the block was evicted)
+    uint32_t *block_slot;  // cap: the table slot that holds the block's key (what an eviction marks); null: no eviction on this data (slabs)
+    uint32_t *free_ids;    // cap: ids of evicted blocks, a stack of counters[CTR_NFREE] entries (pushed by launch 2 of the sort, popped by insertions)
     uint32_t *block_stamp; // cap: epoch of the last substep in which the block was active
     uint32_t *links_epoch; // cap: epoch at which nbr_plus / nbr_minus of the block were last written
     uint32_t *block_acc;   // cap: particle counter being accumulated by k_bin / k_rebin (zero at rest)
