@@ -69,8 +69,10 @@ constexpr uint32_t ID_OVERFLOW = 0xfffffffeu;
 // The key of a table slot whose block was EVICTED (kernels_sort.h regroup_block): look-ups walk past it; an insertion whose key is not
 // in the table takes the first marked slot on its probe sequence (activate_block). No block packs to it (block_in_key_range).
 constexpr uint32_t KEY_TOMB = 0xfffffffeu;
-// substeps a block must have been inactive before launch 2 of the sort may evict it (its id goes on the free list, its table slot is marked)
+// substeps a block must have been inactive before launch 2 of the sort may evict it (its id goes on the free list, its table slot is marked);
+// also the period of the substeps that evict (a power of two: kernels_sort.h k_regroup)
 constexpr uint32_t EVICT_AGE = 8;
+static_assert((EVICT_AGE & (EVICT_AGE - 1u)) == 0u, "EVICT_AGE is used as a mask");
 
 // grid/grid.wgsl:167-184 find_block_header_id (active blocks only)
 __device__ inline uint32_t hmap_find(const Dev &d, uint32_t key, uint32_t epoch) {

@@ -438,7 +438,7 @@ __device__ inline void block_prefix(const Dev &d, uint32_t epoch, uint32_t id, i
 // on a list.
 // Returns the number of particles of the block's new run that changed cell in the last step (statistics, wave-uniform).
 template <int D, bool CDF, bool SHARD>
-__device__ __forceinline__ uint32_t regroup_block(const Dev &d, int side, uint32_t epoch, uint32_t id, uint32_t nphys, bool have_old, bool no_new_blocks,
+__device__ __forceinline__ uint32_t regroup_block(const Dev &d, int side, uint32_t epoch, uint32_t id, uint32_t nphys, bool have_old, bool no_new_blocks, bool check_keys,
                                               uint32_t *s_in, uint32_t *s_out, uint32_t *s_pid) {
     constexpr int NN = Dim<D>::NNBR;
     const int lane = threadIdx.x & 63;
@@ -472,7 +472,7 @@ __device__ __forceinline__ uint32_t regroup_block(const Dev &d, int side, uint32
         // (a body crossing the grid: every few hundred substeps). Whoever still holds the id as "a neighbour that is in the table"
         // (nbr_known) compares the key before trusting it: block_key of an evicted id is NONE until the id is handed out again.
         if constexpr (!SHARD) {
-            if (d.free_ids != nullptr && lane == 0 && stamp != 0u && epoch - stamp > EVICT_AGE && bkey != NONE) {
+            if (d.free_ids != nullptr && lane == 0 && (epoch & (EVICT_AGE - 1u)) == 0u && stamp != 0u && epoch - stamp > EVICT_AGE && bkey != NONE) {
                 const uint32_t hs = d.block_slot[id];
                 d.hkeys[hs] = KEY_TOMB;
                 d.hvals[hs] = NONE;   // (like an empty slot's: an insertion that takes the slot publishes its id here)
@@ -495,7 +495,9 @@ __device__ __forceinline__ uint32_t regroup_block(const Dev &d, int side, uint32
     if (link != NONE) {
         link_stamp = d.block_stamp[link];
         link_cnt = d.block_acc[link];  // particles of that neighbour in this substep (launch 1's total)
-        link_key = d.block_key[link];  // (an id that was evicted since — and maybe handed out again, to another block — is not this neighbour)
+        // (an id that was evicted since — and maybe handed out again, to another block — is not this neighbour; compared in the launch
+        // behind one that may evict: k_regroup)
+        if (check_keys) link_key = d.block_key[link];
     }
     const bool links_valid = old_ok;
     // ---- stage the new cell ids of the block's previous run (contiguous: cells are consecutive runs); with movers
@@ -567,7 +569,7 @@ __device__ __forceinline__ uint32_t regroup_block(const Dev &d, int side, uint32
         if ((int)o < NN) {
             const int sgn = minus ? -1 : 1;
             int nb[3] = {b[0] + sgn * (int)(o & 1u), b[1] + sgn * (int)((o >> 1) & 1u), b[2] + sgn * (int)((o >> 2) & 1u)};
-            if (link != NONE && link_key != pack_key<D>(nb)) link = NONE;   // (evicted: no longer in the table under that id)
+            if (check_keys && link != NONE && link_key != pack_key<D>(nb)) link = NONE;   // (evicted: no longer in the table under that id)
             if (link != NONE) {
                 known = link;
                 res = link_stamp == epoch ? link : NONE;
@@ -1155,9 +1157,14 @@ template <int D, bool CDF, bool SHARD = false> __global__ __launch_bounds__(SORT
     // no block id was handed out since launch 2 of the previous substep? Then a neighbour that was not in the table is
     // still not in it (rim of the active region: the lookups with the longest probe sequences, every substep)
     const bool no_new_blocks = d.counters[CTR_NINSERT] == d.counters[CTR_NPHYS_SEEN + ((epoch - 1u) & 1u)];
+    // Evictions happen in the substeps whose number is a multiple of EVICT_AGE only (regroup_block): an id noted as "in the table" during
+    // such a launch may have been evicted by another wave of the same launch, so the launch AFTER it compares the keys of the ids it
+    // inherits; every other launch inherits ids that were compared or looked up one substep ago and cannot have been evicted since.
+    // (A counter of evictions sampled inside the launches does not say the same: the wave that samples it is not the first to run.)
+    const bool check_keys = ((epoch - 1u) & (EVICT_AGE - 1u)) == 0u;
     uint32_t movers = 0u;
     for (uint32_t id = wave; id < nphys; id += nwaves)
-        movers += regroup_block<D, CDF, SHARD>(d, side, epoch, id, nphys, have_old != 0, no_new_blocks, s_in[w], s_out[w], s_pid[w]);
+        movers += regroup_block<D, CDF, SHARD>(d, side, epoch, id, nphys, have_old != 0, no_new_blocks, check_keys, s_in[w], s_out[w], s_pid[w]);
     // statistics (wgs_stats.cell_changers): one add per workgroup, the partial counts in cache lines of their own
     if ((threadIdx.x & 63u) == 0u) s_wave[w] = movers;
     __syncthreads();

@@ -123,7 +123,7 @@ enum { CTR_NBLOCKS = 0, CTR_ERRORS = 1, CTR_NPHYS = 2,
        CTR_TICKET = 10,  // sharded runs: workgroups of k_g2p_arrivals that are done (the last one does the bookkeeping)
        CTR_NFREE = 11,   // ids on the free list (Dev::free_ids): blocks launch 2 of the sort evicted from the table
        CTR_NINSERT = 12, // insertions into the table since its last rebuild (never decreases: ids are reused, so the id counter does not say)
-       CTR_NTOMB = 13,   // table slots marked KEY_TOMB since the last rebuild (the host rebuilds the table before they crowd it)
+       CTR_NTOMB = 13,   // table slots marked KEY_TOMB and not reused yet (the host clears the marks before they crowd the table)
        CTR_NPHYS_SEEN = 8,  // [8], [9]: the insertion counter (CTR_NINSERT) as launch 2 of an even / odd substep saw it (kernels_sort.h regroup_block)
        CTR_NVISIT = 64,  // [64 + 32 k], k = 0..7: length of the visit list of XCD k (Dev::visit_list), one cache line each
        CTR_NCPIC = 320,  // [320 + 32 k], k = 0..7: length of list k of the near-collider blocks (Dev::cpic_list), one cache line each
