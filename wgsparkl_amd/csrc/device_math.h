@@ -422,12 +422,15 @@ template <int D> __device__ inline void svd(const float *F, Svd<D> &out) {
             float n1 = 1.0f / sqrtf(b1[0] * b1[0] + b1[1] * b1[1] + b1[2] * b1[2]);
             b1[0] *= n1; b1[1] *= n1; b1[2] *= n1;
             float b2[3] = {e[1] * b1[2] - e[2] * b1[1], e[2] * b1[0] - e[0] * b1[2], e[0] * b1[1] - e[1] * b1[0]};
-            // columns (g+1)%3 and (g+2)%3 receive b1, b2 (g = the good column)
+            // columns (g+1)%3 and (g+2)%3 receive b1, b2 (g = the good column). Written as selects on STATIC elements: with the
+            // assignments inside `if (ok[0]) .. else if (ok[1]) ..` hipcc indexed out.u by a run-time offset, which put the array into
+            // scratch memory — ten scratch stores and loads per particle of every Drucker-Prager kernel, for a path no healthy run takes.
 #pragma unroll
             for (int r = 0; r < 3; r++) {
-                if (ok[0]) { out.u[3 + r] = b1[r]; out.u[6 + r] = b2[r]; }
-                else if (ok[1]) { out.u[6 + r] = b1[r]; out.u[r] = b2[r]; }
-                else { out.u[r] = b1[r]; out.u[3 + r] = b2[r]; }
+                const float c0 = out.u[r], c1 = out.u[3 + r], c2 = out.u[6 + r];
+                out.u[r] = ok[0] ? c0 : (ok[1] ? b2[r] : b1[r]);
+                out.u[3 + r] = ok[0] ? b1[r] : (ok[1] ? c1 : b2[r]);
+                out.u[6 + r] = ok[0] ? b2[r] : (ok[1] ? b1[r] : c2);
             }
         } else if (nbad == 1) {
             // missing column = cross product of the next two (cyclic)
@@ -440,7 +443,9 @@ template <int D> __device__ inline void svd(const float *F, Svd<D> &out) {
             float z[3] = {x[1] * y[2] - x[2] * y[1], x[2] * y[0] - x[0] * y[2], x[0] * y[1] - x[1] * y[0]};
 #pragma unroll
             for (int r = 0; r < 3; r++) {
-                if (!ok[0]) out.u[r] = z[r]; else if (!ok[1]) out.u[3 + r] = z[r]; else out.u[6 + r] = z[r];
+                out.u[r] = !ok[0] ? z[r] : out.u[r];
+                out.u[3 + r] = (ok[0] && !ok[1]) ? z[r] : out.u[3 + r];
+                out.u[6 + r] = (ok[0] && ok[1]) ? z[r] : out.u[6 + r];
             }
         }
     }
