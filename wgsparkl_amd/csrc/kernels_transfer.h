@@ -526,7 +526,7 @@ __device__ unsigned long long g_g2p_prof[WGS_G2P_ROWS][8];
 #endif
 constexpr uint32_t G2P_TWO_PASS_MIN_PARTICLES = WGS_G2P_TWO_PASS_MIN;
 #ifndef WGS_G2P_LIST_PASSES
-#define WGS_G2P_LIST_PASSES 2
+#define WGS_G2P_LIST_PASSES 1
 #endif
 #ifndef WGS_G2P_MANY_PASSES
 #define WGS_G2P_MANY_PASSES 4
