@@ -208,7 +208,11 @@ template <int D, int NT> __device__ __forceinline__ void stage_node_cdf_tile(con
         const int ln = (tt[0] & (BW - 1)) + ((tt[1] & (BW - 1)) << BS) + (D == 3 ? ((tt[2] & (BW - 1)) << (2 * BS)) : 0);
         const uint32_t nb = __shfl(link, o & 7);
         c[k] = NodeCdf{0.f, 0u, NONE, 0u};
-        if (n < TILE && nb != NONE) c[k] = d.node_cdf[(size_t)nb * NPB + ln];
+        // (the lane's part of the address is pinned at the access: hipcc otherwise keeps node_cdf + 16 ln, one 64-bit pair per k, alive
+        // for the whole kernel as loop invariants — and, in the kernels that have no registers to spare, in scratch memory)
+        uint32_t lnp = (uint32_t)ln;
+        asm volatile("" : "+v"(lnp));
+        if (n < TILE && nb != NONE) c[k] = d.node_cdf[(size_t)nb * NPB + lnp];
     }
 #pragma unroll
     for (int k = 0; k < K; k++) {
