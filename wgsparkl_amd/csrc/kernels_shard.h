@@ -114,6 +114,7 @@ template <int D> __device__ inline float4 gather_slabs(const Dev &d, uint32_t b,
 // P2G launch (INLAUNCH: worker = wave behind the P2G workgroups; the slabs are then waited for word by word and gathered
 // with agent-scope loads, like gu_waves in kernels_transfer.h): workers [0, nblk_wk) walk the interface-block list, the
 // others copy the guests.
+template <int D> __device__ inline uint32_t rec_claim(const Dev &d, float *msg, uint32_t key, uint32_t tag, uint32_t epoch, int lane);   // (below)
 template <int D, bool INLAUNCH> __device__ __forceinline__ void pack_face_body(const Dev &d, int side, uint32_t epoch, uint32_t wk, uint32_t nblk_wk, uint32_t nwk, int lane) {
     using H = HaloCfg<D>;
     constexpr int BW = Dim<D>::BW, BS = Dim<D>::BSHIFT, TW = Dim<D>::TW, TILE = Dim<D>::TILE, NN = Dim<D>::NNBR;

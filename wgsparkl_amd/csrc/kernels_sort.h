@@ -441,9 +441,14 @@ template <int D, bool CDF, bool SHARD>
 __device__ __forceinline__ uint32_t regroup_block(const Dev &d, int side, uint32_t epoch, uint32_t id, uint32_t nphys, bool have_old, bool no_new_blocks, bool check_keys,
                                               uint32_t *s_in, uint32_t *s_out, uint32_t *s_pid) {
     constexpr int NN = Dim<D>::NNBR;
-    const int lane = threadIdx.x & 63;
+    int lane = threadIdx.x & 63;
+    asm volatile("" : "+v"(lane));
     const float *in = d.buf[side];
-    const uint32_t idx = id * NPB + lane;
+    // (the lane's part of every per-block index is pinned once per block: hipcc otherwise hoists array + 4 lane, one 64-bit pair per
+    // array, out of the loop over the blocks, keeps the pairs in scratch for want of registers and reloads them — a scratch load and a
+    // wait — in front of the block's first loads: the sort is a chain of dependent round trips, and that was one more)
+    const uint32_t lane_p = (uint32_t)lane;
+    const uint32_t idx = id * NPB + lane_p;
     WGS_PROF_START()
     // ---- first round of loads, all independent: activity stamp, previous runs and links of this block (read before
     // anything of it is overwritten), list heads
@@ -462,7 +467,7 @@ __device__ __forceinline__ uint32_t regroup_block(const Dev &d, int side, uint32
         cdf_class = d.block_cpic[id];
     }
     uint32_t link = NONE;
-    if (lane < 16) link = d.nbr_known[id * 16u + lane];
+    if (lane < 16) link = d.nbr_known[id * 16u + lane_p];
     const GroupLoads grp = block_prefix_loads(d, id, lane);
     if (stamp != epoch) {  // wave-uniform: not active in this substep
         // EVICTION (single-domain data): a block nobody activated for EVICT_AGE substeps leaves the table — its slot is marked KEY_TOMB,
