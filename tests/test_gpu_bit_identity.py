@@ -405,3 +405,39 @@ def test_a_body_crossing_the_grid_evicts_blocks_and_stays_bit_identical_to_the_r
     assert sa["overflow"] == 0 and sb["overflow"] == 0
     assert sa["table_rebuilds"] < sb["table_rebuilds"], (sa["table_rebuilds"], sb["table_rebuilds"])
     assert sa["table_rebuilds"] <= 1 + sa["grid_growths"]     # the first substep (+ one per growth of the grid: none expected)
+
+
+@pytest.mark.parametrize("scene", ["sand3", "paddle"])
+def test_node_cdf_summaries_shared_between_blocks_give_the_bits_of_whole_tile_evaluation(hip_libs, scene, monkeypatch):
+    """Where a collider moves, launch 2 of the sort evaluates every block's OWN nodes against the colliders and lets the block's
+    neighbours know which of them have an affinity (Dev::block_cdf_summ, kernels_sort.h) instead of evaluating the (BW+2)^3 tile of
+    every block — each node up to eight times. The class of a block (listed for the CPIC bodies or not) and everything downstream must
+    be what the whole-tile evaluation gives (WGS_DEBUG=2048), also when no word is ever waited for (WGS_DEBUG=2: every neighbour whose
+    word is late is evaluated locally — the path taken when a neighbour's wave is not resident)."""
+    from helpers import pipeline
+    from wgsparkl_amd import MpmData
+    if scene == "sand3":
+        sc = scenes.reference_sand3()
+        steps = 150
+    else:   # a box swept through a block of elastic material resting on the floor: the set of blocks in reach changes every substep
+        sc = scenes.neo_hookean_cube(n_side=40, with_floor=True)
+        sc["particles"].pos[:, 1] -= sc["particles"].pos[:, 1].min() - 2.5 * sc["cell_width"]
+        lo, hi = sc["particles"].pos.min(0), sc["particles"].pos.max(0)
+        paddle = Collider.cuboid((0.6, 2.0, 6.0), translation=(float(lo[0]) - 1.0, float(0.5 * (lo[1] + hi[1])), float(0.5 * (lo[2] + hi[2]))),
+                                 linvel=(30.0, 0.0, 0.0))
+        sc["colliders"] = list(sc["colliders"]) + [paddle]
+        steps = 200
+    pipe = pipeline(3)
+    def run():
+        data = MpmData.new(pipe, sc["params"], sc["particles"], sc["colliders"], sc["cell_width"], sc["grid_capacity"], sc["model"])
+        pipe.step(data, steps)
+        data.sync()
+        return data.read_particles(), data.stats()
+    a, sa = run()
+    assert sa["overflow"] == 0
+    assert np.any(a.cdf_affinity != 0)   # (somebody is within reach of a collider)
+    for dbg in ("2048", "2"):
+        monkeypatch.setenv("WGS_DEBUG", dbg)
+        b, sb = run()
+        for f in ("pos", "vel", "def_grad", "affine", "dp_state", "cdf_affinity", "cdf_normal", "cdf_dist"):
+            assert np.array_equal(getattr(a, f), getattr(b, f)), (dbg, f)

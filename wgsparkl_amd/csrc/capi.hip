@@ -227,6 +227,7 @@ wgs_status alloc_grid(wgs_data *d) {
     GRID_ALLOC(&dev.slab_epoch, cap);
     GRID_ALLOC(&dev.block_cdf_gen, cap);
     GRID_ALLOC(&dev.block_cpic, cap);
+    GRID_ALLOC(&dev.block_cdf_summ, cap);
     GRID_ALLOC(&dev.cpic_list, (size_t)cap * 8);
     dev.visit_cap = dev.npad / 512u + 2u * cap + 16u;
     GRID_ALLOC(&dev.visit_list, (size_t)dev.visit_cap * 8);
@@ -275,7 +276,7 @@ wgs_status grow_grid(wgs_data *d, uint32_t new_cap) {
     }
     void *old_ptrs[] = {old.hkeys, old.hvals, old.block_key, old.block_slot, old.free_ids, old.block_count, old.block_stamp, old.links_epoch, old.block_acc, old.block_dirty, old.blk_narr, old.blk_arr, old.block_ident, old.active,
                         old.block_start, old.act_info, old.act_cells, old.nbr_plus, old.nbr_minus, old.nbr_known, old.act_src, old.cell_head, old.chunk_a, old.chunk_b, old.group_a, old.group_b,
-                        old.cell_start, old.cell_cursor, old.nodes, old.node_cdf, old.slab, old.slab_epoch, old.block_cdf_gen, old.block_cpic, old.cpic_list, old.visit_list, old.halo_list,
+                        old.cell_start, old.cell_cursor, old.nodes, old.node_cdf, old.slab, old.slab_epoch, old.block_cdf_gen, old.block_cpic, old.block_cdf_summ, old.cpic_list, old.visit_list, old.halo_list,
                         old.imp_slab, old.mesh_min, old.mesh_aff};
     for (void *p : old_ptrs) release_alloc(d, p);
     HIP_TRY(hipMemsetAsync(dev.hkeys, 0xff, sizeof(uint32_t) * ((size_t)dev.hmask + 1), d->stream));
@@ -340,7 +341,7 @@ void fill_collider(ColliderDev &c, const wgs_collider &in) {
     for (int k = 0; k < 3; k++) c.com[k] = in.com[k];
 }
 
-constexpr uint32_t WGS_LAUNCH_SHAPE_SWITCHES = 128u | 1024u | 4096u | 8192u | 16384u | 32768u | 65536u | 131072u | 262144u | 524288u | 1048576u | 4194304u | 8388608u | 16777216u;  // WGS_DEBUG bits the shipped library honours
+constexpr uint32_t WGS_LAUNCH_SHAPE_SWITCHES = 2u | 128u | 1024u | 2048u | 4096u | 8192u | 16384u | 32768u | 65536u | 131072u | 262144u | 524288u | 1048576u | 4194304u | 8388608u | 16777216u;  // WGS_DEBUG bits the shipped library honours
 constexpr uint32_t P2G_SMALL_BUDGET_MIN_PARTICLES = 600000;  // one-way CPIC P2G body at 168 VGPRs from this size on
 #ifndef WGS_REGROUP_ROUNDS
 #define WGS_REGROUP_ROUNDS 4u
@@ -792,7 +793,12 @@ template <bool TS> wgs_status enqueue_substep(wgs_data *d, int ts_slot, int part
                 const uint32_t nreg = std::max(1u, std::min((dev.cap + 3u) / 4u, WGS_REGROUP_ROUNDS * ((uint32_t)grid_for(d, 4) - std::min(nscan, (uint32_t)grid_for(d, 2)))));
                 const dim3 g(nscan + nreg);
                 const int have_old = use_rebin ? 1 : 0;
-                if (fused_cdf && dev.sharded) hipLaunchKernelGGL((k_regroup<D, true, true>), g, dim3(SORT_THREADS), 0, s, dev, side, epoch, nscan, have_old);
+                // (summ: every block within reach of a collider is evaluated substep after substep — each evaluates its own nodes and
+                // tells its neighbours, kernels_sort.h block_cdf_summ; with colliders at rest: the instantiation without)
+                const bool summ = (dev.cdf_moving != 0u || dev.cdf_gen == 0u) && !(dev.dbg & 2048u);
+                if (fused_cdf && dev.sharded && summ) hipLaunchKernelGGL((k_regroup<D, true, true, true>), g, dim3(SORT_THREADS), 0, s, dev, side, epoch, nscan, have_old);
+                else if (fused_cdf && dev.sharded) hipLaunchKernelGGL((k_regroup<D, true, true>), g, dim3(SORT_THREADS), 0, s, dev, side, epoch, nscan, have_old);
+                else if (fused_cdf && summ) hipLaunchKernelGGL((k_regroup<D, true, false, true>), g, dim3(SORT_THREADS), 0, s, dev, side, epoch, nscan, have_old);
                 else if (fused_cdf) hipLaunchKernelGGL((k_regroup<D, true, false>), g, dim3(SORT_THREADS), 0, s, dev, side, epoch, nscan, have_old);
                 else if (dev.sharded) hipLaunchKernelGGL((k_regroup<D, false, true>), g, dim3(SORT_THREADS), 0, s, dev, side, epoch, nscan, have_old);
                 else hipLaunchKernelGGL((k_regroup<D, false, false>), g, dim3(SORT_THREADS), 0, s, dev, side, epoch, nscan, have_old);
@@ -1100,6 +1106,8 @@ static wgs_status create_impl(wgs_pipeline *pipeline, const wgs_sim_params *para
     dev.model = WGS_MODEL_COROTATED;
     // Developer switches (read once, here; 0 in production): A/B of launch shapes, SAME results — 128 = full k_bin on
     // every substep (no k_rebin), 1024 = no eviction of long-inactive blocks from the table (it is rebuilt when the ids run out instead),
+    // 2048 = launch 2 of the sort never shares node-cdf summaries between neighbouring blocks (every wave evaluates its whole tile),
+    // 2 = ... shares them but never waits for one (a neighbour's word that is not there at the first look is evaluated locally),
     // 4096 = the two G2P bodies as two launches, 8192 = the two P2G bodies always as two launches, 16384 = never the
     // spill-free variant of the plastic G2P pair, 32768 = never the small register budget of the one-way P2G pair,
     // 65536 = never the uniform-material mode (the per-particle constants always travel with the particle), 131072 = the
@@ -1463,6 +1471,7 @@ wgs_status wgs_set_collider_poses(wgs_data *d, const wgs_pose *poses, const floa
 wgs_status wgs_set_body_velocities(wgs_data *d, const wgs_velocity *vels, size_t n) {
     if (!d || (!vels && n)) return fail(WGS_ERR_INVALID_ARGUMENT, "NULL argument");
     if (n > d->dev.n_colliders) return fail(WGS_ERR_INVALID_ARGUMENT, "more velocities than colliders");
+    const uint32_t moving_before = d->moving_mask;
     for (size_t i = 0; i < n; i++) {
         ColliderDev &c = d->host_colliders[i];
         for (int k = 0; k < 3; k++) c.linvel[k] = vels[i].linear[k];
@@ -1473,6 +1482,7 @@ wgs_status wgs_set_body_velocities(wgs_data *d, const wgs_velocity *vels, size_t
                 d->moving_mask |= 1u << i;
             }
     }
+    if (d->moving_mask != moving_before) d->cdf_generation++;   // (what keeps of a block's node cdfs depends on which colliders move)
     static_assert(offsetof(ColliderDev, angvel) - offsetof(ColliderDev, linvel) == 12, "linvel|angvel contiguous");
     if (d->bodies_move) {
         wgs_status st = enable_impulses(d);
@@ -1486,6 +1496,7 @@ wgs_status wgs_set_body_mass_properties(wgs_data *d, const wgs_mass_properties *
     if (!d || (!mp && n)) return fail(WGS_ERR_INVALID_ARGUMENT, "NULL argument");
     if (n > d->dev.n_colliders) return fail(WGS_ERR_INVALID_ARGUMENT, "more mass properties than colliders");
     bool dynamic = false;
+    const uint32_t moving_before = d->moving_mask;
     for (size_t i = 0; i < n; i++) {
         BodyDev &b = d->host_bodies[i];
         for (int k = 0; k < 3; k++) b.inv_mass[k] = mp[i].inv_mass[k];
@@ -1499,6 +1510,7 @@ wgs_status wgs_set_body_mass_properties(wgs_data *d, const wgs_mass_properties *
         if (dyn) d->moving_mask |= 1u << i;
         dynamic = dynamic || dyn;
     }
+    if (d->moving_mask != moving_before) d->cdf_generation++;   // (what keeps of a block's node cdfs depends on which colliders move)
     d->bodies_move = d->bodies_move || dynamic;
     if (d->bodies_move) {
         wgs_status st = enable_impulses(d);

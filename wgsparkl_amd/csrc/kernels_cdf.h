@@ -124,12 +124,12 @@ template <int D> __device__ inline bool project_local_on_boundary(const Collider
 // grid_update_cdf.wgsl:16-39 + collide.wgsl:23-56 for one node at world position pt: a pure function of
 // the node position and the collider poses.
 // `which`: bit i clear = collider i is known to be out of reach of this node (its vote would be empty): skipped.
-template <int D> __device__ inline NodeCdf node_cdf_eval(const Dev &d, const float *pt, uint32_t which = 0xffffu) {
-    const float cap = d.h * 1.5f;
+template <int D> __device__ inline NodeCdf node_cdf_eval(const ColliderDev *colliders, uint32_t n_colliders, float h, const float *pt, uint32_t which) {
+    const float cap = h * 1.5f;
     NodeCdf cdf = {1.0e10f, 0u, NONE, 0u};
-    for (uint32_t i = 0; i < d.n_colliders && i < 16u; i++) {
+    for (uint32_t i = 0; i < n_colliders && i < 16u; i++) {
         if (!((which >> i) & 1u)) continue;  // (wave-uniform in k_setup_scatter)
-        const ColliderDev &c = d.colliders[i];
+        const ColliderDev &c = colliders[i];
         if (c.shape_type >= 3u) continue;  // mesh shapes have no analytic projection (collide.wgsl:36-38)
         float pl[D], projl[D], proj[D];
         pose_to_local<D>(c, pt, pl);
@@ -153,6 +153,9 @@ template <int D> __device__ inline NodeCdf node_cdf_eval(const Dev &d, const flo
     return cdf;
 }
 
+template <int D> __device__ inline NodeCdf node_cdf_eval(const Dev &d, const float *pt, uint32_t which = 0xffffu) {
+    return node_cdf_eval<D>(d.colliders, d.n_colliders, d.h, pt, which);
+}
 // Solve the symmetric (N x N) system M x = r by LDL^T without pivoting (M is a
 // weighted Gram matrix, positive definite whenever its determinant passes the
 // reference's 1e-8 test). The reference uses wgebra Inv::inv3/inv4 (g2p_cdf.wgsl:236,242).

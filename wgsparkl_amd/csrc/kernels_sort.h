@@ -437,12 +437,15 @@ __device__ inline void block_prefix(const Dev &d, uint32_t epoch, uint32_t id, i
 // links are one epoch old describe its previous runs: that is where the stayers are); otherwise every particle is
 // on a list.
 // Returns the number of particles of the block's new run that changed cell in the last step (statistics, wave-uniform).
-template <int D, bool CDF, bool SHARD>
-__device__ __forceinline__ uint32_t regroup_block(const Dev &d, int side, uint32_t epoch, uint32_t id, uint32_t nphys, bool have_old, bool no_new_blocks, bool check_keys,
-                                              uint32_t *s_in, uint32_t *s_out, uint32_t *s_pid) {
+template <int D, bool CDF, bool SHARD, bool SUMM>
+__device__ __forceinline__ uint32_t regroup_block(const Dev &d, int side, uint32_t epoch_of_launch, uint32_t id, uint32_t nphys, bool have_old, bool no_new_blocks, bool check_keys,
+                                              uint32_t *s_in, uint32_t *s_out, uint32_t *s_pid, ColliderDev *cols, bool &cols_staged) {
     constexpr int NN = Dim<D>::NNBR;
     int lane = threadIdx.x & 63;
     asm volatile("" : "+v"(lane));
+    // (and the substep number: what is stored of it — stamps, notes — would otherwise sit in vector registers, or scratch, for the whole launch)
+    uint32_t epoch = epoch_of_launch;
+    if constexpr (SUMM) asm volatile("" : "+s"(epoch));
     const float *in = d.buf[side];
     // (the lane's part of every per-block index is pinned once per block: hipcc otherwise hoists array + 4 lane, one 64-bit pair per
     // array, out of the loop over the blocks, keeps the pairs in scratch for want of registers and reloads them — a scratch load and a
@@ -461,10 +464,11 @@ __device__ __forceinline__ uint32_t regroup_block(const Dev &d, int side, uint32
     const uint32_t bstart_old = d.block_start[id], ident = d.block_ident[id];
     const uint32_t narr = d.blk_narr[id];                                 // arrivals from other blocks ...
     uint32_t a_ent = NONE;                                                // ... lane's entry of their array (fetched when there are any)
-    uint32_t cdf_seen = 0u, cdf_class = 0u;
+    uint32_t cdf_seen = 0u, cdf_class = 0u, cdf_summ = 0u;
     if constexpr (CDF) {
         cdf_seen = d.block_cdf_gen[id];
         cdf_class = d.block_cpic[id];
+        if constexpr (SUMM) cdf_summ = d.block_cdf_summ[id];
     }
     uint32_t link = NONE;
     if (lane < 16) link = d.nbr_known[id * 16u + lane_p];
@@ -615,6 +619,16 @@ __device__ __forceinline__ uint32_t regroup_block(const Dev &d, int side, uint32
     // is outside. One projection per collider instead of (BW+2)^D.
     auto reach_mask = [&](uint32_t which) {   // bit i: collider i (of `which`) can reach a node of this tile
         constexpr int BW = Dim<D>::BW, TW = Dim<D>::TW;
+        if (SUMM && !cols_staged) {   // (wave-uniform; this wave reads what it wrote itself — another wave's copy holds the same words)
+            const uint32_t nw = min(d.n_colliders, 16u) * (uint32_t)(sizeof(ColliderDev) / 4u);
+            for (uint32_t i = (uint32_t)lane; i < nw; i += 64u)
+                __hip_atomic_store(&reinterpret_cast<uint32_t *>(cols)[i], reinterpret_cast<const uint32_t *>(d.colliders)[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+            // (orders the lanes' stores before the reads below for the compiler; in hardware a wave's LDS accesses are served in order)
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            cols_staged = true;
+        }
         uint32_t near = 0u;
         float ctr[D];
 #pragma unroll
@@ -622,7 +636,7 @@ __device__ __forceinline__ uint32_t regroup_block(const Dev &d, int side, uint32
         const float reach = (0.5f * (float)(TW - 1) + 1.5f) * d.h * (D == 3 ? 1.7320508f : 1.4142136f) * 1.001f;
         for (uint32_t i = 0; i < d.n_colliders && i < 16u; i++) {
             if (!((which >> i) & 1u)) continue;
-            const ColliderDev &c = d.colliders[i];
+            const ColliderDev &c = SUMM ? cols[i] : d.colliders[i];   // (SUMM: the copy in LDS)
             if (c.shape_type >= 3u) continue;
             float pl[D], projl[D], proj[D];
             pose_to_local<D>(c, ctr, pl);
@@ -648,52 +662,155 @@ __device__ __forceinline__ uint32_t regroup_block(const Dev &d, int side, uint32
         cdf_cached = cdf_cached && near_moving == 0u;
         own_cached = own_cached && near_moving == 0u;
     }
-    if (cdf_cached) {
-        const bool any = cdf_class != 0u;
-        if (lane == 0 && any) d.cpic_list[(size_t)(id & 7u) * d.cap + atomicAdd(&d.counters[ctr_ncpic(id & 7u, epoch)], 1u)] = id;
-        listed = any;
-        pc_flag = any ? CELL_LISTED : 0u;
-    } else if (own_cached) {
-        // (nothing to do: its nodes are what they were, it holds no particle)
-    } else if (CDF WGS_ABLATE_AND(!(d.dbg & (1u << 21)))) {
-        constexpr int BW = Dim<D>::BW, BS = Dim<D>::BSHIFT, TW = Dim<D>::TW, TILE = Dim<D>::TILE;
-        uint32_t mine = 0u;
-        const uint32_t near = reach_mask(0xffffu);  // bit i: collider i can reach a node of this tile
-        if (near == 0u) {
-            // no collider in reach of the tile (nearly every block): its own 64 nodes get the "far" cdf — lane = node —
-            // and the rim, which belongs to the neighbours, is theirs to write
-            d.node_cdf[(size_t)id * NPB + (uint32_t)lane] = NodeCdf{1.0e10f, 0u, NONE, 0u};
-        } else if (bcount == 0u) {   // (no particles: its own nodes, lane = node)
-            float pt[D];
-            int t[3] = {lane & (BW - 1), (lane >> BS) & (BW - 1), D == 3 ? (lane >> (2 * BS)) : 0};
-#pragma unroll
-            for (int k = 0; k < D; k++) pt[k] = (float)(b[k] * BW + t[k]) * d.h;
-            const NodeCdf c = node_cdf_eval<D>(d, pt, near);
-            d.node_cdf[(size_t)id * NPB + (uint32_t)lane] = c;
-            mine |= c.affinities;
-        } else
-        for (int n = lane; n < ((TILE + 63) / 64) * 64; n += 64) {
-            int t[3] = {n % TW, (n / TW) % TW, D == 3 ? n / (TW * TW) : 0};
-            const int o = (t[0] >= BW ? 1 : 0) | (t[1] >= BW ? 2 : 0) | (t[2] >= BW ? 4 : 0);
-            const uint32_t nb = __shfl(res, o & 7);        // "+" links live in lanes 0..7
-            if (n < TILE && nb != NONE) {                  // nodes of blocks that are not active do not exist
+    if constexpr (!SUMM) {
+        if (cdf_cached) {
+            const bool any = cdf_class != 0u;
+            if (lane == 0 && any) d.cpic_list[(size_t)(id & 7u) * d.cap + atomicAdd(&d.counters[ctr_ncpic(id & 7u, epoch)], 1u)] = id;
+            listed = any;
+            pc_flag = any ? CELL_LISTED : 0u;
+        } else if (own_cached) {
+            // (nothing to do: its nodes are what they were, it holds no particle)
+        } else if (CDF WGS_ABLATE_AND(!(d.dbg & (1u << 21)))) {
+            constexpr int BW = Dim<D>::BW, BS = Dim<D>::BSHIFT, TW = Dim<D>::TW, TILE = Dim<D>::TILE;
+            uint32_t mine = 0u;
+            const uint32_t near = reach_mask(0xffffu);  // bit i: collider i can reach a node of this tile
+            if (near == 0u) {
+                // no collider in reach of the tile (nearly every block): its own 64 nodes get the "far" cdf — lane = node —
+                // and the rim, which belongs to the neighbours, is theirs to write
+                d.node_cdf[(size_t)id * NPB + (uint32_t)lane] = NodeCdf{1.0e10f, 0u, NONE, 0u};
+            } else if (bcount == 0u) {   // (no particles: its own nodes, lane = node)
                 float pt[D];
+                int t[3] = {lane & (BW - 1), (lane >> BS) & (BW - 1), D == 3 ? (lane >> (2 * BS)) : 0};
 #pragma unroll
                 for (int k = 0; k < D; k++) pt[k] = (float)(b[k] * BW + t[k]) * d.h;
                 const NodeCdf c = node_cdf_eval<D>(d, pt, near);
-                if (o == 0) d.node_cdf[(size_t)id * NPB + (t[0] + (t[1] << BS) + (D == 3 ? (t[2] << (2 * BS)) : 0))] = c;
+                d.node_cdf[(size_t)id * NPB + (uint32_t)lane] = c;
                 mine |= c.affinities;
+            } else
+            for (int n = lane; n < ((TILE + 63) / 64) * 64; n += 64) {
+                int t[3] = {n % TW, (n / TW) % TW, D == 3 ? n / (TW * TW) : 0};
+                const int o = (t[0] >= BW ? 1 : 0) | (t[1] >= BW ? 2 : 0) | (t[2] >= BW ? 4 : 0);
+                const uint32_t nb = __shfl(res, o & 7);        // "+" links live in lanes 0..7
+                if (n < TILE && nb != NONE) {                  // nodes of blocks that are not active do not exist
+                    float pt[D];
+#pragma unroll
+                    for (int k = 0; k < D; k++) pt[k] = (float)(b[k] * BW + t[k]) * d.h;
+                    const NodeCdf c = node_cdf_eval<D>(d, pt, near);
+                    if (o == 0) d.node_cdf[(size_t)id * NPB + (t[0] + (t[1] << BS) + (D == 3 ? (t[2] << (2 * BS)) : 0))] = c;
+                    mine |= c.affinities;
+                }
             }
+            const bool any = __ballot(mine != 0u) != 0ull;
+            if (lane == 0) {
+                d.block_cpic[id] = any ? 1u : 0u;
+                // (kept for the coming substeps only when no collider that moves is in reach)
+                if (d.cdf_gen != 0u) d.block_cdf_gen[id] = (near & d.cdf_moving) == 0u ? (d.cdf_gen | (bcount > 0u ? CDF_FULL : 0u)) : 0u;
+                if (any && bcount > 0u) d.cpic_list[(size_t)(id & 7u) * d.cap + atomicAdd(&d.counters[ctr_ncpic(id & 7u, epoch)], 1u)] = id;
+            }
+            listed = any && bcount > 0u;
+            pc_flag = any ? CELL_LISTED : 0u;
         }
-        const bool any = __ballot(mine != 0u) != 0ull;
-        if (lane == 0) {
-            d.block_cpic[id] = any ? 1u : 0u;
-            // (kept for the coming substeps only when no collider that moves is in reach)
-            if (d.cdf_gen != 0u) d.block_cdf_gen[id] = (near & d.cdf_moving) == 0u ? (d.cdf_gen | (bcount > 0u ? CDF_FULL : 0u)) : 0u;
-            if (any && bcount > 0u) d.cpic_list[(size_t)(id & 7u) * d.cap + atomicAdd(&d.counters[ctr_ncpic(id & 7u, epoch)], 1u)] = id;
+    } else {
+        // The (BW+2)^D tile of a block = its own BW^D nodes + the first two layers of its "+" neighbours' — the same node is in the tiles of
+        // up to 2^D blocks, and a wave that evaluated its whole tile (six rounds of 64 nodes against every collider in reach — 10 us, the
+        // slowest waves of this launch wherever a collider MOVES: the reference's sand3) did 5.4 times the work there is. Every wave
+        // evaluates its OWN nodes, one round, and publishes what its "-" neighbours want to know of them — Dev::block_cdf_summ: per offset o,
+        // "some own node in the first BW+2-BW layers along the axes of o has an affinity" — under this substep's number; a particle-bearing
+        // block then reads its "+" neighbours' words. A word that does not come within a few microseconds (the neighbour's wave is not
+        // resident: more blocks than wave slots) is not waited for any longer: the wave evaluates that neighbour's part of its tile itself,
+        // as before — same loop, same code. The class is the same either way: an affinity bit of a node does not depend on whose reach mask
+        // it was evaluated under (a collider outside the mask gives no node of that tile an affinity).
+        // SUMM is chosen by the host where blocks ARE evaluated substep after substep — a collider moves, or nothing keeps (Dev::cdf_gen 0).
+        // With colliders at rest a block is evaluated once in its life and the words would serve nobody; that instantiation is the code
+        // above, untouched: compiled into one kernel with it, this stage cost the launch 4 us of 57 at 16 M particles (registers).
+        constexpr uint32_t SUMM_TAG = 0xffffffu;
+        auto publish_summ = [&](uint32_t bits) {
+            if (lane == 0) __hip_atomic_store(&d.block_cdf_summ[id], ((epoch & SUMM_TAG) << 8) | bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        };
+        if (cdf_cached) {
+            const bool any = cdf_class != 0u;
+            if (lane == 0 && any) d.cpic_list[(size_t)(id & 7u) * d.cap + atomicAdd(&d.counters[ctr_ncpic(id & 7u, epoch)], 1u)] = id;
+            listed = any;
+            pc_flag = any ? CELL_LISTED : 0u;
+            publish_summ(cdf_summ & 0xffu);   // (its nodes are what they were)
+        } else if (own_cached) {
+            publish_summ(cdf_summ & 0xffu);   // (nothing else to do: its nodes are what they were, it holds no particle)
+        } else if (CDF WGS_ABLATE_AND(!(d.dbg & (1u << 21)))) {
+            constexpr int BW = Dim<D>::BW, BS = Dim<D>::BSHIFT, TW = Dim<D>::TW, TILE = Dim<D>::TILE;
+            constexpr int ROUNDS = (TILE + 63) / 64;
+            const uint32_t near = reach_mask(0xffffu);  // bit i: collider i can reach a node of this tile
+            bool any = false;
+            if (near == 0u) {
+                // no collider in reach of the tile (nearly every block): its own 64 nodes get the "far" cdf — lane = node —
+                // and the rim, which belongs to the neighbours, is theirs to write
+                d.node_cdf[(size_t)id * NPB + (uint32_t)lane] = NodeCdf{1.0e10f, 0u, NONE, 0u};
+                publish_summ(0u);
+            } else {
+                uint32_t parts = 1u;   // bit o: the nodes the tile holds of the "+o" neighbour are to be evaluated here (0: the block's own)
+                uint32_t mine = 0u;
+#pragma unroll 1
+                for (int it = 0; it <= ROUNDS; it++) {   // it = 0: the own nodes, lane = node; it >= 1: round it - 1 over the tile (fallback)
+                    if (it == 1) {   // (wave-uniform)
+                        uint32_t bits = 0u;
+                        const int t0[3] = {lane & (BW - 1), (lane >> BS) & (BW - 1), D == 3 ? (lane >> (2 * BS)) : 0};
+#pragma unroll
+                        for (int o = 0; o < NN; o++) {
+                            bool in = mine != 0u;
+#pragma unroll
+                            for (int k = 0; k < D; k++)
+                                if ((o >> k) & 1) in = in && t0[k] < TW - BW;
+                            bits |= __ballot(in) != 0ull ? (1u << o) : 0u;
+                        }
+                        publish_summ(bits);
+                        any = (bits & 1u) != 0u;
+                        parts = 0u;
+                        if (!any && bcount > 0u) {   // (a block without particles: nobody asks for its class)
+                            const uint32_t nb = lane >= 1 && lane < NN ? res : NONE;   // "+" links live in lanes 0..7
+                            const unsigned long long t_start = wall_clock64();
+                            for (;;) {
+                                uint32_t w = 0u;
+                                if (nb != NONE) w = __hip_atomic_load(&d.block_cdf_summ[nb], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                const bool have = nb != NONE && (w >> 8) == (epoch & SUMM_TAG);
+                                any = __ballot(have && ((w >> lane) & 1u) != 0u) != 0ull;
+                                parts = (uint32_t)__ballot(nb != NONE && !have);
+                                if (any || parts == 0u || (d.dbg & 2u) || wall_clock64() - t_start > 400ull) break;   // (100 MHz: 4 us; WGS_DEBUG bit 1: no wait at all — tests)
+                                __builtin_amdgcn_s_sleep(8);
+                            }
+                            if (any) parts = 0u;
+                        }
+                        if (parts == 0u) break;
+                        mine = 0u;
+                    }
+                    int t[3], o = 0;
+                    bool active = true;
+                    if (it == 0) {
+                        t[0] = lane & (BW - 1); t[1] = (lane >> BS) & (BW - 1); t[2] = D == 3 ? (lane >> (2 * BS)) : 0;
+                    } else {
+                        const int n = lane + 64 * (it - 1);
+                        t[0] = n % TW; t[1] = (n / TW) % TW; t[2] = D == 3 ? n / (TW * TW) : 0;
+                        o = (t[0] >= BW ? 1 : 0) | (t[1] >= BW ? 2 : 0) | (t[2] >= BW ? 4 : 0);
+                        active = n < TILE && ((parts >> o) & 1u) != 0u;
+                    }
+                    if (active) {
+                        float pt[D];
+#pragma unroll
+                        for (int k = 0; k < D; k++) pt[k] = (float)(b[k] * BW + t[k]) * d.h;
+                        const NodeCdf c = node_cdf_eval<D>(cols, d.n_colliders, d.h, pt, near);
+                        if (it == 0) d.node_cdf[(size_t)id * NPB + (uint32_t)lane] = c;
+                        mine |= c.affinities;
+                    }
+                }
+                if (parts != 0u) any = __ballot(mine != 0u) != 0ull;   // (the fallback ran)
+            }
+            if (lane == 0) {
+                d.block_cpic[id] = any ? 1u : 0u;
+                // (kept for the coming substeps only when no collider that moves is in reach)
+                if (d.cdf_gen != 0u) d.block_cdf_gen[id] = (near & d.cdf_moving) == 0u ? (d.cdf_gen | (bcount > 0u ? CDF_FULL : 0u)) : 0u;
+                if (any && bcount > 0u) d.cpic_list[(size_t)(id & 7u) * d.cap + atomicAdd(&d.counters[ctr_ncpic(id & 7u, epoch)], 1u)] = id;
+            }
+            listed = any && bcount > 0u;
+            pc_flag = any ? CELL_LISTED : 0u;
         }
-        listed = any && bcount > 0u;
-        pc_flag = any ? CELL_LISTED : 0u;
     }
     WGS_PROF(3)
     // ---- pass 1: members of the new run = stayers of the previous run + arrivals. Arrivals from OTHER blocks are on the
@@ -1146,7 +1263,7 @@ __device__ __forceinline__ uint32_t regroup_block(const Dev &d, int side, uint32
 #define WGS_REGROUP_WPE 4
 #endif
 // SHARD: the data is one slab of a decomposition (a template parameter: the single-domain kernel carries no register for it)
-template <int D, bool CDF, bool SHARD = false> __global__ __launch_bounds__(SORT_THREADS, WGS_REGROUP_WPE) void k_regroup(Dev d, int side, uint32_t epoch, uint32_t nscan, int have_old) {
+template <int D, bool CDF, bool SHARD = false, bool SUMM = false> __global__ __launch_bounds__(SORT_THREADS, WGS_REGROUP_WPE) void k_regroup(Dev d, int side, uint32_t epoch, uint32_t nscan, int have_old) {
     __shared__ unsigned long long s_wave[SORT_THREADS / 64];
     __shared__ unsigned long long s_bcast;
     __shared__ uint32_t s_in[SORT_THREADS / 64][RUNCAP], s_out[SORT_THREADS / 64][RUNCAP], s_pid[SORT_THREADS / 64][RUNCAP];
@@ -1155,10 +1272,16 @@ template <int D, bool CDF, bool SHARD = false> __global__ __launch_bounds__(SORT
         scan_chunk<SHARD>(d, epoch, blockIdx.x, nscan, s_wave, &s_bcast);
         return;
     }
+    // (the colliders' poses and shapes, for the node cdf: a copy per workgroup — from global memory every collider is a round trip of its
+    // own in front of the first node, six of them in the reference's sand3)
+    // Filled by the first wave of the workgroup that needs it and by every other that does (regroup_block: the same words, no barrier —
+    // most launches need none: the blocks' cdfs keep from substep to substep unless a collider moves).
+    __shared__ ColliderDev s_cols[SUMM ? 16 : 1];
+    bool cols_staged = false;
     const uint32_t nphys = min(d.counters[CTR_NPHYS], d.cap);
     const uint32_t wave = ((blockIdx.x - nscan) * SORT_THREADS + threadIdx.x) >> 6;
     const uint32_t nwaves = ((gridDim.x - nscan) * SORT_THREADS) >> 6;
-    const int w = threadIdx.x >> 6;
+    const int w = SUMM ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) : (int)(threadIdx.x >> 6);   // (uniform: the wave's LDS stages are scalar bases, not per-lane addresses held for the whole launch)
     // no block id was handed out since launch 2 of the previous substep? Then a neighbour that was not in the table is
     // still not in it (rim of the active region: the lookups with the longest probe sequences, every substep)
     const bool no_new_blocks = d.counters[CTR_NINSERT] == d.counters[CTR_NPHYS_SEEN + ((epoch - 1u) & 1u)];
@@ -1169,7 +1292,7 @@ template <int D, bool CDF, bool SHARD = false> __global__ __launch_bounds__(SORT
     const bool check_keys = ((epoch - 1u) & (EVICT_AGE - 1u)) == 0u;
     uint32_t movers = 0u;
     for (uint32_t id = wave; id < nphys; id += nwaves)
-        movers += regroup_block<D, CDF, SHARD>(d, side, epoch, id, nphys, have_old != 0, no_new_blocks, check_keys, s_in[w], s_out[w], s_pid[w]);
+        movers += regroup_block<D, CDF, SHARD, SUMM>(d, side, epoch, id, nphys, have_old != 0, no_new_blocks, check_keys, s_in[w], s_out[w], s_pid[w], s_cols, cols_staged);
     // statistics (wgs_stats.cell_changers): one add per workgroup, the partial counts in cache lines of their own
     if ((threadIdx.x & 63u) == 0u) s_wave[w] = movers;
     __syncthreads();

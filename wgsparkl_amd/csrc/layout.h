@@ -221,6 +221,10 @@ struct Dev {
                            // the same launch (kernels_transfer.h): written after the slab's write-through stores have been acknowledged
     uint32_t *block_cdf_gen;  // cap: generation (Dev::cdf_gen) under which block_cpic / node_cdf of the block were last computed
     uint32_t *block_cpic;     // cap: some node of the block's (BW+2)^D tile has non-zero affinity
+    uint32_t *block_cdf_summ; // cap: (epoch & 0xffffff) << 8 | bit o: some OWN node of the block with coordinate <= BW+2-BW-1 on every axis set in o has
+                              // non-zero affinity — what the tile of the block's "-o" neighbour holds of this block. Published (agent scope) by the
+                              // block's wave of launch 2 of the sort as soon as its 64 nodes are evaluated; a neighbour that finds the word of this
+                              // substep does not evaluate those nodes again (kernels_sort.h)
     uint32_t *cpic_list;      // 8 x cap: particle-bearing blocks with block_cpic set; list k = (block id & 7) at [k * cap, + counters[CTR_NCPIC + 32 k]):
                               // eight lists because thousands of returning atomics on ONE counter serialise in the fabric
     uint2 *visit_list;        // 8 x visit_cap: (listed block, chunk of 64 sorted particles that holds some of its particles); list k, at
