@@ -634,10 +634,7 @@ __device__ __forceinline__ uint32_t regroup_block(const Dev &d, int side, uint32
 #pragma unroll
         for (int k = 0; k < D; k++) ctr[k] = ((float)(b[k] * BW) + 0.5f * (float)(TW - 1)) * d.h;
         const float reach = (0.5f * (float)(TW - 1) + 1.5f) * d.h * (D == 3 ? 1.7320508f : 1.4142136f) * 1.001f;
-        for (uint32_t i = 0; i < d.n_colliders && i < 16u; i++) {
-            if (!((which >> i) & 1u)) continue;
-            const ColliderDev &c = SUMM ? cols[i] : d.colliders[i];   // (SUMM: the copy in LDS)
-            if (c.shape_type >= 3u) continue;
+        auto reaches = [&](const ColliderDev &c) {
             float pl[D], projl[D], proj[D];
             pose_to_local<D>(c, ctr, pl);
             const bool inside = project_local_on_boundary<D>(c, pl, projl);
@@ -645,7 +642,20 @@ __device__ __forceinline__ uint32_t regroup_block(const Dev &d, int side, uint32
             float n2 = 0.f;
 #pragma unroll
             for (int k = 0; k < D; k++) n2 += (proj[k] - ctr[k]) * (proj[k] - ctr[k]);
-            near |= (inside || !(n2 > reach * reach)) ? (1u << i) : 0u;
+            return inside || !(n2 > reach * reach);
+        };
+        if constexpr (SUMM) {   // lane = collider: one projection's time for all of them (the same arithmetic per collider)
+            const uint32_t i = (uint32_t)lane & 15u;
+            bool r = false;
+            if (lane < 16 && i < d.n_colliders && ((which >> i) & 1u) && cols[i].shape_type < 3u) r = reaches(cols[i]);
+            near = (uint32_t)__ballot(r) & 0xffffu;
+        } else {
+            for (uint32_t i = 0; i < d.n_colliders && i < 16u; i++) {
+                if (!((which >> i) & 1u)) continue;
+                const ColliderDev &c = d.colliders[i];
+                if (c.shape_type >= 3u) continue;
+                near |= reaches(c) ? (1u << i) : 0u;
+            }
         }
         return near;
     };
