@@ -441,3 +441,40 @@ def test_node_cdf_summaries_shared_between_blocks_give_the_bits_of_whole_tile_ev
         b, sb = run()
         for f in ("pos", "vel", "def_grad", "affine", "dp_state", "cdf_affinity", "cdf_normal", "cdf_dist"):
             assert np.array_equal(getattr(a, f), getattr(b, f)), (dbg, f)
+
+
+@pytest.mark.parametrize("scene", ["sand3", "paddle", "sand2"])
+def test_particle_cdf_by_prologue_waves_of_the_p2g_launch_gives_the_bits_of_the_in_workgroup_prologue(hip_libs, scene, monkeypatch):
+    """With a short near-collider list (as of the host's last look) the paired P2G launch computes the particle cdf of the listed
+    blocks in prologue WAVES, one per visit-list entry, ahead of its workgroups, and hands the quads over inside the launch
+    (written through, counted per block, fetched past the L2: kernels_transfer.h pcdf_waves) instead of in three to six rounds inside
+    each block's CPIC workgroup. Same particles, same arithmetic: the same bits as with WGS_DEBUG=4 (never prologue waves), substep
+    after substep across host looks."""
+    from helpers import pipeline
+    from wgsparkl_amd import MpmData
+    dim = 3
+    if scene == "sand3":
+        sc = scenes.reference_sand3()
+    elif scene == "sand2":
+        sc = scenes.reference_sand2()
+        dim = 2
+    else:
+        sc = scenes.corotated_cube_with_paddle(n_side=32)
+    pipe = pipeline(dim)
+    def run():
+        data = MpmData.new(pipe, sc["params"], sc["particles"], sc["colliders"], sc["cell_width"], sc["grid_capacity"], sc["model"])
+        for _ in range(12):
+            pipe.step(data, 10)
+            data.sync()      # (the host looks at the lists here: the next call sizes its launches from what it saw)
+        st = data.stats()
+        return data.read_particles(), st, (data.read_body_poses() if sc["colliders"] else None)
+    a, sa, ba = run()
+    assert sa["overflow"] == 0 and sa["num_near_collider_blocks"] > 0
+    monkeypatch.setenv("WGS_DEBUG", "4")
+    b, sb, bb = run()
+    for f in ("pos", "vel", "def_grad", "affine", "dp_state", "cdf_affinity", "cdf_normal", "cdf_dist"):
+        assert np.array_equal(getattr(a, f), getattr(b, f)), f
+    if ba is not None:
+        for x, y in zip(ba, bb):
+            for key in x:
+                assert np.array_equal(np.asarray(x[key]), np.asarray(y[key])), key

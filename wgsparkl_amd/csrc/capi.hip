@@ -228,6 +228,7 @@ wgs_status alloc_grid(wgs_data *d) {
     GRID_ALLOC(&dev.block_cdf_gen, cap);
     GRID_ALLOC(&dev.block_cpic, cap);
     GRID_ALLOC(&dev.block_cdf_summ, cap);
+    GRID_ALLOC(&dev.pcdf_done, cap);
     GRID_ALLOC(&dev.cpic_list, (size_t)cap * 8);
     dev.visit_cap = dev.npad / 512u + 2u * cap + 16u;
     GRID_ALLOC(&dev.visit_list, (size_t)dev.visit_cap * 8);
@@ -276,7 +277,7 @@ wgs_status grow_grid(wgs_data *d, uint32_t new_cap) {
     }
     void *old_ptrs[] = {old.hkeys, old.hvals, old.block_key, old.block_slot, old.free_ids, old.block_count, old.block_stamp, old.links_epoch, old.block_acc, old.block_dirty, old.blk_narr, old.blk_arr, old.block_ident, old.active,
                         old.block_start, old.act_info, old.act_cells, old.nbr_plus, old.nbr_minus, old.nbr_known, old.act_src, old.cell_head, old.chunk_a, old.chunk_b, old.group_a, old.group_b,
-                        old.cell_start, old.cell_cursor, old.nodes, old.node_cdf, old.slab, old.slab_epoch, old.block_cdf_gen, old.block_cpic, old.block_cdf_summ, old.cpic_list, old.visit_list, old.halo_list,
+                        old.cell_start, old.cell_cursor, old.nodes, old.node_cdf, old.slab, old.slab_epoch, old.block_cdf_gen, old.block_cpic, old.block_cdf_summ, old.pcdf_done, old.cpic_list, old.visit_list, old.halo_list,
                         old.imp_slab, old.mesh_min, old.mesh_aff};
     for (void *p : old_ptrs) release_alloc(d, p);
     HIP_TRY(hipMemsetAsync(dev.hkeys, 0xff, sizeof(uint32_t) * ((size_t)dev.hmask + 1), d->stream));
@@ -341,7 +342,8 @@ void fill_collider(ColliderDev &c, const wgs_collider &in) {
     for (int k = 0; k < 3; k++) c.com[k] = in.com[k];
 }
 
-constexpr uint32_t WGS_LAUNCH_SHAPE_SWITCHES = 2u | 128u | 1024u | 2048u | 4096u | 8192u | 16384u | 32768u | 65536u | 131072u | 262144u | 524288u | 1048576u | 4194304u | 8388608u | 16777216u;  // WGS_DEBUG bits the shipped library honours
+constexpr uint32_t WGS_LAUNCH_SHAPE_SWITCHES = 2u | 4u | 128u | 1024u | 2048u | 4096u | 8192u | 16384u | 32768u | 65536u | 131072u | 262144u | 524288u | 1048576u | 4194304u | 8388608u | 16777216u;  // WGS_DEBUG bits the shipped library honours
+constexpr uint32_t PCDF_WAVES_MAX_VISITS = 256;   // per XCD list: above, the prologue waves would be a round of work in front of the launch, not a use of idle CUs
 constexpr uint32_t P2G_SMALL_BUDGET_MIN_PARTICLES = 600000;  // one-way CPIC P2G body at 168 VGPRs from this size on
 #ifndef WGS_REGROUP_ROUNDS
 #define WGS_REGROUP_ROUNDS 4u
@@ -349,7 +351,11 @@ constexpr uint32_t P2G_SMALL_BUDGET_MIN_PARTICLES = 600000;  // one-way CPIC P2G
 #ifndef WGS_GU_WG_PER_CU
 #define WGS_GU_WG_PER_CU 8
 #endif
+#ifndef WGS_P2G_PAIR_SMALL_SCENE
+#define WGS_P2G_PAIR_SMALL_SCENE 0u
+#endif
 constexpr uint32_t P2G_PAIR_MIN_BLOCKS = 8;  // near-collider blocks from which P2G runs both bodies in one launch
+constexpr uint32_t P2G_PAIR_ALWAYS_BELOW = WGS_P2G_PAIR_SMALL_SCENE;   // ... and scenes with fewer particles than this pair whatever the list length
 int grid_for(const wgs_data *d, int blocks_per_cu) { return d->pipeline->num_cus * blocks_per_cu; }
 
 // ---- read-back kernels ---------------------------------------------------
@@ -859,29 +865,42 @@ template <bool TS> wgs_status enqueue_substep(wgs_data *d, int ts_slot, int part
             // body — nearly every block — would run at two thirds of its occupancy (C4, 8 M particles: P2G 416 -> 347 us
             // with the two launches). Bit-identical either way (the same body text under -ffp-contract=on).
             const bool big_two_way = d->two_way && n >= P2G_SMALL_BUDGET_MIN_PARTICLES;
+            // Prologue waves (kernels_transfer.h pcdf_waves): the particle cdf of the listed blocks by one wave per visit-list entry in front
+            // of the paired launch, while the lists are short enough for the idle part of the chip to take them at once (as of the
+            // host's last look: the waves stride over whatever the lists hold now). Single-domain data only: a slab's pack waves read
+            // the guests' quads inside the launch. WGS_DEBUG bit 2 (value 4) = never.
+            uint32_t npro = 0u;
+            if (d->cpic && !dev.sharded && d->last_nvisit != UINT32_MAX && d->last_nvisit != 0u && d->last_nvisit <= PCDF_WAVES_MAX_VISITS && !(dev.dbg & 4u))
+                npro = 8u * ((std::min(d->last_nvisit + 8u, dev.visit_cap) + NW - 1u) / NW);
+            dev.pcdf_waves = 0u;
 #define WGS_P2G_PAIR(TW, WPE)                                                                                                          \
     do {                                                                                                                               \
-        const dim3 pg(2u * p2g_wgs + ride);                                                                                            \
-        if (gum == 2) hipLaunchKernelGGL((k_p2g_pair<D, TW, WPE, 2>), pg, p2g_block, 0, s, dev, side, epoch, p2g_wgs, npack, npack_blk, layer_sel);      \
-        else if (gum == 3) hipLaunchKernelGGL((k_p2g_pair<D, TW, WPE, 3>), pg, p2g_block, 0, s, dev, side, epoch, p2g_wgs, npack, npack_blk, layer_sel); \
-        else hipLaunchKernelGGL((k_p2g_pair<D, TW, WPE, 0>), pg, p2g_block, 0, s, dev, side, epoch, p2g_wgs, npack, npack_blk, layer_sel);               \
+        dev.pcdf_waves = npro != 0u ? 1u : 0u;                                                                                         \
+        const dim3 pg(npro + 2u * p2g_wgs + ride);                                                                                     \
+        if (gum == 2) hipLaunchKernelGGL((k_p2g_pair<D, TW, WPE, 2>), pg, p2g_block, 0, s, dev, side, epoch, p2g_wgs, npack, npack_blk, layer_sel, npro);      \
+        else if (gum == 3) hipLaunchKernelGGL((k_p2g_pair<D, TW, WPE, 3>), pg, p2g_block, 0, s, dev, side, epoch, p2g_wgs, npack, npack_blk, layer_sel, npro); \
+        else hipLaunchKernelGGL((k_p2g_pair<D, TW, WPE, 0>), pg, p2g_block, 0, s, dev, side, epoch, p2g_wgs, npack, npack_blk, layer_sel, npro);               \
+        dev.pcdf_waves = 0u;                                                                                                           \
     } while (0)
 #define WGS_P2G_LAST(CP, TW, PC, FILTER)                                                                                                        \
     do {                                                                                                                                        \
-        const dim3 lg(p2g_wgs + ride);                                                                                                          \
-        if (gum == 2) hipLaunchKernelGGL((k_p2g<D, CP, TW, PC, 2>), lg, p2g_block, 0, s, dev, side, FILTER, epoch, p2g_wgs, npack, npack_blk, layer_sel);        \
-        else if (gum == 3) hipLaunchKernelGGL((k_p2g<D, CP, TW, PC, 3>), lg, p2g_block, 0, s, dev, side, FILTER, epoch, p2g_wgs, npack, npack_blk, layer_sel);   \
-        else hipLaunchKernelGGL((k_p2g<D, CP, TW, PC, 0>), lg, p2g_block, 0, s, dev, side, FILTER, epoch, p2g_wgs, npack, npack_blk, layer_sel);                 \
+        const uint32_t np_ = (PC) ? npro : 0u;                                                                                                  \
+        dev.pcdf_waves = np_ != 0u ? 1u : 0u;                                                                                                   \
+        const dim3 lg(np_ + p2g_wgs + ride);                                                                                                    \
+        if (gum == 2) hipLaunchKernelGGL((k_p2g<D, CP, TW, PC, 2>), lg, p2g_block, 0, s, dev, side, FILTER, epoch, p2g_wgs, npack, npack_blk, layer_sel, np_);        \
+        else if (gum == 3) hipLaunchKernelGGL((k_p2g<D, CP, TW, PC, 3>), lg, p2g_block, 0, s, dev, side, FILTER, epoch, p2g_wgs, npack, npack_blk, layer_sel, np_);   \
+        else hipLaunchKernelGGL((k_p2g<D, CP, TW, PC, 0>), lg, p2g_block, 0, s, dev, side, FILTER, epoch, p2g_wgs, npack, npack_blk, layer_sel, np_);                 \
+        dev.pcdf_waves = 0u;                                                                                                                    \
     } while (0)
-            if (d->cpic && !big_two_way && (big_one_way || (d->last_ncpic != UINT32_MAX && d->last_ncpic >= P2G_PAIR_MIN_BLOCKS)) && !(dev.dbg & 8192u)) {
+            if (d->cpic && !big_two_way && (big_one_way || n < P2G_PAIR_ALWAYS_BELOW || (d->last_ncpic != UINT32_MAX && d->last_ncpic >= P2G_PAIR_MIN_BLOCKS)) && !(dev.dbg & 8192u)) {
                 // many blocks near colliders (as of the last wgs_sync): both bodies in one launch (k_p2g_pair)
                 if (d->two_way) WGS_P2G_PAIR(true, 1);
                 else if (big_one_way) WGS_P2G_PAIR(false, 3);
                 else WGS_P2G_PAIR(false, 1);
             } else if (d->cpic) {
                 // (the first of the two launches hands its slabs over like the last one when anything rides in that one)
-                if (gum != 0) hipLaunchKernelGGL((k_p2g<D, false, false, false, 1>), p2g_grid, p2g_block, 0, s, dev, side, 1, epoch, p2g_wgs, 0u, 0u, layer_sel);
-                else hipLaunchKernelGGL((k_p2g<D, false>), p2g_grid, p2g_block, 0, s, dev, side, 1, epoch, p2g_wgs, 0u, 0u, layer_sel);
+                if (gum != 0) hipLaunchKernelGGL((k_p2g<D, false, false, false, 1>), p2g_grid, p2g_block, 0, s, dev, side, 1, epoch, p2g_wgs, 0u, 0u, layer_sel, 0u);
+                else hipLaunchKernelGGL((k_p2g<D, false>), p2g_grid, p2g_block, 0, s, dev, side, 1, epoch, p2g_wgs, 0u, 0u, layer_sel, 0u);
                 // near-collider list: particle cdf in the prologue (the node cdfs are complete: k_setup_scatter<CDF>, or
                 // k_cdf after k_p2g_cdf with mesh colliders), then the CPIC transfer
                 if (d->two_way) WGS_P2G_LAST(true, true, true, 2);
@@ -1108,6 +1127,7 @@ static wgs_status create_impl(wgs_pipeline *pipeline, const wgs_sim_params *para
     // every substep (no k_rebin), 1024 = no eviction of long-inactive blocks from the table (it is rebuilt when the ids run out instead),
     // 2048 = launch 2 of the sort never shares node-cdf summaries between neighbouring blocks (every wave evaluates its whole tile),
     // 2 = ... shares them but never waits for one (a neighbour's word that is not there at the first look is evaluated locally),
+    // 4 = the particle cdf of the listed blocks always inside their CPIC workgroups of P2G (no prologue waves),
     // 4096 = the two G2P bodies as two launches, 8192 = the two P2G bodies always as two launches, 16384 = never the
     // spill-free variant of the plastic G2P pair, 32768 = never the small register budget of the one-way P2G pair,
     // 65536 = never the uniform-material mode (the per-particle constants always travel with the particle), 131072 = the

@@ -440,6 +440,7 @@ template <int D> __global__ __launch_bounds__(CDF_THREADS) void k_cdf(Dev d, int
             if (any && cnt > 0) d.cpic_list[(size_t)(b & 7u) * d.cap + atomicAdd(&d.counters[ctr_ncpic(b & 7u, epoch)], 1u)] = b;
         }
         if (any && cnt > 0 && tid < 64) append_visits(d, b, d.block_start[b], cnt, tid, epoch);  // (the first wave of the workgroup)
+        if (any && cnt > 0 && tid == 0) d.pcdf_done[b] = 0u;
         // (3: the particle cdf of the listed blocks runs in the prologue of the CPIC P2G launch, three waves per block)
     }
 }

@@ -1233,7 +1233,10 @@ __device__ __forceinline__ uint32_t regroup_block(const Dev &d, int side, uint32
         d.block_ident[id] = (fast_clean && bstart == bstart_old) ? ((epoch << 1) | (pc_flag != 0u ? 1u : 0u)) : 0u;
         // (block_acc is cleared by the grid update: the waves of this group read it)
     }
-    if (listed) append_visits(d, id, bstart, btotal, lane, epoch);
+    if (listed) {
+        append_visits(d, id, bstart, btotal, lane, epoch);
+        if (lane == 0) d.pcdf_done[id] = 0u;   // (counted up by the prologue waves of this substep's P2G launch, if it has any)
+    }
     if constexpr (SHARD) {  // block layers that travel to a neighbour: an entry k_pack_face can work from without another look-up —
         // [id, key, the 2^D slabs the block's nodes are gathered from (its "-" neighbours that hold particles: lanes 8..15)]
         const IfaceMasks im = iface_masks<D>(d, b[0]);

@@ -198,25 +198,76 @@ template <int D, bool TWOWAY = false, bool INTERIOR = false> __device__ __forcei
 // waves pack the outgoing messages (kernels_shard.h pack_face_body; `npack_blk` of their waves walk the interface-block
 // list, the others copy the guests), then the grid update of the INTERIOR blocks; the interface layers are updated after
 // the exchange (k_grid_update<D, 3> with iface_only).
+// One wave of the prologue workgroups of a P2G launch: the particle cdf of the visit-list entries it strides over (described at k_p2g_pair).
+template <int D> __device__ __forceinline__ void pcdf_waves(const Dev &d, int side, uint32_t epoch, uint32_t wave_of_list, uint32_t waves_per_list, uint32_t k, int lane, NodeCdf *tile) {
+    const uint32_t nvis = min(d.counters[ctr_nvisit(k, epoch)], d.visit_cap);
+    const uint2 *vl = d.visit_list + (size_t)k * d.visit_cap;
+    const uint32_t nsorted = min(d.nv, d.counters[CTR_NSORTED]);
+    float *buf = d.buf[side];
+    uint32_t staged = NONE;
+    for (uint32_t v = wave_of_list; v < nvis; v += waves_per_list) {
+        const uint2 e = vl[v];
+        const uint32_t b = (uint32_t)__builtin_amdgcn_readfirstlane((int)e.x);
+        if (b != staged) {
+            // (single wave: its LDS accesses are served in order; the fences keep the compiler from moving the reads of the previous
+            // tile below, or the reads of this one above, the stores)
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            stage_node_cdf_tile<D, 64>(d, b, tile, lane);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            staged = b;
+        }
+        int bc[3] = {0, 0, 0};
+        unpack_key<D>(d.block_key[b], bc);
+        const uint32_t j = e.y * 64u + (uint32_t)lane;
+        bool mine = false;
+        if (j < nsorted) {
+            const uint32_t cid = d.perm_cell[j];
+            mine = cid != NONE && ((cid & ~CELL_LISTED) >> 6) == b;
+        }
+        if (mine) {
+            const uint32_t src = d.perm[j];
+            const ParticleCdfIn in = particle_cdf_fetch<D>(d, buf, src);
+            particle_cdf_update<D, true>(d, buf, src, in, tile, bc, epoch);
+        }
+        const uint32_t done = (uint32_t)__popcll(__ballot(mine));
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the quads are in memory before the count says so
+        if (lane == 0 && done != 0u) __hip_atomic_fetch_add(&d.pcdf_done[b], done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
 template <int D, bool CPIC, bool TWOWAY = false, bool PCDF = false, int GU = 0>
-__global__ __launch_bounds__(P2GCfg<D>::NW * 64) void k_p2g(Dev d, int side, int filter, uint32_t epoch, uint32_t nblk, uint32_t npack, uint32_t npack_blk, uint32_t layer_sel) {
+__global__ __launch_bounds__(P2GCfg<D>::NW * 64) void k_p2g(Dev d, int side, int filter, uint32_t epoch, uint32_t nblk, uint32_t npack, uint32_t npack_blk, uint32_t layer_sel, uint32_t npro) {
     using Cfg = P2GCfg<D>;
+    constexpr int TILE = Dim<D>::TILE;
+    __shared__ float4 s_tile[Cfg::NW][TILE];
+    if constexpr (PCDF) {   // (prologue waves in front of the CPIC launch of the near-collider list: as in k_p2g_pair, below)
+        if (blockIdx.x < npro) {
+            const uint32_t w = threadIdx.x >> 6;
+            pcdf_waves<D>(d, side, epoch, (blockIdx.x >> 3) * (uint32_t)Cfg::NW + w, (npro >> 3) * (uint32_t)Cfg::NW, blockIdx.x & 7u, (int)(threadIdx.x & 63u),
+                          reinterpret_cast<NodeCdf *>(s_tile[w]));
+            return;
+        }
+    }
+    const uint32_t wg = blockIdx.x - (PCDF ? npro : 0u), nwg = gridDim.x - (PCDF ? npro : 0u);
     if constexpr (GU == 2) {
-        if (blockIdx.x >= nblk) {
-            gu_waves<D, TWOWAY>(d, epoch, (blockIdx.x - nblk) * Cfg::NW + (threadIdx.x >> 6), (gridDim.x - nblk) * Cfg::NW, (int)(threadIdx.x & 63u));
+        if (wg >= nblk) {
+            gu_waves<D, TWOWAY>(d, epoch, (wg - nblk) * Cfg::NW + (threadIdx.x >> 6), (nwg - nblk) * Cfg::NW, (int)(threadIdx.x & 63u));
             return;
         }
     }
     if constexpr (GU == 3) {
-        if (blockIdx.x >= nblk) {
-            const uint32_t t = blockIdx.x - nblk, w = threadIdx.x >> 6;
+        if (wg >= nblk) {
+            const uint32_t t = wg - nblk, w = threadIdx.x >> 6;
             const int lane = (int)(threadIdx.x & 63u);
             if (t < npack) pack_face_body<D, true>(d, side, epoch, t * Cfg::NW + w, npack_blk, npack * Cfg::NW, lane);
-            else gu_waves<D, TWOWAY, true>(d, epoch, (t - npack) * Cfg::NW + w, (gridDim.x - nblk - npack) * Cfg::NW, lane);
+            else gu_waves<D, TWOWAY, true>(d, epoch, (t - npack) * Cfg::NW + w, (nwg - nblk - npack) * Cfg::NW, lane);
             return;
         }
     }
-    constexpr int BW = Dim<D>::BW, BS = Dim<D>::BSHIFT, TW = Dim<D>::TW, TILE = Dim<D>::TILE;
+    constexpr int BW = Dim<D>::BW, BS = Dim<D>::BSHIFT, TW = Dim<D>::TW;
     constexpr int NT = Cfg::NW * 64;
     constexpr int SLOTS = P2G_J * NPB;
     constexpr int ROW = NPB + WGS_P2G_ROW_PAD;   // padded [rank] row: ds_write_b128 serves 8 contiguous lanes per cycle over 8 slots of 16 bytes (bank = dword mod 32);
@@ -225,7 +276,6 @@ __global__ __launch_bounds__(P2GCfg<D>::NW * 64) void k_p2g(Dev d, int side, int
     constexpr int NQ = Cfg::NQ;
     __shared__ float4 s_q[NQ][P2G_J * ROW];
     __shared__ uint32_t s_aff[CPIC ? P2G_J * ROW : 1];
-    __shared__ float4 s_tile[Cfg::NW][TILE];
     __shared__ uint32_t s_cs[NPB], s_cn[NPB];
     constexpr int IMPQ = D == 3 ? 2 : 1;  // impulse quads per node: (lin, 0), (ang, 0) | (lin.xy, ang, 0)
     __shared__ float4 s_nrm[TWOWAY ? P2G_J * ROW : 1];
@@ -237,7 +287,7 @@ __global__ __launch_bounds__(P2GCfg<D>::NW * 64) void k_p2g(Dev d, int side, int
 #define P2G_PCDF PCDF
 #define P2G_HANDOVER (GU != 0)
 #define P2G_GUESTS_INLAUNCH (GU == 3)
-#define P2G_BLK blockIdx.x
+#define P2G_BLK wg
 #define P2G_NBLK nblk
 #include "p2g_body.inc"
 #undef P2G_CPIC
@@ -265,26 +315,45 @@ __global__ __launch_bounds__(P2GCfg<D>::NW * 64) void k_p2g(Dev d, int side, int
 // on — with the plain body at full occupancy the pair costs nothing while the list is empty —, and smaller ones keep
 // the unconstrained body, whose paired and separate forms are bit-identical. The two-way body (256 VGPRs) is not
 // offered the small budget.
-// (GU: as for k_p2g; the grid is `half` CPIC + `half` plain workgroups, then the grid-update workgroups)
+// (GU: as for k_p2g; the grid is `npro` prologue + `half` CPIC + `half` plain workgroups, then the grid-update workgroups)
+//
+// PROLOGUE WAVES (`npro` > 0, Dev::pcdf_waves set): the particle cdf of the listed blocks (g2p_cdf.wgsl) is 3-6 rounds of ~4 us in the
+// CPIC workgroup of a block — 192 threads for 512 particles — and that workgroup's accumulation cannot start before the last of them;
+// with few listed blocks (the reference's sand3: a dozen of 450) the launch waited for those chains while most of the chip was idle.
+// The first `npro` workgroups take the cdf instead, one WAVE per visit-list entry (a listed block's share of a chunk of 64 sorted
+// particles — the list the fused G2P walks): node-cdf tile of the block into the wave's LDS tile, the particles' quads written through
+// (agent scope), the count of finished particles added to Dev::pcdf_done[block] once the stores are acknowledged. The block's CPIC
+// workgroup — a higher workgroup index: dispatched after every prologue workgroup, so the wait cannot deadlock — polls that word
+// until it equals the block's particle total and fetches the affinities with agent-scope loads (p2g_body.inc). No fence anywhere.
 template <int D, bool TWOWAY, int WPE = 1, int GU = 0>
-__global__ __launch_bounds__(P2GCfg<D>::NW * 64, WPE) void k_p2g_pair(Dev d, int side, uint32_t epoch, uint32_t half, uint32_t npack, uint32_t npack_blk, uint32_t layer_sel) {
+__global__ __launch_bounds__(P2GCfg<D>::NW * 64, WPE) void k_p2g_pair(Dev d, int side, uint32_t epoch, uint32_t half, uint32_t npack, uint32_t npack_blk, uint32_t layer_sel, uint32_t npro) {
     using Cfg = P2GCfg<D>;
+    constexpr int TILE = Dim<D>::TILE;
+    __shared__ float4 s_tile[Cfg::NW][TILE];
+    if (blockIdx.x < npro) {   // (npro is a multiple of 8: list k = the workgroup's XCD)
+        static_assert(sizeof(NodeCdf) == sizeof(float4), "a wave's accumulation tile doubles as its node-cdf tile");
+        const uint32_t w = threadIdx.x >> 6;
+        pcdf_waves<D>(d, side, epoch, (blockIdx.x >> 3) * (uint32_t)Cfg::NW + w, (npro >> 3) * (uint32_t)Cfg::NW, blockIdx.x & 7u, (int)(threadIdx.x & 63u),
+                      reinterpret_cast<NodeCdf *>(s_tile[w]));
+        return;
+    }
+    const uint32_t wg = blockIdx.x - npro, nwg = gridDim.x - npro;   // (everything below counts from the first CPIC workgroup)
     if constexpr (GU == 2) {
-        if (blockIdx.x >= 2u * half) {
-            gu_waves<D, TWOWAY>(d, epoch, (blockIdx.x - 2u * half) * Cfg::NW + (threadIdx.x >> 6), (gridDim.x - 2u * half) * Cfg::NW, (int)(threadIdx.x & 63u));
+        if (wg >= 2u * half) {
+            gu_waves<D, TWOWAY>(d, epoch, (wg - 2u * half) * Cfg::NW + (threadIdx.x >> 6), (nwg - 2u * half) * Cfg::NW, (int)(threadIdx.x & 63u));
             return;
         }
     }
     if constexpr (GU == 3) {
-        if (blockIdx.x >= 2u * half) {
-            const uint32_t t = blockIdx.x - 2u * half, w = threadIdx.x >> 6;
+        if (wg >= 2u * half) {
+            const uint32_t t = wg - 2u * half, w = threadIdx.x >> 6;
             const int lane = (int)(threadIdx.x & 63u);
             if (t < npack) pack_face_body<D, true>(d, side, epoch, t * Cfg::NW + w, npack_blk, npack * Cfg::NW, lane);
-            else gu_waves<D, TWOWAY, true>(d, epoch, (t - npack) * Cfg::NW + w, (gridDim.x - 2u * half - npack) * Cfg::NW, lane);
+            else gu_waves<D, TWOWAY, true>(d, epoch, (t - npack) * Cfg::NW + w, (nwg - 2u * half - npack) * Cfg::NW, lane);
             return;
         }
     }
-    constexpr int BW = Dim<D>::BW, BS = Dim<D>::BSHIFT, TW = Dim<D>::TW, TILE = Dim<D>::TILE;
+    constexpr int BW = Dim<D>::BW, BS = Dim<D>::BSHIFT, TW = Dim<D>::TW;
     constexpr int NT = Cfg::NW * 64;
     constexpr int SLOTS = P2G_J * NPB;
     constexpr int ROW = NPB + WGS_P2G_ROW_PAD;
@@ -292,7 +361,6 @@ __global__ __launch_bounds__(P2GCfg<D>::NW * 64, WPE) void k_p2g_pair(Dev d, int
     constexpr int NQ = Cfg::NQ;
     __shared__ float4 s_q[NQ][P2G_J * ROW];
     __shared__ uint32_t s_aff[P2G_J * ROW];
-    __shared__ float4 s_tile[Cfg::NW][TILE];
     __shared__ uint32_t s_cs[NPB], s_cn[NPB];
     constexpr int IMPQ = D == 3 ? 2 : 1;
     __shared__ float4 s_nrm[TWOWAY ? P2G_J * ROW : 1];
@@ -301,12 +369,12 @@ __global__ __launch_bounds__(P2GCfg<D>::NW * 64, WPE) void k_p2g_pair(Dev d, int
 #define P2G_HANDOVER (GU != 0)
 #define P2G_GUESTS_INLAUNCH (GU == 3)
 #define P2G_NBLK half
-    if (blockIdx.x >= half) {
+    if (wg >= half) {
         const int filter = 1;
 #define P2G_CPIC false
 #define P2G_TWOWAY false
 #define P2G_PCDF false
-#define P2G_BLK (blockIdx.x - half)
+#define P2G_BLK (wg - half)
 #include "p2g_body.inc"
 #undef P2G_CPIC
 #undef P2G_TWOWAY
@@ -317,7 +385,7 @@ __global__ __launch_bounds__(P2GCfg<D>::NW * 64, WPE) void k_p2g_pair(Dev d, int
 #define P2G_CPIC true
 #define P2G_TWOWAY TWOWAY
 #define P2G_PCDF true
-#define P2G_BLK blockIdx.x
+#define P2G_BLK wg
 #include "p2g_body.inc"
 #undef P2G_CPIC
 #undef P2G_TWOWAY
