@@ -351,11 +351,7 @@ constexpr uint32_t P2G_SMALL_BUDGET_MIN_PARTICLES = 600000;  // one-way CPIC P2G
 #ifndef WGS_GU_WG_PER_CU
 #define WGS_GU_WG_PER_CU 8
 #endif
-#ifndef WGS_P2G_PAIR_SMALL_SCENE
-#define WGS_P2G_PAIR_SMALL_SCENE 0u
-#endif
 constexpr uint32_t P2G_PAIR_MIN_BLOCKS = 8;  // near-collider blocks from which P2G runs both bodies in one launch
-constexpr uint32_t P2G_PAIR_ALWAYS_BELOW = WGS_P2G_PAIR_SMALL_SCENE;   // ... and scenes with fewer particles than this pair whatever the list length
 int grid_for(const wgs_data *d, int blocks_per_cu) { return d->pipeline->num_cus * blocks_per_cu; }
 
 // ---- read-back kernels ---------------------------------------------------
@@ -892,7 +888,11 @@ template <bool TS> wgs_status enqueue_substep(wgs_data *d, int ts_slot, int part
         else hipLaunchKernelGGL((k_p2g<D, CP, TW, PC, 0>), lg, p2g_block, 0, s, dev, side, FILTER, epoch, p2g_wgs, npack, npack_blk, layer_sel, np_);                 \
         dev.pcdf_waves = 0u;                                                                                                                    \
     } while (0)
-            if (d->cpic && !big_two_way && (big_one_way || n < P2G_PAIR_ALWAYS_BELOW || (d->last_ncpic != UINT32_MAX && d->last_ncpic >= P2G_PAIR_MIN_BLOCKS)) && !(dev.dbg & 8192u)) {
+            // (small two-way scenes pair whatever the list length: they fill less than one round of workgroups, so the plain body's lost
+            // occupancy costs nothing and a launch goes — the reference's sand2, 490 k particles, 2D: 76-79 -> 67-68 us per substep;
+            // the one-way 262 k cube: P2G 20.4 + a boundary -> 18.3 us, not taken: its fused G2P then ran 27 us every other run against 21-22)
+            const bool small_two_way = d->two_way && n < P2G_SMALL_BUDGET_MIN_PARTICLES;
+            if (d->cpic && !big_two_way && (big_one_way || small_two_way || (d->last_ncpic != UINT32_MAX && d->last_ncpic >= P2G_PAIR_MIN_BLOCKS)) && !(dev.dbg & 8192u)) {
                 // many blocks near colliders (as of the last wgs_sync): both bodies in one launch (k_p2g_pair)
                 if (d->two_way) WGS_P2G_PAIR(true, 1);
                 else if (big_one_way) WGS_P2G_PAIR(false, 3);
