@@ -208,6 +208,16 @@ template <int D> __device__ __forceinline__ void pcdf_waves(const Dev &d, int si
     for (uint32_t v = wave_of_list; v < nvis; v += waves_per_list) {
         const uint2 e = vl[v];
         const uint32_t b = (uint32_t)__builtin_amdgcn_readfirstlane((int)e.x);
+        // (the particle's chain — sort entry, state — is requested before the tile's — links, node cdfs: two pairs of round trips side by side.
+        // A lane whose slot belongs to another block fetches a particle it will not touch.)
+        const uint32_t j = e.y * 64u + (uint32_t)lane;
+        uint32_t cid = NONE, src = 0u;
+        if (j < nsorted) {
+            cid = d.perm_cell[j];
+            src = d.perm[j];
+        }
+        const uint32_t bkey = d.block_key[b];
+        const ParticleCdfIn in = particle_cdf_fetch<D>(d, buf, src);
         if (b != staged) {
             // (single wave: its LDS accesses are served in order; the fences keep the compiler from moving the reads of the previous
             // tile below, or the reads of this one above, the stores)
@@ -220,18 +230,9 @@ template <int D> __device__ __forceinline__ void pcdf_waves(const Dev &d, int si
             staged = b;
         }
         int bc[3] = {0, 0, 0};
-        unpack_key<D>(d.block_key[b], bc);
-        const uint32_t j = e.y * 64u + (uint32_t)lane;
-        bool mine = false;
-        if (j < nsorted) {
-            const uint32_t cid = d.perm_cell[j];
-            mine = cid != NONE && ((cid & ~CELL_LISTED) >> 6) == b;
-        }
-        if (mine) {
-            const uint32_t src = d.perm[j];
-            const ParticleCdfIn in = particle_cdf_fetch<D>(d, buf, src);
-            particle_cdf_update<D, true>(d, buf, src, in, tile, bc, epoch);
-        }
+        unpack_key<D>(bkey, bc);
+        const bool mine = cid != NONE && ((cid & ~CELL_LISTED) >> 6) == b;
+        if (mine) particle_cdf_update<D, true>(d, buf, src, in, tile, bc, epoch);
         const uint32_t done = (uint32_t)__popcll(__ballot(mine));
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the quads are in memory before the count says so
         if (lane == 0 && done != 0u) __hip_atomic_fetch_add(&d.pcdf_done[b], done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -281,6 +282,7 @@ __global__ __launch_bounds__(P2GCfg<D>::NW * 64) void k_p2g(Dev d, int side, int
     __shared__ float4 s_nrm[TWOWAY ? P2G_J * ROW : 1];
     __shared__ NodeCdf s_ncdf[PCDF ? TILE : 1];
     __shared__ float4 s_imp[TWOWAY ? Cfg::NW : 1][TWOWAY ? IMPQ : 1][TWOWAY ? TILE : 1];
+    __shared__ ColliderMotion s_colm[TWOWAY ? 16 : 1];   // (p2g_body.inc: the colliders' motion for the two-way impulses)
 
 #define P2G_CPIC CPIC
 #define P2G_TWOWAY TWOWAY
@@ -366,6 +368,7 @@ __global__ __launch_bounds__(P2GCfg<D>::NW * 64, WPE) void k_p2g_pair(Dev d, int
     __shared__ float4 s_nrm[TWOWAY ? P2G_J * ROW : 1];
     __shared__ NodeCdf s_ncdf[TILE];
     __shared__ float4 s_imp[TWOWAY ? Cfg::NW : 1][TWOWAY ? IMPQ : 1][TWOWAY ? TILE : 1];
+    __shared__ ColliderMotion s_colm[TWOWAY ? 16 : 1];   // (p2g_body.inc: the colliders' motion for the two-way impulses)
 #define P2G_HANDOVER (GU != 0)
 #define P2G_GUESTS_INLAUNCH (GU == 3)
 #define P2G_NBLK half
