@@ -342,7 +342,7 @@ void fill_collider(ColliderDev &c, const wgs_collider &in) {
     for (int k = 0; k < 3; k++) c.com[k] = in.com[k];
 }
 
-constexpr uint32_t WGS_LAUNCH_SHAPE_SWITCHES = 2u | 4u | 128u | 1024u | 2048u | 4096u | 8192u | 16384u | 32768u | 65536u | 131072u | 262144u | 524288u | 1048576u | 4194304u | 8388608u | 16777216u;  // WGS_DEBUG bits the shipped library honours
+constexpr uint32_t WGS_LAUNCH_SHAPE_SWITCHES = 2u | 4u | 8u | 128u | 1024u | 2048u | 4096u | 8192u | 16384u | 32768u | 65536u | 131072u | 262144u | 524288u | 1048576u | 4194304u | 8388608u | 16777216u;  // WGS_DEBUG bits the shipped library honours
 constexpr uint32_t PCDF_WAVES_MAX_VISITS = 256;   // per XCD list: above, the prologue waves would be a round of work in front of the launch, not a use of idle CUs
 constexpr uint32_t P2G_SMALL_BUDGET_MIN_PARTICLES = 600000;  // one-way CPIC P2G body at 168 VGPRs from this size on
 #ifndef WGS_REGROUP_ROUNDS
@@ -868,10 +868,11 @@ template <bool TS> wgs_status enqueue_substep(wgs_data *d, int ts_slot, int part
             uint32_t npro = 0u;
             if (d->cpic && !dev.sharded && d->last_nvisit != UINT32_MAX && d->last_nvisit != 0u && d->last_nvisit <= PCDF_WAVES_MAX_VISITS && !(dev.dbg & 4u))
                 npro = 8u * ((std::min(d->last_nvisit + 8u, dev.visit_cap) + NW - 1u) / NW);
+            if (d->cpic && !dev.sharded && (dev.dbg & 8u)) npro = 8u;   // (tests: waves sized for a list the host never saw grow — the launch itself then decides, device_math.h pcdf_waves_on)
             dev.pcdf_waves = 0u;
 #define WGS_P2G_PAIR(TW, WPE)                                                                                                          \
     do {                                                                                                                               \
-        dev.pcdf_waves = npro != 0u ? 1u : 0u;                                                                                         \
+        dev.pcdf_waves = npro;                                                                                                                 \
         const dim3 pg(npro + 2u * p2g_wgs + ride);                                                                                     \
         if (gum == 2) hipLaunchKernelGGL((k_p2g_pair<D, TW, WPE, 2>), pg, p2g_block, 0, s, dev, side, epoch, p2g_wgs, npack, npack_blk, layer_sel, npro);      \
         else if (gum == 3) hipLaunchKernelGGL((k_p2g_pair<D, TW, WPE, 3>), pg, p2g_block, 0, s, dev, side, epoch, p2g_wgs, npack, npack_blk, layer_sel, npro); \
@@ -881,7 +882,7 @@ template <bool TS> wgs_status enqueue_substep(wgs_data *d, int ts_slot, int part
 #define WGS_P2G_LAST(CP, TW, PC, FILTER)                                                                                                        \
     do {                                                                                                                                        \
         const uint32_t np_ = (PC) ? npro : 0u;                                                                                                  \
-        dev.pcdf_waves = np_ != 0u ? 1u : 0u;                                                                                                   \
+        dev.pcdf_waves = np_;                                                                                                                    \
         const dim3 lg(np_ + p2g_wgs + ride);                                                                                                    \
         if (gum == 2) hipLaunchKernelGGL((k_p2g<D, CP, TW, PC, 2>), lg, p2g_block, 0, s, dev, side, FILTER, epoch, p2g_wgs, npack, npack_blk, layer_sel, np_);        \
         else if (gum == 3) hipLaunchKernelGGL((k_p2g<D, CP, TW, PC, 3>), lg, p2g_block, 0, s, dev, side, FILTER, epoch, p2g_wgs, npack, npack_blk, layer_sel, np_);   \
@@ -1127,7 +1128,8 @@ static wgs_status create_impl(wgs_pipeline *pipeline, const wgs_sim_params *para
     // every substep (no k_rebin), 1024 = no eviction of long-inactive blocks from the table (it is rebuilt when the ids run out instead),
     // 2048 = launch 2 of the sort never shares node-cdf summaries between neighbouring blocks (every wave evaluates its whole tile),
     // 2 = ... shares them but never waits for one (a neighbour's word that is not there at the first look is evaluated locally),
-    // 4 = the particle cdf of the listed blocks always inside their CPIC workgroups of P2G (no prologue waves),
+    // 4 = the particle cdf of the listed blocks always inside their CPIC workgroups of P2G (no prologue waves), 8 = prologue waves sized for an
+    // empty list whatever the host saw (the launch then finds the lists too long for them and leaves the work to the workgroups),
     // 4096 = the two G2P bodies as two launches, 8192 = the two P2G bodies always as two launches, 16384 = never the
     // spill-free variant of the plastic G2P pair, 32768 = never the small register budget of the one-way P2G pair,
     // 65536 = never the uniform-material mode (the per-particle constants always travel with the particle), 131072 = the

@@ -125,6 +125,18 @@ __device__ inline void append_visits(const Dev &d, uint32_t id, uint32_t start, 
     }
 }
 
+// Do the prologue workgroups of this P2G launch take the particle cdf of the listed blocks (kernels_transfer.h pcdf_waves)? The host sized
+// them from the lists it saw last; the lists of THIS substep decide: no wave gets more than two visits, or the blocks' own workgroups
+// do the work as before (a list that grew a hundredfold since the host's last look would otherwise be walked by a few waves, visit
+// after visit, with every listed block waiting). Every workgroup of the launch reads the same eight counters: the same answer.
+__device__ inline bool pcdf_waves_on(const Dev &d, uint32_t epoch, uint32_t waves_per_workgroup) {
+    if (d.pcdf_waves == 0u) return false;
+    uint32_t longest = 0u;
+#pragma unroll
+    for (uint32_t k = 0; k < 8u; k++) longest = max(longest, d.counters[ctr_nvisit(k, epoch)]);
+    return longest <= 2u * (d.pcdf_waves >> 3) * waves_per_workgroup;
+}
+
 __device__ inline uint32_t hmap_lookup(const Dev &d, uint32_t key) {
     uint32_t slot = hash_key(key) & d.hmask;
     for (uint32_t probe = 0; probe <= d.hmask; ++probe) {

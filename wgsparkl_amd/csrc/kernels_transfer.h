@@ -200,6 +200,7 @@ template <int D, bool TWOWAY = false, bool INTERIOR = false> __device__ __forcei
 // the exchange (k_grid_update<D, 3> with iface_only).
 // One wave of the prologue workgroups of a P2G launch: the particle cdf of the visit-list entries it strides over (described at k_p2g_pair).
 template <int D> __device__ __forceinline__ void pcdf_waves(const Dev &d, int side, uint32_t epoch, uint32_t wave_of_list, uint32_t waves_per_list, uint32_t k, int lane, NodeCdf *tile) {
+    if (!pcdf_waves_on(d, epoch, (uint32_t)P2GCfg<D>::NW)) return;   // (the lists outgrew what the host sized these waves for: the blocks' workgroups do it)
     const uint32_t nvis = min(d.counters[ctr_nvisit(k, epoch)], d.visit_cap);
     const uint2 *vl = d.visit_list + (size_t)k * d.visit_cap;
     const uint32_t nsorted = min(d.nv, d.counters[CTR_NSORTED]);

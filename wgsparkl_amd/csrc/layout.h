@@ -233,7 +233,8 @@ struct Dev {
     uint32_t *halo_list;      // sharded runs, cap x HALO_ENT words: the active blocks of the layers that travel (what k_pack_face gathers and packs)
     uint32_t *pcdf_done;      // cap: particles of a listed block whose cdf this substep's prologue WAVES of the P2G launch have written (reset by
                               // the sort when it lists the block); the block's CPIC workgroup waits for its particle total (kernels_transfer.h pcdf_waves)
-    uint32_t pcdf_waves;      // this P2G launch has prologue waves (set by the host per launch): the CPIC body waits for them instead of computing
+    uint32_t pcdf_waves;      // prologue workgroups at the front of this P2G launch (set by the host per launch; 0: none). Whether they WORK is decided
+                              // inside the launch from this substep's list lengths (device_math.h pcdf_waves_on): the same answer in every workgroup
     uint32_t visit_cap;       // per list (an eighth of the chunks + 2 per block would do; a block is visited once per chunk it spans)
     uint32_t cdf_gen;         // node cdfs and block classes computed under this generation stay valid for a block (it keeps its id and
                               // therefore its place) as long as no collider that can MOVE reaches its tile; 0: no colliders
