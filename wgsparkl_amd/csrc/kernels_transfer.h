@@ -635,12 +635,11 @@ __global__ __launch_bounds__(G2P_THREADS, G2P_WAVES_PER_EU) void k_g2p_update(De
 // are capped at the same register budget, so the main path keeps its occupancy; the launch saves the ~4.5 us a
 // dependent kernel boundary costs even when the list is empty. `nlist` follows the list length the host last saw
 // (wgs_sync), so an empty list costs a few hundred workgroups that exit at once.
-// WPE (waves per SIMD the register budget is cut for): 3 everywhere, except that the Drucker-Prager CPIC body spills
-// ~350 B per lane under that cap; with 2 (256 VGPRs, no spills) the list half runs faster and the main half slower
-// (lower occupancy). capi.hip picks 2 when half of the active blocks or more are listed, as of the host's last look.
-// (With the list half as it was in the middle of round 2 — chunk lanes on XCDs, 27-term stencil for every particle —
-// a third of the blocks listed was already enough: 4 M sand between walls 16 % faster; since the visit lists and the
-// per-particle choice of the stencil that scene is 4.5 % faster with 3: 362-371 -> 346-351 us.)
+// WPE (waves per SIMD the register budget is cut for): 3 everywhere (168 VGPRs; the corotated Drucker-Prager pair keeps 20 B of
+// scratch per lane under that cap since round 5 — it was 312 B, and every reload from scratch waits for the acknowledgement of every
+// store in flight: NOTES.md —, the neo-Hookean + plastic pair 92-116 B); with 2 (256 VGPRs, nothing spilled) the list half runs faster
+// and the main half slower (lower occupancy). capi.hip picks 2 when half of the active blocks or more are listed, as of the host's
+// last look.
 template <int D, int MODEL, bool PLASTIC, int WPE = G2P_WAVES_PER_EU, int NPASS = 1, bool SHARD = false, bool BIN = false>
 __global__ __launch_bounds__(G2P_THREADS, WPE) void k_g2p_pair(Dev d, int side, uint32_t epoch, uint32_t nmain, uint32_t nlist) {
     constexpr uint32_t npass = NPASS;
@@ -658,8 +657,8 @@ __global__ __launch_bounds__(G2P_THREADS, WPE) void k_g2p_pair(Dev d, int side, 
 #undef G2P_BX
 #undef G2P_GX
     } else {  // the 8 * nlist waves of the visit list
-        // (runs of at most two entries: the CPIC body has no registers left for the deeper prefetch of the main body —
-        // with four, the non-plastic pair spilled 232 B per lane instead of 96 and 16 M particles on a floor lost 5 %)
+        // (one visit at a time, WGS_G2P_LIST_PASSES: the CPIC body has no registers left for the main body's prefetch — with two entries
+        // per run the next visit's quads went through scratch, 12-20 dwords per visit; with four the non-plastic pair lost 5 % at 16 M)
         constexpr uint32_t npass = NPASS < WGS_G2P_LIST_PASSES ? NPASS : WGS_G2P_LIST_PASSES;
 #define G2P_CMODE 2
 #define G2P_BX blockIdx.x
