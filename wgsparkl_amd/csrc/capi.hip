@@ -343,7 +343,10 @@ void fill_collider(ColliderDev &c, const wgs_collider &in) {
 }
 
 constexpr uint32_t WGS_LAUNCH_SHAPE_SWITCHES = 2u | 4u | 8u | 128u | 1024u | 2048u | 4096u | 8192u | 16384u | 32768u | 65536u | 131072u | 262144u | 524288u | 1048576u | 4194304u | 8388608u | 16777216u;  // WGS_DEBUG bits the shipped library honours
-constexpr uint32_t PCDF_WAVES_MAX_VISITS = 256;   // per XCD list: above, the prologue waves would be a round of work in front of the launch, not a use of idle CUs
+#ifndef WGS_PCDF_WAVES_MAX_VISITS
+#define WGS_PCDF_WAVES_MAX_VISITS 256
+#endif
+constexpr uint32_t PCDF_WAVES_MAX_VISITS = WGS_PCDF_WAVES_MAX_VISITS;   // per XCD list: above, the prologue waves would be a round of work in front of the launch, not a use of idle CUs
 constexpr uint32_t P2G_SMALL_BUDGET_MIN_PARTICLES = 600000;  // one-way CPIC P2G body at 168 VGPRs from this size on
 #ifndef WGS_REGROUP_ROUNDS
 #define WGS_REGROUP_ROUNDS 4u
