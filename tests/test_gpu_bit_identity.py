@@ -481,3 +481,46 @@ def test_particle_cdf_by_prologue_waves_of_the_p2g_launch_gives_the_bits_of_the_
             for x, y in zip(ba, bb):
                 for key in x:
                     assert np.array_equal(np.asarray(x[key]), np.asarray(y[key])), (dbg, key)
+
+
+@pytest.mark.parametrize("scene", ["at_rest", "landed", "flying"])
+def test_direct_runs_of_unchanged_blocks_give_the_bits_of_the_gather_through_the_permutation(hip_libs, scene, monkeypatch):
+    """A block whose run is its previous run member for member (nobody moved, nobody arrived) is handed to the plain body of P2G with
+    its cells' runs in the buffer's own coordinates: the particles are read where they are, without the gather through `perm`
+    (layout.h CELL_DIRECT; one dependent round trip less per block). The same particles in the same order: the same bits as with
+    WGS_DEBUG = 33554432 (every block through the permutation) — a cube in free fall (every block direct), the cube landing on the floor
+    (direct and gathered blocks side by side, listed blocks beside them) and the cube crossing the grid and spinning (hardly any direct
+    block; blocks becoming direct and dirty again), with a host look in between."""
+    from helpers import pipeline
+    from wgsparkl_amd import MpmData
+    sc = scenes.neo_hookean_cube(n_side=86, with_floor=True)
+    ps = sc["particles"]
+    nsub = 12
+    if scene == "landed":
+        ps.pos[:, 1] -= 5.7
+        ps.vel[:, 1] = -3.0
+        nsub = 24
+    elif scene == "flying":
+        r = ps.pos - ps.pos.mean(0)
+        ps.vel[:] = (np.array([4.0, 2.5, 3.0]) + np.cross(np.array([0.0, 0.3, 0.1]), r)).astype(np.float32)
+        nsub = 60
+
+    def run():
+        pipe = pipeline(3)
+        data = MpmData.new(pipe, sc["params"], sc["particles"], sc["colliders"], sc["cell_width"], sc["grid_capacity"], sc["model"])
+        pipe.step(data, nsub // 2)
+        data.sync()
+        pipe.step(data, nsub - nsub // 2)
+        data.sync()
+        st = data.stats()
+        assert st["overflow"] == 0
+        return data.read_particles(), data.read_grid(), st
+    a, ga, sta = run()
+    monkeypatch.setenv("WGS_DEBUG", "33554432")
+    b, gb, stb = run()
+    for f in ("pos", "vel", "def_grad", "affine", "cdf_affinity"):
+        assert np.array_equal(getattr(a, f), getattr(b, f)), f
+    for x, y in zip(ga, gb):
+        assert np.array_equal(np.asarray(x), np.asarray(y))
+    if scene == "flying":
+        assert sta["cell_changers"] > 0   # (the scene does move: blocks are dirty)

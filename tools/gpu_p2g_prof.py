@@ -40,5 +40,8 @@ for rep in range(2):
     for k, n in enumerate(names):
         d = (w[:, 1 + k] - w[:, 0]) / 100.0
         print(f"   {n:32s} mean {d.mean():7.2f}  p10 {np.percentile(d,10):7.2f}  p90 {np.percentile(d,90):7.2f} us since the block's start")
+    for k, n in ((6, "record + runs loaded"), (7, "runs in LDS, tile zeroed, longest run")):
+        d = (w[:, k] - w[:, 0]) / 100.0
+        print(f"   {n:32s} mean {d.mean():7.2f}  p10 {np.percentile(d,10):7.2f}  p90 {np.percentile(d,90):7.2f} us since the block's start")
     st = np.sort((w[:, 0] - t0) / 100.0)
     print("   block start times (us) deciles:", [round(float(x), 1) for x in np.percentile(st, [0, 10, 25, 50, 75, 90, 100])])

@@ -342,7 +342,7 @@ void fill_collider(ColliderDev &c, const wgs_collider &in) {
     for (int k = 0; k < 3; k++) c.com[k] = in.com[k];
 }
 
-constexpr uint32_t WGS_LAUNCH_SHAPE_SWITCHES = 2u | 4u | 8u | 128u | 1024u | 2048u | 4096u | 8192u | 16384u | 32768u | 65536u | 131072u | 262144u | 524288u | 1048576u | 4194304u | 8388608u | 16777216u;  // WGS_DEBUG bits the shipped library honours
+constexpr uint32_t WGS_LAUNCH_SHAPE_SWITCHES = 2u | 4u | 8u | 128u | 1024u | 2048u | 4096u | 8192u | 16384u | 32768u | 65536u | 131072u | 262144u | 524288u | 1048576u | 4194304u | 8388608u | 16777216u | 33554432u;  // WGS_DEBUG bits the shipped library honours
 #ifndef WGS_PCDF_WAVES_MAX_VISITS
 #define WGS_PCDF_WAVES_MAX_VISITS 256
 #endif
@@ -1141,7 +1141,8 @@ static wgs_status create_impl(wgs_pipeline *pipeline, const wgs_sim_params *para
     // 1048576 = launch 1 of the sort (k_rebin) every substep instead of the binning inside the fused G2P, 4194304 = P2G of a
     // lockstep slab split into its boundary layers and the rest (the shape wgs_sharded_step uses when it forks), 8388608 =
     // wgs_sharded_step forks the exchange onto a second stream beside the interior's P2G (measured slower here: capi_sharded.inc),
-    // 16777216 = launch 2 of the sort orders the cells of a dirty block by insertion instead of by ranks (kernels_sort.h).
+    // 16777216 = launch 2 of the sort orders the cells of a dirty block by insertion instead of by ranks (kernels_sort.h),
+    // 33554432 = P2G gathers every block through the sort permutation (no direct runs for unchanged blocks: layout.h CELL_DIRECT).
     // The ablations that change the RESULTS (64 = G2P moves bytes only, 256 = P2G without its accumulation loop,
     // 512 = P2G without its particle loads) exist only in builds with -DWGS_ABLATE; the shipped library ignores them.
     dev.dbg = getenv("WGS_DEBUG") ? (uint32_t)strtoul(getenv("WGS_DEBUG"), nullptr, 0) : 0u;

@@ -1215,7 +1215,11 @@ __device__ __forceinline__ uint32_t regroup_block(const Dev &d, int side, uint32
     // ---- new runs, reset of what this substep consumed
     d.cell_start[idx] = bstart + lstart;
     d.cell_cursor[idx] = bstart + lstart + total;
-    d.act_cells[(size_t)aidx * NPB + lane] = make_uint2(bstart + lstart, bstart + lstart + total);   // (the same, where P2G finds it without the block id)
+    // (the same, where P2G finds it without the block id — or, for a run that is the block's previous run member for member, where the
+    // particles ARE: [cs_old, ce_old) of the buffer, which P2G then reads without the gather through perm: layout.h CELL_DIRECT.
+    // WGS_DEBUG bit 25: never — same particles in the same order either way, tested)
+    const bool direct = fast_clean && !(d.dbg & 33554432u);
+    d.act_cells[(size_t)aidx * NPB + lane] = direct ? make_uint2(cs_old, ce_old) : make_uint2(bstart + lstart, bstart + lstart + total);
     if (head != 0u) d.cell_head[idx] = 0u;
     if (lane == 0 && narr != 0u) d.blk_narr[id] = 0u;
     if (d.n_rigid != 0u) {             // mesh-collider cdf accumulators of this substep (k_p2g_cdf)
@@ -1226,7 +1230,7 @@ __device__ __forceinline__ uint32_t regroup_block(const Dev &d, int side, uint32
     if (lane >= 8 && lane < 16) d.act_src[aidx * 8u + (uint32_t)(lane & 7)] = link_cnt > 0u ? res : NONE;
     if (lane == 63) {
         d.active[aidx] = id;           // grid.wgsl:323-334: the active list, in physical-id order
-        d.act_info[aidx] = make_uint4(id, bkey, btotal, pc_flag);   // (.w: the block class, where this launch computes it)
+        d.act_info[aidx] = make_uint4(id, bkey, btotal, pc_flag | (direct ? CELL_DIRECT : 0u));   // (.w: the block class, where this launch computes it; direct runs)
         d.block_start[id] = bstart;    // first_particle
         d.block_count[id] = btotal;    // snapshot used by P2G / grid update / G2P
         d.links_epoch[id] = epoch;     // the neighbour links and cell runs written above are those of this substep

@@ -144,6 +144,12 @@ enum { ERRBIT_OVERFLOW = 1u, ERRBIT_KEYRANGE = 2u, ERRBIT_SHARD = 4u, ERRBIT_MAT
 // sort when it computes the block classes itself; the fused G2P then knows which body a particle belongs to from the sort
 // entry it loads anyway, instead of a dependent block_cpic lookup in the middle of every chunk.
 constexpr uint32_t CELL_LISTED = 0x80000000u;
+// Bit 30 of an act_info record's flags (round 6): the block's run is its PREVIOUS run, member for member (nobody moved, nobody arrived:
+// the sort's fast_clean) — its act_cells entries then hold the cells' runs in the CURRENT BUFFER's coordinates (the previous sorted
+// order, which is the storage order), and the plain body of P2G reads the particles there without the gather through `perm`: one
+// dependent round trip less per block (stage clocks at the headline: 1.35 of a block's 8 us). The CPIC body walks cell_start /
+// cell_cursor (sorted coordinates) and is not concerned.
+constexpr uint32_t CELL_DIRECT = 0x40000000u;
 // Bit 31 of a Dev::cellid entry: the particle changed cell in the step that wrote the entry (NONE stays NONE). Launch 2 of the sort tells
 // the stayers of a run from the particles that came from another cell of the block by it, and counts the cell-changers.
 constexpr uint32_t CELL_MOVED = 0x80000000u;
@@ -200,8 +206,8 @@ struct Dev {
     uint32_t *block_count; // cap: particles whose associated cell is in the block (num_particles)
     uint32_t *block_start; // cap: exclusive scan of block_count over the active list (first_particle)
     uint32_t *active;      // cap: physical ids of the blocks active in this substep, [0, num_active_blocks)
-    uint4 *act_info;       // cap, by ACTIVE-LIST index: {block id, key, particles, CELL_LISTED if near a collider} — what P2G needs of a block in one load
-    uint2 *act_cells;      // cap*64, by ACTIVE-LIST index: {start, end} of each cell's run in perm (cell_start / cell_cursor are by block id)
+    uint4 *act_info;       // cap, by ACTIVE-LIST index: {block id, key, particles, CELL_LISTED if near a collider | CELL_DIRECT} — what P2G needs of a block in one load
+    uint2 *act_cells;      // cap*64, by ACTIVE-LIST index: {start, end} of each cell's run in perm (cell_start / cell_cursor are by block id) — in the current buffer itself where the record says CELL_DIRECT
     uint32_t *nbr_plus;    // cap*8: physical ids of b + {0,1}^D (always active)
     uint32_t *nbr_minus;   // cap*8: physical ids of b - {0,1}^D, NONE when inactive
     uint32_t *act_src;     // cap*8, by ACTIVE-LIST index: the b - {0,1}^D neighbours that hold particles (the slabs a node of b is
@@ -395,6 +401,17 @@ __device__ inline void st_plain(__amdgpu_buffer_rsrc_t r, uint32_t byte_off, con
 __device__ inline float4 ld_agent(__amdgpu_buffer_rsrc_t r, uint32_t byte_off) {
     const wgs_v4u u = __builtin_amdgcn_raw_buffer_load_b128(r, byte_off, 0, WGS_CPOL_SC1);
     return make_float4(__uint_as_float(u.x), __uint_as_float(u.y), __uint_as_float(u.z), __uint_as_float(u.w));
+}
+// maximum over the 64 lanes by DPP row shifts and broadcasts: half a dozen VALU instructions where six __shfl_xor steps are six
+// dependent ds_bpermute round trips (P2G's longest run of a block: 0.4 of the 0.7 us between a block's record and its first fetch)
+__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
+    v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, true));   // row_shr:1
+    v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, true));   // row_shr:2
+    v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, true));   // row_shr:4
+    v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, true));   // row_shr:8: lane 15 of a row holds the row's maximum
+    v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false));  // row_bcast:15 into rows 1 and 3
+    v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false));  // row_bcast:31 into rows 2 and 3
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
 }
 // persistent particle id (the caller's index) lives after the quads
 template <int D> __device__ inline uint32_t ldpid(const float *base, uint32_t npad, uint32_t i) {
