@@ -18,7 +18,7 @@ anything is timed the decomposition validates itself against a single-domain run
 mismatch). --scaling weak (default): N
 copies of the config side by side along x (fixed work per GPU); strong: the named size cut into N slabs (north_star's
 16M target: --config c5 --scaling strong). Without flags, the line also carries `extra` legs: the same cube after it
-landed on the floor, c3, the reference's own sand3 (202 k particles) and sand2 (490 k, 2D) scenes, c2_stirred (the cube
+landed on the floor, c3, c4 on one GPU, the reference's own sand3 (202 k particles) and sand2 (490 k, 2D) scenes, c2_stirred (the cube
 crossing the grid and spinning: > 10 % of its particles change cell per substep), c2_frames (20 substeps per wgs_step call
 with the pose read-back between calls) and c5 (strong over the N GPUs), each with its pass times, its own G2P roofline figure
 and `mover_fraction` (particles that changed cell per substep, counted on the device).
@@ -495,6 +495,12 @@ def main():
                                       "the C2 cube after it landed: lowered onto the floor with a -3 cells/s impact, 200 substeps before the timed region")
             sc = scenes.config_scene("c3")
             extra["c3"] = slim(measure(env, sc, 1, 0, k, w, "k_g2p_pair<plastic>"), sc["name"])
+            # BASELINE.json configs[3] on ONE GPU (the config names four; it fits one: 8 M particles = 3.3 GB): corotated elasticity — an SVD per
+            # particle, the reference's default model (src/models/linear_elasticity.wgsl:28-41) — with the floor and one kinematic
+            # rotating cuboid pushed into the cube (a body whose velocity the host sets and whose pose the device integrates every
+            # substep: crates/wgsparkl3d/examples/sand3.rs:95-103); 100 substeps before the timed region, so that the cuboid is in contact
+            sc = scenes.config_scene("c4")
+            extra["c4"] = slim(measure(env, sc, 1, 0, k, w, KERNEL_ELASTIC, settle=100), sc["name"] + ", one GPU, 100 substeps before the timed region")
             # the size the reference itself ships (its scenes hold 75 k - 490 k particles): latency-bound here, four dependent launches
             sc = scenes.reference_sand3()
             extra["sand3_202k"] = slim(measure(env, sc, 1, 0, k, w, "k_g2p_pair<plastic>", settle=100), sc["name"] + ", 100 substeps before the timed region")

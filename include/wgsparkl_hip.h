@@ -187,6 +187,12 @@ int32_t wgs_dim(void);
 /* Build identification: dimension, target arch and — never in a shipped library — "WGS_ABLATE" when the kernels were
  * compiled with their ablation switches (bench.py refuses such a build). */
 const char *wgs_build_info(void);
+/* Version of this header's structs and entry points as the LIBRARY was built (WGS_ABI_VERSION as the caller was): the structs carry no
+ * size field — wgs_get_stats writes sizeof(wgs_stats) of ITS header —, so a binding checks wgs_abi_version() == WGS_ABI_VERSION once,
+ * after loading the library, and refuses to go on otherwise (include/wgsparkl_hip.hpp and wgsparkl_amd/_ffi.py do). History: 5 =
+ * wgs_stats grew by block_ids .. table_refreshes (24 bytes); 6 = this function. New counters will come behind a call of their own. */
+#define WGS_ABI_VERSION 6
+uint32_t wgs_abi_version(void);
 
 /* MpmPipeline::new(&Device) -> Result<Self, ComposerError>  (src/pipeline.rs:176-193).
  * Binds to HIP device `hip_device`; fails with WGS_ERR_NO_DEVICE when there is none

@@ -70,6 +70,8 @@ class MpmData;
 class MpmPipeline {
   public:
     static MpmPipeline create(int hip_device) {
+        // (the structs carry no size field: a library built from another header version is refused here, once — wgsparkl_hip.h)
+        if (wgs_abi_version() != WGS_ABI_VERSION) throw Error(WGS_ERR_INVALID_ARGUMENT, "libwgsparkl_hip was built from another version of wgsparkl_hip.h");
         wgs_pipeline *p = nullptr;
         check(wgs_pipeline_create(hip_device, &p));
         return MpmPipeline(p);

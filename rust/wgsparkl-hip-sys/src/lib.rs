@@ -157,6 +157,9 @@ pub struct wgs_comm {
 pub const WGS_COMM_ID_BYTES: usize = 128;
 pub const WGS_COMM_SELF_NEIGHBOURS: i32 = 1;
 
+/// include/wgsparkl_hip.h WGS_ABI_VERSION as this file mirrors it
+pub const ABI_VERSION: u32 = 6;
+
 extern "C" {
     pub fn wgs_last_error() -> *const c_char;
     pub fn wgs_dim() -> i32;
@@ -195,6 +198,8 @@ extern "C" {
     pub fn wgs_get_stats(d: *mut wgs_data, out: *mut wgs_stats) -> wgs_status;
     pub fn wgs_read_timing_overhead(d: *mut wgs_data, ms_per_mark: *mut f32) -> wgs_status;
     pub fn wgs_build_info() -> *const c_char;
+    /// WGS_ABI_VERSION of the header the library was built from; a binding compares it with `ABI_VERSION` once after loading
+    pub fn wgs_abi_version() -> u32;
     pub fn wgs_set_grid_growth(d: *mut wgs_data, enabled: i32) -> wgs_status;
     pub fn wgs_set_uniform_material(d: *mut wgs_data, mass: f32, init_volume: f32, lambda: f32, mu: f32) -> wgs_status;
     /// test hook: the device scan on caller data (prefix_sum.rs:183-229 vectors)

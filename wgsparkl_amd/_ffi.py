@@ -12,6 +12,7 @@ import subprocess
 _CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 
 WGS_OK = 0
+ABI_VERSION = 6   # include/wgsparkl_hip.h WGS_ABI_VERSION
 WGS_NUM_PASSES = 10
 PASS_NAMES = ("update rigid particles", "grid sort", "grid_update_cdf", "p2g_cdf", "g2p_cdf", "p2g",
               "grid_update", "g2p", "particles_update", "integrate_bodies")  # src/pipeline.rs:201-271
@@ -25,7 +26,7 @@ EXPORTS = (
     "wgs_shard_buffer_header_bytes", "wgs_set_stream", "wgs_shard_export",
     # one call per frame on sharded data (RCCL inside the library) + build identification
     "wgs_comm_get_unique_id", "wgs_comm_create", "wgs_comm_destroy", "wgs_shard_attach", "wgs_sharded_step",
-    "wgs_sharded_step_lockstep", "wgs_build_info", "wgs_debug_scan", "wgs_set_grid_growth", "wgs_set_uniform_material",
+    "wgs_sharded_step_lockstep", "wgs_build_info", "wgs_abi_version", "wgs_debug_scan", "wgs_set_grid_growth", "wgs_set_uniform_material",
 )
 
 
@@ -176,6 +177,9 @@ def load(dim: int):
     lib.wgs_set_stream.argtypes = [vp, vp]
     lib.wgs_shard_export.argtypes = [vp, vp, C.c_uint32, u32p]
     lib.wgs_build_info.restype = C.c_char_p
+    lib.wgs_abi_version.restype = C.c_uint32
+    if lib.wgs_abi_version() != ABI_VERSION:   # (the structs carry no size field: include/wgsparkl_hip.h WGS_ABI_VERSION)
+        raise RuntimeError(f"{path}: ABI version {lib.wgs_abi_version()}, this binding mirrors {ABI_VERSION} — rebuild the library (csrc/build.sh)")
     lib.wgs_set_grid_growth.argtypes = [vp, C.c_int32]
     lib.wgs_set_uniform_material.argtypes = [vp, C.c_float, C.c_float, C.c_float, C.c_float]
     lib.wgs_debug_scan.argtypes = [vp, u32p, C.c_uint32, u32p, u32p]

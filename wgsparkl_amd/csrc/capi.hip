@@ -654,6 +654,8 @@ wgs_status sticky_status(wgs_data *d) {
         return fail(WGS_ERR_KEY_RANGE, "a particle left the packed block-key range (grid.wgsl:88-95)");
     if (d->sticky_errors & ERRBIT_HANDOVER)
         return fail(WGS_ERR_HIP, "internal: a grid-update wave gave up waiting for a block's P2G slab (the sort's block totals and cell runs disagree)");
+    if (d->sticky_errors & ERRBIT_PCDF)
+        return fail(WGS_ERR_HIP, "internal: a near-collider workgroup of P2G gave up waiting for the prologue waves of its launch and computed the particle cdf itself (results intact; the launch lost 0.2 s)");
     if (d->sticky_errors & ERRBIT_MATERIAL)
         return fail(WGS_ERR_INVALID_ARGUMENT, "wgs_set_uniform_material: a particle of this wgs_data carries other constants (mass, init_volume, lambda, mu)");
     return WGS_OK;
@@ -1049,6 +1051,7 @@ extern "C" {
 
 const char *wgs_last_error(void) { return g_last_error.c_str(); }
 int32_t wgs_dim(void) { return D; }
+uint32_t wgs_abi_version(void) { return WGS_ABI_VERSION; }
 const char *wgs_build_info(void) {
     return "wgsparkl_hip dim=" WGS_STR(WGS_DIM) " arch=gfx950"
 #ifdef WGS_ABLATE

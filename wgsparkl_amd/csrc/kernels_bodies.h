@@ -116,7 +116,13 @@ template <int D> __device__ inline void bodies_integrate_one(const Dev &d, uint3
         bool rest = true;
         for (int k = 0; k < D; k++) rest = rest && nl[k] == 0.f && (b.inv_mass[k] == 0.f || d.sp->gravity[k] == 0.f);
         for (int k = 0; k < ANG; k++) rest = rest && na[k] == 0.f;
-        if (rest) return;
+        if (rest) {
+            // (the velocity all the same: an impulse that cancels a body's velocity exactly leaves nl = 0 with c.linvel != 0 — the reference
+            // writes the zero, rigid_impulses.wgsl:128-131; storing 0 over 0 keeps a fixed collider bit-static)
+            for (int k = 0; k < D; k++) c.linvel[k] = nl[k];
+            for (int k = 0; k < ANG; k++) c.angvel[k] = na[k];
+            return;
+        }
     }
     // Body::integrateVelocity: rotate about the world centre of mass by exp(angvel dt), translate by linvel dt
     float comw[3] = {0.f, 0.f, 0.f}, arm[3] = {0.f, 0.f, 0.f}, rarm[3] = {0.f, 0.f, 0.f};

@@ -481,7 +481,11 @@ __device__ __forceinline__ uint32_t regroup_block(const Dev &d, int side, uint32
         // (a body crossing the grid: every few hundred substeps). Whoever still holds the id as "a neighbour that is in the table"
         // (nbr_known) compares the key before trusting it: block_key of an evicted id is NONE until the id is handed out again.
         if constexpr (!SHARD) {
-            if (d.free_ids != nullptr && lane == 0 && (epoch & (EVICT_AGE - 1u)) == 0u && stamp != 0u && epoch - stamp > EVICT_AGE && bkey != NONE) {
+            // (bounded on the device: while the marks hold a quarter of the table's 2 x cap slots nobody is evicted — live blocks + marks
+            // then stay below 1.5 x cap whatever the host's look is late by, and a probe sequence always ends: the host clears the marks,
+            // capi.hip maintain_grid -> k_table_refresh, and eviction goes on)
+            if (d.free_ids != nullptr && lane == 0 && (epoch & (EVICT_AGE - 1u)) == 0u && stamp != 0u && epoch - stamp > EVICT_AGE && bkey != NONE &&
+                d.counters[CTR_NTOMB] <= d.cap / 2u) {
                 const uint32_t hs = d.block_slot[id];
                 d.hkeys[hs] = KEY_TOMB;
                 d.hvals[hs] = NONE;   // (like an empty slot's: an insertion that takes the slot publishes its id here)

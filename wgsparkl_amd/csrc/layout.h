@@ -139,7 +139,8 @@ constexpr uint32_t CTR_PARITY = 16;
 __host__ __device__ inline uint32_t ctr_ncpic(uint32_t k, uint32_t epoch) { return (uint32_t)CTR_NCPIC + 32u * k + CTR_PARITY * (epoch & 1u); }
 __host__ __device__ inline uint32_t ctr_nvisit(uint32_t k, uint32_t epoch) { return (uint32_t)CTR_NVISIT + 32u * k + CTR_PARITY * (epoch & 1u); }
 __host__ __device__ inline uint32_t ctr_nhalo(uint32_t epoch) { return (uint32_t)CTR_NHALO + CTR_PARITY * (epoch & 1u); }
-enum { ERRBIT_OVERFLOW = 1u, ERRBIT_KEYRANGE = 2u, ERRBIT_SHARD = 4u, ERRBIT_MATERIAL = 8u, ERRBIT_HANDOVER = 16u };
+enum { ERRBIT_OVERFLOW = 1u, ERRBIT_KEYRANGE = 2u, ERRBIT_SHARD = 4u, ERRBIT_MATERIAL = 8u, ERRBIT_HANDOVER = 16u,
+       ERRBIT_PCDF = 32u };   // a CPIC workgroup of P2G gave up waiting for the prologue waves' particle cdf and computed it itself (results intact)
 // Bit 31 of a perm_cell entry (block ids stay below 2^24): the particle's block is near a collider. Written by launch 2 of the
 // sort when it computes the block classes itself; the fused G2P then knows which body a particle belongs to from the sort
 // entry it loads anyway, instead of a dependent block_cpic lookup in the middle of every chunk.
