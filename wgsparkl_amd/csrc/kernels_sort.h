@@ -340,12 +340,8 @@ __device__ __forceinline__ void scan_chunk(const Dev &d, uint32_t epoch, uint32_
         const bool act = first + j < nphys && stamp[j] == epoch;
         sum += act ? ((1ull << 32) | (unsigned long long)acc[j]) : 0ull;
     }
-    unsigned long long inc = sum;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        const unsigned long long t = __shfl_up(inc, off);
-        if (lane >= off) inc += t;
-    }
+    // (the two words scanned separately — the particle total of a launch stays below 2^32 — by DPP: layout.h wave_scan_incl_u32)
+    const unsigned long long inc = ((unsigned long long)wave_scan_incl_u32((uint32_t)(sum >> 32)) << 32) | (unsigned long long)wave_scan_incl_u32((uint32_t)sum);
     if (lane == 63) s_wave[wave] = inc;
     __syncthreads();
     unsigned long long wave_off = 0ull, total = 0ull;
@@ -366,8 +362,7 @@ __device__ __forceinline__ void scan_chunk(const Dev &d, uint32_t epoch, uint32_
     unsigned long long part = 0ull;
     for (uint32_t p = (uint32_t)tid; p < k; p += SORT_THREADS)
         part += ((unsigned long long)wait_tagged(&d.chunk_a[p], epoch) << 32) + wait_tagged(&d.chunk_b[p], epoch);
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) part += __shfl_xor(part, off);
+    part = ((unsigned long long)wave_sum_u32((uint32_t)(part >> 32)) << 32) + (unsigned long long)wave_sum_u32((uint32_t)part);   // (each word below 2^32)
     __syncthreads();  // s_wave consumed above
     if (lane == 0) s_wave[wave] = part;
     __syncthreads();
@@ -419,9 +414,7 @@ __device__ inline void block_prefix(const Dev &d, uint32_t epoch, uint32_t id, i
     const bool before = lane < (int)j && gbase + (uint32_t)lane < nphys && g.stamp == epoch;
     const uint32_t cnt = (uint32_t)__popcll(__ballot(before));
     uint32_t psum = before ? g.acc : 0u;
-#pragma unroll
-    for (int off = 8; off > 0; off >>= 1) psum += __shfl_xor(psum, off);   // lanes 0..15 hold the terms
-    psum = __shfl(psum, 0);
+    psum = wave_sum_u32(psum);   // (lanes 0..15 hold the terms, the others zero)
     const uint32_t grp = id / SCAN_ITEMS;
     aidx = wait_tagged(&d.group_a[grp], epoch) + cnt;
     start = wait_tagged(&d.group_b[grp], epoch) + psum;
@@ -515,7 +508,7 @@ __device__ __forceinline__ uint32_t regroup_block(const Dev &d, int side, uint32
     const bool links_valid = old_ok;
     // ---- stage the new cell ids of the block's previous run (contiguous: cells are consecutive runs); with movers
     // into this block also the particle ids of the run (the merge compares them)
-    const uint32_t run0 = __shfl(cs_old, 0), run1 = __shfl(ce_old, 63);
+    const uint32_t run0 = lane_value(cs_old, 0), run1 = lane_value(ce_old, 63);
     const uint32_t runlen = run1 - run0;
     const bool in_lds = runlen <= (uint32_t)RUNCAP;
     const uint32_t narr_in = min(narr, BLK_ARR);          // (wave-uniform)
@@ -609,7 +602,7 @@ __device__ __forceinline__ uint32_t regroup_block(const Dev &d, int side, uint32
     };
     WGS_PROF(1)
     // (the block's particle total is known before its runs are: launch 1's count, or the count kept up to date by the fused G2P)
-    const uint32_t bcount = __shfl(grp.acc, (int)(id & (uint32_t)(SCAN_ITEMS - 1)));
+    const uint32_t bcount = lane_value(grp.acc, (int)(id & (uint32_t)(SCAN_ITEMS - 1)));
     uint32_t pc_flag = 0u;  // CELL_LISTED for the perm_cell entries of a block near a collider
     bool listed = false;  // near a collider and holding particles: on the lists of the CPIC bodies of P2G / G2P
     // ---- node cdf tile + block class (independent of the scan: placed before the wait for it)
@@ -921,13 +914,8 @@ __device__ __forceinline__ uint32_t regroup_block(const Dev &d, int side, uint32
                 }
     }
     const uint32_t total = n_stay + n_arr;
-    uint32_t inc = total;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        const uint32_t t = __shfl_up(inc, off);
-        if (lane >= off) inc += t;
-    }
-    const uint32_t btotal = __shfl(inc, 63);
+    const uint32_t inc = wave_scan_incl_u32(total);
+    const uint32_t btotal = lane_value(inc, 63);
     const uint32_t lstart = inc - total;  // start of this cell's run inside the block
     WGS_PROF(2)
     // ---- pass 2: merge in ascending particle id. Stayers are in id order already; the next arrival is selected
@@ -1264,14 +1252,9 @@ __device__ __forceinline__ uint32_t regroup_block(const Dev &d, int side, uint32
     uint32_t movers = 0u;
     if (have_old) {   // (every particle is an arrival on a table-rebuild substep)
         if (par) {
-            movers = n_moved;
-#pragma unroll
-            for (int off = 32; off > 0; off >>= 1) movers += __shfl_xor(movers, off);
-            movers += narr_in;
+            movers = wave_sum_u32(n_moved) + narr_in;
         } else {
-            movers = n_arr;
-#pragma unroll
-            for (int off = 32; off > 0; off >>= 1) movers += __shfl_xor(movers, off);
+            movers = wave_sum_u32(n_arr);
         }
     }
     return movers;

@@ -414,6 +414,21 @@ __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
     v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false));  // row_bcast:31 into rows 2 and 3
     return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
 }
+// Inclusive prefix sum over the 64 lanes, likewise (rows of 16 by row_shr 1 / 2 / 4 / 8, then lane 15 of rows 0 and 2 into rows 1 and 3,
+// then lane 31 into rows 2 and 3): six VALU instructions where the __shfl_up ladder is six dependent ds_bpermute round trips — a wave
+// of launch 2 of the sort made two dozen such round trips per block, a quarter of its 5.6 us at rest. All 64 lanes must be active.
+__device__ __forceinline__ uint32_t wave_scan_incl_u32(uint32_t v) {
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, true);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, true);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, true);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, true);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);
+    return v;
+}
+__device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v) { return (uint32_t)__builtin_amdgcn_readlane((int)wave_scan_incl_u32(v), 63); }
+// the value of a wave-uniform lane, by v_readlane instead of a ds_bpermute round trip
+__device__ __forceinline__ uint32_t lane_value(uint32_t v, int uniform_lane) { return (uint32_t)__builtin_amdgcn_readlane((int)v, uniform_lane); }
 // persistent particle id (the caller's index) lives after the quads
 template <int D> __device__ inline uint32_t ldpid(const float *base, uint32_t npad, uint32_t i) {
     uint32_t off = ((uint32_t)Pl<D>::NQ * 4u * npad + i) * 4u;
