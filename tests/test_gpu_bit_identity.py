@@ -524,3 +524,34 @@ def test_direct_runs_of_unchanged_blocks_give_the_bits_of_the_gather_through_the
         assert np.array_equal(np.asarray(x), np.asarray(y))
     if scene == "flying":
         assert sta["cell_changers"] > 0   # (the scene does move: blocks are dirty)
+
+
+def test_large_two_way_scenes_with_the_near_collider_launch_first_give_the_bits_of_the_other_order(hip_libs, monkeypatch):
+    """Large simulations with a body that moves (>= 600 k particles: BASELINE.json configs[3]) run P2G as two launches; since round 6 the
+    near-collider launch goes FIRST and the grid update rides behind the plain launch (at the plain body's occupancy instead of the two-way
+    body's). Same slabs, same gather: the bits of the plain-launch-first order (WGS_DEBUG = 67108864), also across a host look."""
+    from helpers import pipeline
+    from wgsparkl_amd import MpmData
+    sc = scenes.config_scene("c4", n_side=86)
+    assert sc["particles"].n >= 600_000
+
+    def run():
+        pipe = pipeline(3)
+        data = MpmData.new(pipe, sc["params"], sc["particles"], sc["colliders"], sc["cell_width"], sc["grid_capacity"], sc["model"])
+        pipe.step(data, 30)
+        data.sync()
+        pipe.step(data, 30)
+        data.sync()
+        st = data.stats()
+        assert st["overflow"] == 0 and st["num_near_collider_blocks"] > 0
+        return data.read_particles(), data.read_grid(), data.read_body_poses()
+    a, ga, pa = run()
+    monkeypatch.setenv("WGS_DEBUG", "67108864")
+    b, gb, pb = run()
+    for f in ("pos", "vel", "def_grad", "affine", "cdf_affinity"):
+        assert np.array_equal(getattr(a, f), getattr(b, f)), f
+    for x, y in zip(ga, gb):
+        assert np.array_equal(np.asarray(x), np.asarray(y))
+    for x, y in zip(pa, pb):
+        for key in ("rotation", "translation", "linvel", "angvel"):
+            assert np.array_equal(np.asarray(x[key]), np.asarray(y[key])), key

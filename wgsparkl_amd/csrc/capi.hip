@@ -342,7 +342,7 @@ void fill_collider(ColliderDev &c, const wgs_collider &in) {
     for (int k = 0; k < 3; k++) c.com[k] = in.com[k];
 }
 
-constexpr uint32_t WGS_LAUNCH_SHAPE_SWITCHES = 2u | 4u | 8u | 128u | 1024u | 2048u | 4096u | 8192u | 16384u | 32768u | 65536u | 131072u | 262144u | 524288u | 1048576u | 4194304u | 8388608u | 16777216u | 33554432u;  // WGS_DEBUG bits the shipped library honours
+constexpr uint32_t WGS_LAUNCH_SHAPE_SWITCHES = 2u | 4u | 8u | 128u | 1024u | 2048u | 4096u | 8192u | 16384u | 32768u | 65536u | 131072u | 262144u | 524288u | 1048576u | 4194304u | 8388608u | 16777216u | 33554432u | 67108864u;  // WGS_DEBUG bits the shipped library honours
 #ifndef WGS_PCDF_WAVES_MAX_VISITS
 #define WGS_PCDF_WAVES_MAX_VISITS 256
 #endif
@@ -903,6 +903,19 @@ template <bool TS> wgs_status enqueue_substep(wgs_data *d, int ts_slot, int part
                 if (d->two_way) WGS_P2G_PAIR(true, 1);
                 else if (big_one_way) WGS_P2G_PAIR(false, 3);
                 else WGS_P2G_PAIR(false, 1);
+            } else if (d->cpic && big_two_way && gum == 2 && !(dev.dbg & 67108864u)) {
+                // Large two-way simulations on a single domain: the near-collider launch FIRST, the plain launch behind it with the grid
+                // update riding in IT. The grid-update waves take the registers of the launch they ride in: behind the two-way body (209
+                // registers, two waves per SIMD) the update of every block of the scene ran at two thirds of the occupancy it has behind
+                // the plain body (160), and started only when the last near-collider workgroup — a 30 us chain each — had a slot. Same
+                // sums in the same order (WGS_DEBUG bit 26 = the plain launch first, as before: tested bit-identical).
+                {
+                    dev.pcdf_waves = npro;
+                    const dim3 lg(npro + p2g_wgs);
+                    hipLaunchKernelGGL((k_p2g<D, true, true, true, 1>), lg, p2g_block, 0, s, dev, side, 2, epoch, p2g_wgs, 0u, 0u, layer_sel, npro);
+                    dev.pcdf_waves = 0u;
+                }
+                hipLaunchKernelGGL((k_p2g<D, false, false, false, 2, true>), dim3(p2g_wgs + ride), p2g_block, 0, s, dev, side, 1, epoch, p2g_wgs, npack, npack_blk, layer_sel, 0u);
             } else if (d->cpic) {
                 // (the first of the two launches hands its slabs over like the last one when anything rides in that one)
                 if (gum != 0) hipLaunchKernelGGL((k_p2g<D, false, false, false, 1>), p2g_grid, p2g_block, 0, s, dev, side, 1, epoch, p2g_wgs, 0u, 0u, layer_sel, 0u);
@@ -1145,7 +1158,8 @@ static wgs_status create_impl(wgs_pipeline *pipeline, const wgs_sim_params *para
     // lockstep slab split into its boundary layers and the rest (the shape wgs_sharded_step uses when it forks), 8388608 =
     // wgs_sharded_step forks the exchange onto a second stream beside the interior's P2G (measured slower here: capi_sharded.inc),
     // 16777216 = launch 2 of the sort orders the cells of a dirty block by insertion instead of by ranks (kernels_sort.h),
-    // 33554432 = P2G gathers every block through the sort permutation (no direct runs for unchanged blocks: layout.h CELL_DIRECT).
+    // 33554432 = P2G gathers every block through the sort permutation (no direct runs for unchanged blocks: layout.h CELL_DIRECT),
+    // 67108864 = large two-way simulations run the plain P2G launch in front of the near-collider one (round 5's order).
     // The ablations that change the RESULTS (64 = G2P moves bytes only, 256 = P2G without its accumulation loop,
     // 512 = P2G without its particle loads) exist only in builds with -DWGS_ABLATE; the shipped library ignores them.
     dev.dbg = getenv("WGS_DEBUG") ? (uint32_t)strtoul(getenv("WGS_DEBUG"), nullptr, 0) : 0u;

@@ -240,7 +240,9 @@ template <int D> __device__ __forceinline__ void pcdf_waves(const Dev &d, int si
     }
 }
 
-template <int D, bool CPIC, bool TWOWAY = false, bool PCDF = false, int GU = 0>
+// GUTW: the grid-update waves that ride in this launch gather the bodies' impulses (two-way coupling) although the launch's own body does not
+// accumulate any — the plain launch of a large two-way simulation, run BEHIND the near-collider launch (capi.hip).
+template <int D, bool CPIC, bool TWOWAY = false, bool PCDF = false, int GU = 0, bool GUTW = TWOWAY>
 __global__ __launch_bounds__(P2GCfg<D>::NW * 64) void k_p2g(Dev d, int side, int filter, uint32_t epoch, uint32_t nblk, uint32_t npack, uint32_t npack_blk, uint32_t layer_sel, uint32_t npro) {
     using Cfg = P2GCfg<D>;
     constexpr int TILE = Dim<D>::TILE;
@@ -256,7 +258,7 @@ __global__ __launch_bounds__(P2GCfg<D>::NW * 64) void k_p2g(Dev d, int side, int
     const uint32_t wg = blockIdx.x - (PCDF ? npro : 0u), nwg = gridDim.x - (PCDF ? npro : 0u);
     if constexpr (GU == 2) {
         if (wg >= nblk) {
-            gu_waves<D, TWOWAY>(d, epoch, (wg - nblk) * Cfg::NW + (threadIdx.x >> 6), (nwg - nblk) * Cfg::NW, (int)(threadIdx.x & 63u));
+            gu_waves<D, GUTW>(d, epoch, (wg - nblk) * Cfg::NW + (threadIdx.x >> 6), (nwg - nblk) * Cfg::NW, (int)(threadIdx.x & 63u));
             return;
         }
     }
@@ -265,7 +267,7 @@ __global__ __launch_bounds__(P2GCfg<D>::NW * 64) void k_p2g(Dev d, int side, int
             const uint32_t t = wg - nblk, w = threadIdx.x >> 6;
             const int lane = (int)(threadIdx.x & 63u);
             if (t < npack) pack_face_body<D, true>(d, side, epoch, t * Cfg::NW + w, npack_blk, npack * Cfg::NW, lane);
-            else gu_waves<D, TWOWAY, true>(d, epoch, (t - npack) * Cfg::NW + w, (nwg - nblk - npack) * Cfg::NW, lane);
+            else gu_waves<D, GUTW, true>(d, epoch, (t - npack) * Cfg::NW + w, (nwg - nblk - npack) * Cfg::NW, lane);
             return;
         }
     }
