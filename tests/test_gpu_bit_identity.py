@@ -44,6 +44,37 @@ def test_uniform_material_mode_is_bit_identical(hip_libs, monkeypatch):
         assert np.array_equal(ga[0], gb[0]) and np.array_equal(ga[1], gb[1])
 
 
+@pytest.mark.parametrize("dim", [2, 3])
+def test_uniform_plasticity_parameters_give_the_bits_of_the_general_layout(hip_libs, monkeypatch, dim):
+    """Round 6 (layout.h Dev::uni_dp): when every particle carries the same Drucker-Prager h0..h3 the plastic fused G2P takes them
+    as kernel arguments and leaves the DP0 quad alone (mode 1); when lambda, mu of the plasticity and max_stretch are shared as well,
+    the per-particle plastic state is ONE quad (mode 2). Decided at creation, bitwise. Four clouds — everything shared with a
+    breakable phase (mode 2), every other particle with its own plastic lambda / mu (mode 1), with its own max_stretch (mode 1),
+    with its own h0 (general layout) — against WGS_DEBUG = 65536 (never a uniform mode): same bits, and the read-back shows the
+    caller's parameters."""
+    def cloud(kind):
+        ps = scenes.random_cloud(2500, dim=dim, seed=11 + kind, extent=9.0, young=1e6, plasticity=DruckerPrager.new(1e6, 0.25),
+                                 phase=ParticlePhase(1.0, 1.04) if kind != 3 else None)
+        if kind == 1: ps.dp[::2, 4:6] *= np.float32(1.5)
+        if kind == 2: ps.phase[::2, 1] = np.float32(1.08)
+        if kind == 3: ps.dp[::2, 0] *= np.float32(0.9)
+        return ps
+    cols = [Collider.cuboid((50.0,) * dim, (5.0, -49.0) + ((5.0,) if dim == 3 else ()), **({} if dim == 3 else {"rotation": (0.0,)}))]
+    for kind in range(4):
+        def run():
+            ps = cloud(kind)
+            sc = dict(particles=ps, params=SimulationParams((0.0, -9.81, 0.0)[:dim], 5e-4), colliders=cols, cell_width=1.0, grid_capacity=4096, model=MODEL_COROTATED)
+            return ps, run_gpu(sc, 30).read_particles()
+        ps, a = run()
+        monkeypatch.setenv("WGS_DEBUG", "65536")
+        _, b = run()
+        monkeypatch.delenv("WGS_DEBUG")
+        for f in ("pos", "vel", "def_grad", "affine", "dp", "dp_state", "phase"):
+            assert np.array_equal(getattr(a, f), getattr(b, f)), (kind, f)
+        assert np.array_equal(a.dp, ps.dp) and np.array_equal(a.phase[:, 1], ps.phase[:, 1]), kind
+        assert (a.dp_state != np.array([1.0, 1.0, 0.0], np.float32)).any() and (kind == 3 or (a.phase[:, 0] == 0.0).any()), "the scene should have yielded and broken by now"
+
+
 def test_g2p_launch_shapes_are_bit_identical(hip_libs, monkeypatch):
     """The fused G2P advances one chunk of 64 sorted particles per wave, or — from 1.5 M particles on, where the launch is
     bound by latency x occupancy — two, with both chunks' particle state requested up front (kernels_transfer.h). The

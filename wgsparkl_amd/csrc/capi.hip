@@ -420,6 +420,15 @@ template <int DIM> __device__ inline void fix_uniform(const Dev &d, Unpacked &u)
             u.mass = d.uni_mass; u.vol = d.uni_vol; u.lam = d.uni_lambda; u.mu = d.uni_mu;
         }
     }
+    // uniform plasticity parameters (layout.h Dev::uni_dp): in mode 2 DP1 holds (st0, st1, st2, phase) — unpack_slot read it as
+    // (dp4, dp5, st0, st1) — and DP2 is not kept up to date
+    if (d.uni_dp == 2u) {
+        const float s0 = u.dp[4], s1 = u.dp[5], s2 = u.st[0], ph = u.st[1];
+        u.st[0] = s0; u.st[1] = s1; u.st[2] = s2;
+        u.phase[0] = ph; u.phase[1] = d.uni_max_stretch;
+    }
+    if (d.uni_dp != 0u)
+        for (int k = 0; k < (d.uni_dp == 2u ? 6 : 4); k++) u.dp[k] = d.uni_dpv[k];
 }
 
 // general layout -> uniform-material layout: F[8] takes the place of the mass in XM.w
@@ -491,9 +500,15 @@ __global__ void k_import_plastic_state(Dev d, int side, const float *states) {
         if (pid == 0xffffffffu) continue;  // vacated slot of a sharded run
         const float *st = states + (size_t)pid * 3;
         float4 q1 = ldq(buf, npad, P::DP1, j), q2 = ldq(buf, npad, P::DP2, j);
-        q1.z = st[0];
-        q1.w = st[1];
-        q2.x = st[2];
+        if (d.uni_dp == 2u) {   // (the state is one quad: layout.h)
+            q1.x = st[0];
+            q1.y = st[1];
+            q1.z = st[2];
+        } else {
+            q1.z = st[0];
+            q1.w = st[1];
+            q2.x = st[2];
+        }
         stq(buf, npad, P::DP1, j, q1);
         stq(buf, npad, P::DP2, j, q2);
     }
@@ -1263,6 +1278,26 @@ static wgs_status create_impl(wgs_pipeline *pipeline, const wgs_sim_params *para
         if ((phase == 0.0f && dp[4] != 0.0f) || (phase > 0.0f && max_stretch > 0.0f && max_stretch < FLT_MAX)) plastic = true;
     }
     d->plastic = plastic || force_plastic != 0;
+    // uniform plasticity parameters (bitwise; single-domain data, like the automatic uniform-material mode; layout.h Dev::uni_dp):
+    // 1 = one set of h0..h3, 2 = all six and max_stretch — the per-particle state is then packed into DP1 before the upload
+    if (d->plastic && n > 0 && !sharded && !(dev.dbg & 65536u)) {
+        bool u4 = true, u6 = true;
+        for (uint32_t i = 1; i < n && u4; i++) {
+            u4 = memcmp(&s_dp[(size_t)i * 6], &s_dp[0], 4 * sizeof(float)) == 0;
+            u6 = u6 && memcmp(&s_dp[(size_t)i * 6 + 4], &s_dp[4], 2 * sizeof(float)) == 0 && memcmp(&s_phase[(size_t)i * 2 + 1], &s_phase[1], sizeof(float)) == 0;
+        }
+        if (u4) {
+            dev.uni_dp = u6 ? 2u : 1u;
+            for (int k = 0; k < 6; k++) dev.uni_dpv[k] = s_dp[k];
+            dev.uni_max_stretch = s_phase[1];
+            if (u6)
+                for (uint32_t i = 0; i < n; i++) {
+                    float *q1 = quad(P::DP1, i);
+                    const float *q2 = quad(P::DP2, i);
+                    q1[0] = q1[2]; q1[1] = q1[3]; q1[2] = q2[0]; q1[3] = q2[1];   // (st0, st1, st2, phase)
+                }
+        }
+    }
     // one material for all particles (bitwise)? -> uniform-material mode (layout.h). Sharded data: the caller says so
     // (wgs_set_uniform_material), a rank cannot know the other ranks' particles.
     bool uniform = D == 3 && n > 0 && !sharded && !(dev.dbg & 65536u);
@@ -1313,6 +1348,13 @@ static wgs_status create_impl(wgs_pipeline *pipeline, const wgs_sim_params *para
         dev.uni_lambda = particles[0].model.lambda;
         dev.uni_mu = particles[0].model.mu;
         hipLaunchKernelGGL(k_to_uniform, dim3(grid_for(d, 4)), dim3(256), 0, d->stream, dev, 0, 0);
+    }
+    if (dev.uni_dp != 0u) {   // (the other ping-pong buffer's copy of the quads the step leaves alone: layout.h Dev::uni_dp)
+        for (int qd : {(int)Pl<D>::DP0, (int)Pl<D>::DP2}) {
+            const size_t plane = (size_t)qd * dev.npad * 4;   // (floats: quad q of slot i sits at float (q * npad + i) * 4)
+            if (hipMemcpyAsync(dev.buf[1] + plane, dev.buf[0] + plane, (size_t)dev.npad * 16, hipMemcpyDeviceToDevice, d->stream) != hipSuccess)
+                return bail(fail(WGS_ERR_HIP, "hipMemcpy D2D failed"));
+        }
     }
     if (hipStreamSynchronize(d->stream) != hipSuccess) return bail(fail(WGS_ERR_HIP, "initial upload failed"));
     *out = d;

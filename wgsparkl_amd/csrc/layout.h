@@ -280,6 +280,15 @@ struct Dev {
     // (wgs_set_uniform_material); the general layout remains for everything else.
     uint32_t uniform;
     float uni_mass, uni_vol, uni_lambda, uni_mu;
+    // (round 6) The same for the plasticity parameters, on single-domain data, decided at creation (bitwise comparison of all particles):
+    //   uni_dp = 1: one set of DruckerPrager h0..h3 (the DP0 quad) — the plastic fused G2P takes the four from here and neither reads
+    //               nor rewrites the quad: both ping-pong buffers hold it for every slot from the upload on;
+    //   uni_dp = 2: lambda, mu of the plasticity and max_stretch are shared as well — the whole per-particle plastic STATE is then one
+    //               quad, DP1 = (plastic det, plastic hardening, log_vol_gain, phase), and DP2 drops out of the step too.
+    // 32 / 64 of the plastic step's 216 + bytes per particle. Whoever else touches these quads (export, checkpoint restore) goes
+    // through unpack_slot + fix_uniform / k_import_plastic_state, which know the mode; slabs of a decomposition never use it.
+    uint32_t uni_dp;
+    float uni_dpv[6], uni_max_stretch;
     int model;           // WGS_MODEL_*
     uint32_t dbg;        // launch-shape A/B switches (env WGS_DEBUG; same results, see capi.hip), 0 in production. The
                          // result-changing ablations only exist in builds with -DWGS_ABLATE (never the shipped library)
