@@ -333,6 +333,52 @@ def test_particles_enter_an_empty_slab_and_leave_theirs_empty(hip_libs, with_flo
         assert err < tol, (f, err)
 
 
+def test_slabs_evict_the_blocks_a_body_leaves_behind(hip_libs):
+    """Round 6: slabs of a decomposition evict their long-inactive blocks like single-domain data (kernels_sort.h regroup_block; until now a slab
+    rebuilt its table every 1 024 substeps and whenever a moving body had used up the ids). A 16^3 cube flies through three slabs at a third of
+    a cell per substep, with a block capacity that 150 substeps of its trail would exhaust: every slab builds its table once, ids come back
+    on the free lists, nothing overflows, and the particles are those of the single-domain run."""
+    from helpers import pipeline
+    from wgsparkl_amd.sharded import NativeShard, SlabPartition, associated_block_x, native_lockstep, split_scene, uniform_material_of
+    sc = scenes.neo_hookean_cube(n_side=16, with_floor=False)
+    ps = sc["particles"]
+    ps.vel[:, 0] = 400.0
+    ps.vel[:, 1] = 0.0
+    sc["params"] = SimulationParams((0.0, 0.0, 0.0), sc["params"].dt)
+    sc["grid_capacity"] = 256                                  # the cube holds ~64 blocks at a time and touches ~40 new ones every dozen substeps
+    k = 150                                                    # 50 cells
+    ref_data = run_gpu(sc, k)
+    ref = ref_data.read_particles()
+    assert ref_data.stats()["overflow"] == 0
+    bx = associated_block_x(ps.pos, sc["cell_width"], 3)
+    b0 = int(bx.min())
+    part = SlabPartition([b0, b0 + 5, b0 + 10, b0 + 18])
+    pipe = pipeline(3)
+    shards = []
+    for r, (sub, gids) in enumerate(split_scene(ps, part, sc["cell_width"])):
+        lo, hi = part.block_range(r)
+        shards.append(NativeShard(pipe, sc["params"], sub, gids, sc["colliders"], sc["cell_width"], sc["grid_capacity"], lo, hi, r > 0, r < 2,
+                                  particle_capacity=ps.n, model=sc["model"], uniform_material=uniform_material_of(ps),
+                                  halo_capacity_records=512, migrant_capacity=4096))
+    for _ in range(k // 10):
+        native_lockstep(pipe, shards, 10)
+        for s in shards:
+            s.sync()
+    st = [s.stats() for s in shards]
+    assert all(x["overflow"] == 0 for x in st), st
+    assert all(x["table_rebuilds"] <= 1 for x in st), [x["table_rebuilds"] for x in st]
+    assert sum(x["block_ids_free"] + x["table_marks"] for x in st) > 0, "no slab evicted a block"
+    assert [s.num_particles() for s in shards][0] == 0
+    outs = [s.export() for s in shards]
+    ids = np.concatenate([o["ids"] for o in outs])
+    assert np.array_equal(np.sort(ids), np.arange(ps.n, dtype=np.uint32))
+    order = np.argsort(ids)
+    for f, tol in (("pos", 1e-5), ("vel", 1e-5), ("def_grad", 1e-5)):
+        err = rel_rms(np.concatenate([o[f] for o in outs])[order], getattr(ref, f))
+        report_margin(f"slabs evicting a body's trail {f}", err, tol)
+        assert err < tol, (f, err)
+
+
 @pytest.mark.parametrize("name", ["mesh_floor3d", "polyline2d"])
 def test_mesh_colliders_on_sharded_data(hip_libs, name):
     """Mesh colliders (rigid-particle samples) on slabs: every slab holds every sample, the node cdfs of the

@@ -1,7 +1,7 @@
 """Developer utility: long lockstep runs of a bar cut into slabs (particles sloshing across the cuts, table rebuilds inside the run);
 no particle may be lost or doubled, nothing may overflow, everything stays finite."""
 import os, sys, time; sys.path.insert(0, '.'); sys.path.insert(0, 'tests')
-os.environ.setdefault("WGS_REHASH_PERIOD", "256")
+if os.environ.get("WGS_SOAK_NO_PERIOD") != "1": os.environ.setdefault("WGS_REHASH_PERIOD", "256")   # (WGS_SOAK_NO_PERIOD=1: no periodic rebuild — eviction keeps the slabs' tables instead)
 import numpy as np
 from helpers import pipeline
 from gpu_common import _native_slabs

@@ -194,7 +194,7 @@ wgs_status alloc_grid(wgs_data *d) {
     GRID_ALLOC(&dev.hkeys, hcap);
     GRID_ALLOC(&dev.hvals, hcap);
     GRID_ALLOC(&dev.block_key, cap);
-    if (!dev.sharded && !(dev.dbg & 1024u)) {   // (eviction of blocks long inactive: single-domain data; WGS_DEBUG bit 10 = never, the table is rebuilt instead)
+    if (!(dev.dbg & 1024u)) {   // (eviction of blocks long inactive — slabs of a decomposition too since round 6; WGS_DEBUG bit 10 = never, the table is rebuilt instead)
         GRID_ALLOC(&dev.block_slot, cap);
         GRID_ALLOC(&dev.free_ids, cap);
     }
@@ -1200,7 +1200,7 @@ static wgs_status create_impl(wgs_pipeline *pipeline, const wgs_sim_params *para
     st = alloc_grid(d);
     if (st != WGS_OK) return bail(st);
     // data that evicts its long-inactive blocks needs no periodic table rebuild (the marks the evictions leave are cleared by
-    // k_table_refresh, without touching a particle); slabs keep the period
+    // k_table_refresh, without touching a particle) — slabs of a decomposition included since round 6
     if (dev.free_ids != nullptr && !getenv("WGS_REHASH_PERIOD")) d->rehash_period = 0u;
     TRY_ALLOC(&dev.counters, (size_t)CTR_COUNT);
     TRY_ALLOC(&d->sp, (size_t)1);

@@ -467,13 +467,13 @@ __device__ __forceinline__ uint32_t regroup_block(const Dev &d, int side, uint32
     if (lane < 16) link = d.nbr_known[id * 16u + lane_p];
     const GroupLoads grp = block_prefix_loads(d, id, lane);
     if (stamp != epoch) {  // wave-uniform: not active in this substep
-        // EVICTION (single-domain data): a block nobody activated for EVICT_AGE substeps leaves the table — its slot is marked KEY_TOMB,
+        // EVICTION: a block nobody activated for EVICT_AGE substeps leaves the table — its slot is marked KEY_TOMB,
         // its id goes on the free list the next insertion takes from. The table and the ids then live as long as the simulation moves
         // slowly enough for the marks not to crowd the table (the host watches CTR_NTOMB), instead of being rebuilt from every particle —
         // a k_bin launch and a regrouping of everything, ~0.65 ms at 1 M particles — whenever three quarters of the ids were handed out
         // (a body crossing the grid: every few hundred substeps). Whoever still holds the id as "a neighbour that is in the table"
         // (nbr_known) compares the key before trusting it: block_key of an evicted id is NONE until the id is handed out again.
-        if constexpr (!SHARD) {
+        {
             // (bounded on the device: while the marks hold a quarter of the table's 2 x cap slots nobody is evicted — live blocks + marks
             // then stay below 1.5 x cap whatever the host's look is late by, and a probe sequence always ends: the host clears the marks,
             // capi.hip maintain_grid -> k_table_refresh, and eviction goes on)

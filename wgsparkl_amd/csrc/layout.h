@@ -191,7 +191,7 @@ struct Dev {
     uint32_t cap;        // block capacity
     // per physical block id (ids persist while the block stays in the hash map)
     uint32_t *block_key;   // cap: packed virtual id (NONE: the id is on the free list — the block was evicted)
-    uint32_t *block_slot;  // cap: the table slot that holds the block's key (what an eviction marks); null: no eviction on this data (slabs)
+    uint32_t *block_slot;  // cap: the table slot that holds the block's key (what an eviction marks); null: no eviction on this data (WGS_DEBUG bit 10)
     uint32_t *free_ids;    // cap: ids of evicted blocks, a stack of counters[CTR_NFREE] entries (pushed by launch 2 of the sort, popped by insertions)
     uint32_t *block_stamp; // cap: epoch of the last substep in which the block was active
     uint32_t *links_epoch; // cap: epoch at which nbr_plus / nbr_minus of the block were last written
