@@ -59,7 +59,9 @@ for rep in range(2):
         print(f"   visits of the list walk: {len(vv)} rows")
         for k, n in enumerate(names):
             ww = vv[vv[:, 1 + k] > 0]
-            if len(ww): print(f"      {n:32s} mean {((ww[:, 1 + k] - ww[:, 0]) / 100.0).mean():7.2f} us since the visit's start")
+            if len(ww):
+                dd = (ww[:, 1 + k] - ww[:, 0]) / 100.0
+                print(f"      {n:32s} mean {dd.mean():7.2f}  p10 {np.percentile(dd, 10):6.2f}  p50 {np.percentile(dd, 50):6.2f}  p90 {np.percentile(dd, 90):6.2f} us since the visit's start")
         o = np.argsort(vv[:, 0]); 
     st = np.sort((w[:, 0] - t0) / 100.0)
     print("   wave start times (us) deciles:", [round(float(x), 1) for x in np.percentile(st, [0, 10, 25, 50, 75, 90, 100])])
