@@ -196,12 +196,11 @@ template <int N> __device__ inline float det_small(const float *m) {
 // lanes active). The tile's nodes live in b and its 7 "+" neighbours: lanes 0..7 of every wave fetch the links once,
 // then ALL node loads of the thread are issued before the first LDS store — two dependent round trips per tile instead
 // of two per 64 / NT nodes.
-template <int D, int NT> __device__ __forceinline__ void stage_node_cdf_tile(const Dev &d, uint32_t b, NodeCdf *s_cdf, int tid) {
+// (`link`: lanes 0..7 of every wave hold nbr_plus[b * 8 + lane] — a caller that knows the block a round trip before it stages the tile asks for the links
+// then: the list walk of the fused G2P, whose visit entry names the block while the sort entries of its particles are still on their way)
+template <int D, int NT> __device__ __forceinline__ void stage_node_cdf_tile_links(const Dev &d, uint32_t link, NodeCdf *s_cdf, int tid) {
     constexpr int BW = Dim<D>::BW, BS = Dim<D>::BSHIFT, TW = Dim<D>::TW, TILE = Dim<D>::TILE;
     constexpr int K = (TILE + NT - 1) / NT;
-    const int lane = tid & 63;
-    uint32_t link = NONE;
-    if (lane < 8) link = d.nbr_plus[b * 8u + (uint32_t)lane];
     NodeCdf c[K];
 #pragma unroll
     for (int k = 0; k < K; k++) {
@@ -222,6 +221,13 @@ template <int D, int NT> __device__ __forceinline__ void stage_node_cdf_tile(con
         const int n = tid + k * NT;
         if (n < TILE) s_cdf[n] = c[k];
     }
+}
+
+template <int D, int NT> __device__ __forceinline__ void stage_node_cdf_tile(const Dev &d, uint32_t b, NodeCdf *s_cdf, int tid) {
+    const int lane = tid & 63;
+    uint32_t link = NONE;
+    if (lane < 8) link = d.nbr_plus[b * 8u + (uint32_t)lane];
+    stage_node_cdf_tile_links<D, NT>(d, link, s_cdf, tid);
 }
 
 // g2p_cdf.wgsl:39-250 for one particle (`src` = its slot in the buffer): affinity / sign bits, distance and normal
